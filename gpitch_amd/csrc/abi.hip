@@ -1,0 +1,252 @@
+// abi.hip — extern "C" entry points of libgpitch_hip.so (see include/gpitch_abi.h).
+#include "engine.h"
+#include <string.h>
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------------
+// timers
+GpTimerScope::GpTimerScope(gp_handle h_, int which_) : h(h_), which(which_) {
+  if (!h || !h->timers_on) return;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+  };
+  e0 = get(); e1 = get();
+  if (e0) (void)hipEventRecord(e0, h->stream);
+}
+GpTimerScope::~GpTimerScope() {
+  if (!h || !h->timers_on || !e0 || !e1) return;
+  (void)hipEventRecord(e1, h->stream);
+  h->pending.push_back({e0, e1, which});
+}
+
+static gp_status drain_timers(gp_handle h) {
+  for (auto& r : h->pending) {
+    GP_HIP_CHECK(h, hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    GP_HIP_CHECK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+    h->timer_ms[r.which] += ms;
+    h->timer_n[r.which] += 1;
+    h->event_pool.push_back(r.e0);
+    h->event_pool.push_back(r.e1);
+  }
+  h->pending.clear();
+  return GP_OK;
+}
+
+extern "C" {
+
+int32_t gp_abi_version(void) { return GPITCH_ABI_VERSION; }
+
+gp_status gp_create(int32_t device_id, void* stream, gp_handle* out) {
+  if (!out) return GP_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GP_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= count) return GP_ERR_BAD_ARG;
+  gp_handle h = new gp_handle_s();
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete h; return GP_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete h; return GP_ERR_HIP; }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete h; return GP_ERR_NO_DEVICE; }
+  h->num_cus = prop.multiProcessorCount;
+  // NULL selects HIP's default (null) stream — the one torch and plain HIP code use unless told otherwise,
+  // so work enqueued here is ordered with the caller's other device work without extra events.
+  h->stream = (hipStream_t)stream;
+  h->own_stream = false;
+  if (hipMalloc((void**)&h->d_status, 4 * sizeof(int32_t)) != hipSuccess) { delete h; return GP_ERR_HIP; }
+  (void)hipMemsetAsync(h->d_status, 0, 4 * sizeof(int32_t), h->stream);
+  *out = h;
+  return GP_OK;
+}
+
+gp_status gp_destroy(gp_handle h) {
+  if (!h) return GP_OK;
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& r : h->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : h->event_pool) (void)hipEventDestroy(e);
+  if (h->d_status) (void)hipFree(h->d_status);
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return GP_OK;
+}
+
+gp_status gp_sync(gp_handle h) {
+  if (!h) return GP_ERR_BAD_ARG;
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return GP_OK;
+}
+
+const char* gp_last_error(gp_handle h) { return h ? h->last_error.c_str() : "null handle"; }
+int32_t gp_last_not_pd_index(gp_handle h) { return h ? h->not_pd_index : -1; }
+
+gp_status gp_timers_enable(gp_handle h, int32_t on) { if (!h) return GP_ERR_BAD_ARG; h->timers_on = (on != 0); return GP_OK; }
+gp_status gp_timers_reset(gp_handle h) {
+  if (!h) return GP_ERR_BAD_ARG;
+  GP_CHECK(drain_timers(h));
+  for (int i = 0; i < GP_TIMER_COUNT; i++) { h->timer_ms[i] = 0; h->timer_n[i] = 0; }
+  return GP_OK;
+}
+gp_status gp_timers_read(gp_handle h, int32_t which, double* total_ms, int64_t* launches) {
+  if (!h || which < 0 || which >= GP_TIMER_COUNT) return GP_ERR_BAD_ARG;
+  GP_CHECK(drain_timers(h));
+  if (total_ms) *total_ms = h->timer_ms[which];
+  if (launches) *launches = h->timer_n[which];
+  return GP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L2 operators
+static bool kern_ok(const gp_kernel_desc* k) {
+  if (!k || !k->theta) return false;
+  if (k->type < GP_KERN_MATERN12 || k->type > GP_KERN_MATERN12SM) return false;
+  if ((k->type == GP_KERN_MERCER_MATERN12SM || k->type == GP_KERN_MATERN12SM) && k->num_partials < 1) return false;
+  return true;
+}
+
+gp_status gp_kernel_build(gp_handle h, const gp_kernel_desc* kern, const double* x1, int32_t n1, const double* x2,
+                          int32_t n2, double* out, int64_t ld, int32_t accumulate) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!kern_ok(kern) || !x1 || !out || n1 < 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_kernel_build: bad argument");
+  if (!x2) n2 = n1;
+  if (n2 < 0 || ld < n2) return gp_fail(h, GP_ERR_BAD_ARG, "gp_kernel_build: bad n2/ld");
+  if (n1 == 0 || n2 == 0) return GP_OK;
+  DevKern k = dev_kern(kern);
+  double* feat = nullptr;
+  if (k.type == GP_KERN_MERCER_MATERN12SM) {
+    // one-shot operator: the feature scratch is a transient allocation (the plans carry their own)
+    size_t nd = kernel_build_feat_ws_doubles(k.m, n1, x2 ? n2 : n1);
+    GP_HIP_CHECK(h, hipMallocAsync((void**)&feat, nd * sizeof(double), h->stream));
+  }
+  gp_status s = launch_kernel_build(h, k, x1, n1, x2, n2, out, ld, accumulate, 0.0, feat);
+  if (feat) GP_HIP_CHECK(h, hipFreeAsync(feat, h->stream));
+  return s;
+}
+
+gp_status gp_kernel_diag(gp_handle h, const gp_kernel_desc* kern, int32_t n, double* out, int32_t accumulate) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!kern_ok(kern) || !out || n < 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_kernel_diag: bad argument");
+  return launch_kernel_diag(h, dev_kern(kern), n, out, accumulate);
+}
+
+size_t gp_chol_workspace_bytes(int32_t M) {
+  if (M <= 0) return 256;
+  return gp_align_up((size_t)M * M * sizeof(double), 256) + gp_align_up(kernel_build_feat_ws_doubles(32, M, M) * sizeof(double), 256);
+}
+
+gp_status gp_kuu_cholesky(gp_handle h, const gp_kernel_desc* kern, const double* z, int32_t M, double jitter, double* L,
+                          double* Linv, void* workspace, size_t workspace_bytes) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!kern_ok(kern) || !z || M <= 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_kuu_cholesky: bad argument");
+  GpArena ar(workspace, workspace_bytes);
+  double* Lbuf = L ? L : ar.take<double>((size_t)M * M);
+  DevKern k = dev_kern(kern);
+  double* feat = (k.type == GP_KERN_MERCER_MATERN12SM) ? ar.take<double>(kernel_build_feat_ws_doubles(k.m, M, M)) : nullptr;
+  if (!ar.ok || !Lbuf) return gp_fail(h, GP_ERR_WORKSPACE, "gp_kuu_cholesky: workspace too small");
+  GP_CHECK(launch_kernel_build(h, k, z, M, nullptr, M, Lbuf, M, 0, jitter, feat));
+  GP_CHECK(launch_cholesky_single(h, Lbuf, M, M));
+  if (Linv) GP_CHECK(launch_tri_inverse_single(h, Lbuf, Linv, M, M));
+  return check_not_pd(h);
+}
+
+gp_status gp_cholesky_inplace(gp_handle h, double* A, int32_t M, int64_t ld) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!A || M <= 0 || ld < M) return gp_fail(h, GP_ERR_BAD_ARG, "gp_cholesky_inplace: bad argument");
+  GP_CHECK(launch_cholesky_single(h, A, M, ld));
+  return check_not_pd(h);
+}
+
+size_t gp_conditional_workspace_bytes(int32_t N, int32_t M) {
+  if (N <= 0 || M <= 0) return 256;
+  return cond_task_workspace_doubles(M, N, 32, false) * sizeof(double) + cond_batch_desc_bytes(1) + 4096;
+}
+
+gp_status gp_conditional_diag(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N, const double* z,
+                              int32_t M, const double* q_mu, const double* q_sqrt, int32_t whiten, double jitter,
+                              double* fmean, double* fvar, void* workspace, size_t workspace_bytes) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!kern_ok(kern) || !xnew || !z || !q_mu || !fmean || !fvar || N < 0 || M <= 0)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_conditional_diag: bad argument");
+  if (N == 0) return GP_OK;
+  GpArena ar(workspace, workspace_bytes);
+  CondBatch cb;
+  cb.tasks.resize(1);
+  CondTask& t = cb.tasks[0];
+  t.kern = dev_kern(kern); t.z = z; t.M = M; t.q_mu = q_mu; t.q_sqrt = q_sqrt; t.fmean = fmean; t.fvar = fvar;
+  cb.desc_bytes = cond_batch_desc_bytes(1);
+  cb.d_desc = ar.take<char>(cb.desc_bytes);
+  if (!cond_task_carve(ar, t, N, whiten != 0) || !cb.d_desc)
+    return gp_fail(h, GP_ERR_WORKSPACE, "gp_conditional_diag: workspace too small");
+  cb.N = N;
+  GP_CHECK(cond_batch_upload(h, cb, whiten != 0));
+  GP_CHECK(cond_batch_run(h, cb, xnew, N, whiten != 0, jitter));
+  return check_not_pd(h);
+}
+
+gp_status gp_mpd_varexp(gp_handle h, const double* Fmu, const double* Fvar, const double* y, int32_t N, int32_t P,
+                        int32_t nlin, const double* noise_var, double* per_frame, double* sum_host) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!Fmu || !Fvar || !y || !noise_var || N < 0 || P < 1 || nlin < 0 || nlin > 2)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_mpd_varexp: bad argument");
+  if (N == 0) { if (sum_host) *sum_host = 0.0; return GP_OK; }
+  int blocks = (N + 255) / 256;
+  double* partial = nullptr;
+  if (sum_host) GP_HIP_CHECK(h, hipMallocAsync((void**)&partial, (2 * (size_t)blocks + 2) * sizeof(double), h->stream));
+  int nb = 0;
+  gp_status s = launch_mpd_lik(h, Fmu, Fvar, (int64_t)2 * P, 1, y, N, P, nlin, noise_var, 1.0, per_frame, partial, &nb,
+                               nullptr, nullptr);
+  if (s == GP_OK && sum_host) {
+    double* res = partial + 2 * (size_t)blocks;
+    s = launch_finish_sum(h, partial, nb, 2, 1, res, 1.0, 0);
+    if (s == GP_OK) {
+      GP_HIP_CHECK(h, hipMemcpyAsync(sum_host, res, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  if (partial) GP_HIP_CHECK(h, hipFreeAsync(partial, h->stream));
+  return s;
+}
+
+gp_status gp_gauss_kl(gp_handle h, const double* q_mu, const double* q_sqrt, int32_t M, const gp_kernel_desc* kern,
+                      const double* z, double jitter, double* out_host, void* workspace, size_t workspace_bytes) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!q_mu || !q_sqrt || M < 1 || !out_host) return gp_fail(h, GP_ERR_BAD_ARG, "gp_gauss_kl: bad argument");
+  GpArena ar(workspace, workspace_bytes);
+  char* d_item = ar.take<char>(kl_item_bytes());
+  double* d_out = ar.take<double>(4);
+  if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, "gp_gauss_kl: workspace too small (need >= 4 KiB)");
+  if (kern) {
+    (void)z; (void)jitter;
+    return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_gauss_kl: K != None (unwhitened) not implemented yet");
+  }
+  std::vector<char> item(kl_item_bytes());
+  kl_item_fill(item.data(), q_mu, q_sqrt, M, d_out, nullptr, nullptr);
+  GP_HIP_CHECK(h, hipMemcpyAsync(d_item, item.data(), item.size(), hipMemcpyHostToDevice, h->stream));
+  GP_CHECK(launch_kl_white(h, d_item, 1));
+  GP_HIP_CHECK(h, hipMemcpyAsync(out_host, d_out, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return GP_OK;
+}
+
+gp_status gp_transform_forward(gp_handle h, const double* fs, const uint8_t* tcode, int64_t n, double* params) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!fs || !tcode || !params || n < 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_transform_forward: bad argument");
+  return launch_transform_forward(h, fs, tcode, n, params);
+}
+gp_status gp_transform_backward(gp_handle h, const double* params, const uint8_t* tcode, int64_t n, double* fs) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!fs || !tcode || !params || n < 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_transform_backward: bad argument");
+  return launch_transform_backward(h, params, tcode, n, fs);
+}
+gp_status gp_adam_step(gp_handle h, double* fs, double* params, const double* grad, const uint8_t* tcode, double* m,
+                       double* v, int64_t n, int64_t t, double lr, double beta1, double beta2, double eps) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!fs || !params || !grad || !tcode || !m || !v || n < 0 || t < 1)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_adam_step: bad argument");
+  return launch_adam(h, fs, params, grad, tcode, m, v, n, t, lr, beta1, beta2, eps);
+}
+
+}  // extern "C"

@@ -1,0 +1,456 @@
+// bwd.hip — hand-written reverse pass of the whitened Pdgp ELBO (what TF autodiff supplies to
+// gpflow Model.optimize in the reference, gpitch/pdgp.py:133-170 via demo-modgp.py:44-45).
+//
+// With A = W Kuf (W = L^-1), B = Lq^T A, fmean = A^T mu, fvar = kdiag - colsum(A^2) + colsum(B^2) and
+// upstream gm = dELBO/dfmean, gv = dELBO/dfvar (N-vectors per latent GP), D = diag(2 gv):
+//   H     = A D A^T                      (split-K product over the frames, symmetric)
+//   u     = A gm                          -> d/d mu
+//   d/dLq = tril(H Lq)
+//   E     = Lq Lq^T - I
+//   Wbar  = tril(E H L^T + mu (L u)^T)    (uses Kuf = L A, so no second pass over the frames)
+//   Kuf_bar = R (A D) + alpha gm^T,  R = W^T E,  alpha = W^T mu      (one dense strip GEMM)
+//   Lbar  = -tril(W^T Wbar W^T);  P = Phi(L^T Lbar);  S = W^T P W;  Kuu_bar = (S + S^T)/2
+// and the hyper-parameter / inducing-input gradients are contractions of Kuf_bar and Kuu_bar with the
+// analytic kernel derivatives, evaluated on the fly.
+#include "pdgp_plan.h"
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------
+// small batched vector / matrix kernels (problem fields reused; see each kernel)
+
+// o0[i] = sum_n A[i][n] * v0[n];  if o1: o1[i] += that.   grid (M, batch)
+__global__ void __launch_bounds__(256) rowdot_kernel(const GemmProblem* __restrict__ probs) {
+  const GemmProblem p = probs[blockIdx.y];
+  const int i = blockIdx.x;
+  if (i >= p.M) return;
+  const double* row = p.A + (int64_t)i * p.lda;
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < p.N; n += 256) acc = fma(row[n], p.v0[n], acc);
+  __shared__ double red[4];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = (red[0] + red[1]) + (red[2] + red[3]);
+    p.o0[i] = s;
+    if (p.o1) p.o1[i] += s;
+  }
+}
+
+// C[i][i] -= 1
+__global__ void __launch_bounds__(256) sub_identity_kernel(const GemmProblem* __restrict__ probs) {
+  const GemmProblem p = probs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < p.M) p.C[(int64_t)i * p.ldc + i] -= 1.0;
+}
+
+// C = Phi(C): lower triangle kept, diagonal halved, strictly-upper zeroed
+__global__ void __launch_bounds__(256) phi_kernel(const GemmProblem* __restrict__ probs) {
+  const GemmProblem p = probs[blockIdx.y];
+  const int64_t total = (int64_t)p.M * p.M;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx / p.M), j = (int)(idx % p.M);
+    double* c = p.C + (int64_t)i * p.ldc + j;
+    if (j > i) *c = 0.0;
+    else if (j == i) *c *= 0.5;
+  }
+}
+
+// C[i][j] += v0[i] * v1[j] for j <= i
+__global__ void __launch_bounds__(256) rank1_tril_kernel(const GemmProblem* __restrict__ probs) {
+  const GemmProblem p = probs[blockIdx.y];
+  const int64_t total = (int64_t)p.M * p.M;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx / p.M), j = (int)(idx % p.M);
+    if (j <= i) p.C[(int64_t)i * p.ldc + j] += p.v0[i] * p.v1[j];
+  }
+}
+
+// o0 = op(A) v0, A is M x M (lda); trans: o0[j] = sum_i A[i][j] v0[i].   grid (M, batch), one block per output
+__global__ void __launch_bounds__(64) matvec_kernel(const GemmProblem* __restrict__ probs, int trans) {
+  const GemmProblem p = probs[blockIdx.y];
+  const int r = blockIdx.x;
+  if (r >= p.M) return;
+  double acc = 0.0;
+  if (!trans) for (int k = threadIdx.x; k < p.M; k += 64) acc = fma(p.A[(int64_t)r * p.lda + k], p.v0[k], acc);
+  else        for (int k = threadIdx.x; k < p.M; k += 64) acc = fma(p.A[(int64_t)k * p.lda + r], p.v0[k], acc);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (threadIdx.x == 0) p.o0[r] = acc;
+}
+
+static int ew_grid(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 512 ? 512 : (b < 1 ? 1 : b)); }
+
+gp_status launch_rowdot_batched(gp_handle h, const GemmProblem* d, int batch, int maxM) {
+  hipLaunchKernelGGL(rowdot_kernel, dim3(maxM, batch), dim3(256), 0, h->stream, d);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+gp_status launch_sub_identity_batched(gp_handle h, const GemmProblem* d, int batch, int maxM) {
+  hipLaunchKernelGGL(sub_identity_kernel, dim3((maxM + 255) / 256, batch), dim3(256), 0, h->stream, d);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+gp_status launch_phi_batched(gp_handle h, const GemmProblem* d, int batch, int maxM) {
+  hipLaunchKernelGGL(phi_kernel, dim3(ew_grid((int64_t)maxM * maxM), batch), dim3(256), 0, h->stream, d);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+gp_status launch_rank1_tril_batched(gp_handle h, const GemmProblem* d, int batch, int maxM) {
+  hipLaunchKernelGGL(rank1_tril_kernel, dim3(ew_grid((int64_t)maxM * maxM), batch), dim3(256), 0, h->stream, d);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+gp_status launch_matvec_batched(gp_handle h, const GemmProblem* d, int batch, int maxM, int trans) {
+  hipLaunchKernelGGL(matvec_kernel, dim3(maxM, batch), dim3(64), 0, h->stream, d, trans);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hyper-parameter contraction:  sums[s] = sum_{i,j} Gw[i][j] * dK[i][j]/dtheta_s
+//   Gw[i][j] = G[i*ldg + j] (+ alpha[i]*gm[j])            (Kuf side, symmetric = 0)
+//   Gw[i][j] = (G[i][j] + G[j][i]) / 2                     (Kuu side, symmetric = 1, x2 == x1)
+// layout of the sums: [d_variance, d_lengthscales, d_energy_0.., d_frequency_0..]  (2 + 2m)
+// gz_part[colblock][i] = sum_{j in block} Gw[i][j] * dK[i][j]/dx1_i
+#define HY_THREADS 256
+#define HY_ROWS 32
+
+int hyper_num_sums(int m) { return 2 + 2 * m; }
+
+template <int MMAX>
+__global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, const double* __restrict__ x1, int n1,
+                                                                    const double* __restrict__ x2, int n2,
+                                                                    const double* __restrict__ G, int64_t ldg,
+                                                                    const double* __restrict__ alpha,
+                                                                    const double* __restrict__ gm, int symmetric,
+                                                                    const double* __restrict__ f1,
+                                                                    const double* __restrict__ f2,
+                                                                    double* __restrict__ partials,
+                                                                    double* __restrict__ gz_part) {
+  extern __shared__ double smem[];  // [HY_ROWS][2m] row features, then reduction scratch
+  const double* th = k.theta;
+  const double var = th[0], ls = th[1];
+  const int m = k.m;
+  const int j = blockIdx.x * HY_THREADS + threadIdx.x;
+  const int i0 = blockIdx.y * HY_ROWS;
+  const int iend = min(i0 + HY_ROWS, n1);
+  const bool sm = (k.type == GP_KERN_MERCER_MATERN12SM);
+  double* fzs = smem;
+  double* red = smem + (sm ? HY_ROWS * 2 * m : 0);  // [4 waves][max(2+2m, HY_ROWS)]
+  if (sm) {
+    for (int t = threadIdx.x; t < HY_ROWS * 2 * m; t += HY_THREADS) {
+      int q = t / HY_ROWS, ii = t % HY_ROWS;
+      fzs[ii * 2 * m + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
+    }
+  }
+  __syncthreads();
+  const bool live = (j < n2);
+  const int jc = live ? j : n2 - 1;
+  const double xb = x2[jc];
+  const double b = xb / ls, bb = __dmul_rn(b, b);
+  const double gmj = (gm && live) ? gm[jc] : 0.0;
+  double fxc[MMAX], fxs[MMAX];  // column features: sqrt(e_q) cos / sin (static indices only)
+#pragma unroll
+  for (int q = 0; q < MMAX; q++) {
+    fxc[q] = (sm && q < m) ? f2[(size_t)q * n2 + jc] : 0.0;
+    fxs[q] = (sm && q < m) ? f2[(size_t)(q + m) * n2 + jc] : 0.0;
+  }
+  double acc_v = 0.0, acc_l = 0.0;
+  double acc_e[MMAX], acc_f[MMAX];
+#pragma unroll
+  for (int q = 0; q < MMAX; q++) { acc_e[q] = 0.0; acc_f[q] = 0.0; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  for (int i = i0; i < iend; i++) {
+    const double xa = x1[i];
+    double w = 0.0;
+    if (live) {
+      w = G[(int64_t)i * ldg + j];
+      if (symmetric) w = 0.5 * (w + G[(int64_t)j * ldg + i]);
+      if (alpha) w = fma(alpha[i], gmj, w);
+    }
+    const double a = xa / ls, aa = __dmul_rn(a, a);
+    const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b), aa), bb);
+    const double d = xa - xb;
+    double dz = 0.0;  // w * dK/dx1
+    if (k.type == GP_KERN_RBF) {
+      const double e = exp(-0.5 * r2);
+      acc_v = fma(w, e, acc_v);
+      acc_l = fma(w, var * e * r2 / ls, acc_l);
+      dz = -w * var * e * d / (ls * ls);
+    } else {
+      const double r = __dsqrt_rn(__dadd_rn(r2, 1e-12));
+      if (sm) {
+        const double E = exp(-r);
+        double S = 0.0, Ssin = 0.0;
+        const double* fz = &fzs[(i - i0) * 2 * m];
+        const double wvE = w * var * E;
+#pragma unroll
+        for (int q = 0; q < MMAX; q++) {
+          if (q < m) {
+            const double zc = fz[q], zs = fz[q + m];
+            const double xc = fxc[q], xs = fxs[q];
+            const double cc = fma(zc, xc, zs * xs);   // e_q cos(w_q d)
+            const double ss = fma(zs, xc, -zc * xs);  // e_q sin(w_q d)
+            const double eq = th[2 + q], fq = th[2 + m + q];
+            S += cc;
+            Ssin = fma(ss, 6.283185307179586 * fq, Ssin);
+            acc_e[q] = fma(wvE, cc / eq, acc_e[q]);
+            acc_f[q] = fma(-wvE * 6.283185307179586 * d, ss, acc_f[q]);
+          }
+        }
+        acc_v = fma(w * E, S, acc_v);
+        acc_l = fma(wvE * S, r2 / (ls * r), acc_l);
+        dz = wvE * (-S * d / (ls * ls * r) - Ssin);
+      } else {
+        double phi, dphi;  // K = var * phi(r), dphi = phi'(r)
+        if (k.type == GP_KERN_MATERN12) { phi = exp(-r); dphi = -phi; }
+        else if (k.type == GP_KERN_MATERN32) {
+          const double s3 = 1.7320508075688772, e = exp(-s3 * r);
+          phi = (1.0 + s3 * r) * e; dphi = -3.0 * r * e;
+        } else {
+          const double s5 = 2.23606797749979, e = exp(-s5 * r);
+          phi = (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e; dphi = -(5.0 / 3.0) * r * (1.0 + s5 * r) * e;
+        }
+        acc_v = fma(w, phi, acc_v);
+        acc_l = fma(w * var * dphi, -r2 / (ls * r), acc_l);
+        dz = w * var * dphi * d / (ls * ls * r);
+      }
+    }
+    if (gz_part) {
+      for (int o = 32; o > 0; o >>= 1) dz += __shfl_down(dz, o, 64);
+      if (lane == 0) red[wave * HY_ROWS + (i - i0)] = dz;
+    }
+  }
+  if (gz_part) {
+    __syncthreads();
+    if (threadIdx.x < HY_ROWS && i0 + (int)threadIdx.x < n1) {
+      const int t = threadIdx.x;
+      double s = (red[0 * HY_ROWS + t] + red[1 * HY_ROWS + t]) + (red[2 * HY_ROWS + t] + red[3 * HY_ROWS + t]);
+      gz_part[(int64_t)blockIdx.x * n1 + i0 + t] = symmetric ? 2.0 * s : s;
+    }
+    __syncthreads();
+  }
+  // block-reduce the (2 + 2m) sums
+  const int ns = 2 + 2 * m;
+  auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+  double rv = wred(acc_v), rl = wred(acc_l);
+  if (lane == 0) { red[wave * ns + 0] = rv; red[wave * ns + 1] = rl; }
+#pragma unroll
+  for (int q = 0; q < MMAX; q++) {
+    if (q < m) {
+      double re = wred(acc_e[q]), rf = wred(acc_f[q]);
+      if (lane == 0) { red[wave * ns + 2 + q] = re; red[wave * ns + 2 + m + q] = rf; }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ns) {
+    const int t = threadIdx.x;
+    const double s = (red[0 * ns + t] + red[1 * ns + t]) + (red[2 * ns + t] + red[3 * ns + t]);
+    partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ns + t] = s;
+  }
+}
+
+gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
+                                const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
+                                const double* feat, double* partials, int* nparts, double* gz_partials) {
+  if (k.type == GP_KERN_MATERN12SM) return gp_fail(h, GP_ERR_UNSUPPORTED, "gradient of Matern12sm is not implemented");
+  GpTimerScope ts(h, GP_TIMER_HYPER);
+  const bool sm = (k.type == GP_KERN_MERCER_MATERN12SM);
+  const double* f1 = feat;
+  const double* f2 = (x2 == x1 || !feat) ? feat : feat + gp_align_up((size_t)2 * k.m * n1, 32);
+  dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + HY_ROWS - 1) / HY_ROWS);
+  const int ns = 2 + 2 * k.m;
+  const int redw = ns > HY_ROWS ? ns : HY_ROWS;
+  size_t sh = ((sm ? (size_t)HY_ROWS * 2 * k.m : 0) + 4 * (size_t)redw) * sizeof(double);
+  if (!sm || k.m <= 0) {
+    hipLaunchKernelGGL((hyper_contract_kernel<1>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
+                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
+  } else if (k.m <= 8) {
+    hipLaunchKernelGGL((hyper_contract_kernel<8>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
+                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
+  } else if (k.m <= 16) {
+    hipLaunchKernelGGL((hyper_contract_kernel<16>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
+                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
+  } else {
+    hipLaunchKernelGGL((hyper_contract_kernel<32>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
+                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
+  }
+  GP_HIP_CHECK(h, hipGetLastError());
+  if (nparts) *nparts = grid.x * grid.y;
+  return GP_OK;
+}
+
+// g_theta[s] += sum of partials (+ kdiag term); g_z[i] += sum over column blocks
+__global__ void __launch_bounds__(256) hyper_finish_kernel(DevKern k, const double* __restrict__ partials, int nparts,
+                                                           const double* __restrict__ gv_sum,
+                                                           double* __restrict__ g_theta,
+                                                           const double* __restrict__ gz_part, int ncolblocks, int n1,
+                                                           double* __restrict__ g_z) {
+  const int ns = 2 + 2 * k.m;
+  const int s = blockIdx.x;
+  if (s < ns) {
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int c = threadIdx.x; c < nparts; c += 256) a += partials[(int64_t)c * ns + s];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      double v = red[0];
+      if (gv_sum) {  // d kdiag / d theta contribution: kdiag = var (stationary) or var * sum(e)
+        const double gs = gv_sum[0];
+        const bool smk = (k.type == GP_KERN_MERCER_MATERN12SM || k.type == GP_KERN_MATERN12SM);
+        if (s == 0) {
+          double se = 1.0;
+          if (smk) { se = 0.0; for (int q = 0; q < k.m; q++) se += k.theta[2 + q]; }
+          v += gs * se;
+        } else if (smk && s >= 2 && s < 2 + k.m) {
+          v += gs * k.theta[0];
+        }
+      }
+      g_theta[s] += v;
+    }
+  } else if (g_z && gz_part) {
+    // remaining blocks: z-gradient, 256 rows per block
+    const int i = (blockIdx.x - ns) * 256 + threadIdx.x;
+    if (i < n1) {
+      double a = 0.0;
+      for (int c = 0; c < ncolblocks; c++) a += gz_part[(int64_t)c * n1 + i];
+      g_z[i] += a;
+    }
+  }
+}
+
+gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, int nparts, const double* gv_sum,
+                              double* g_theta, const double* gz_partials, int ncolblocks, int n1, double* g_z) {
+  const int ns = 2 + 2 * k.m;
+  int blocks = ns + ((g_z && gz_partials) ? (n1 + 255) / 256 : 0);
+  hipLaunchKernelGGL(hyper_finish_kernel, dim3(blocks), dim3(256), 0, h->stream, k, partials, nparts, gv_sum, g_theta,
+                     gz_partials, ncolblocks, n1, g_z);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// orchestration
+enum BwdSlot { S_H = 0, S_U, S_HLQ, S_E, S_EH, S_WBAR, S_LU, S_RANK1, S_R, S_ALPHA, S_G, S_T2, S_LBAR, S_P, S_T3, S_S,
+               S_COUNT };
+
+static inline int64_t ldN_b(int N) { return (N + 1) & ~1; }
+
+gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad) {
+  (void)x;
+  const int G = p->G;
+  const size_t slot_bytes = gp_align_up(G * sizeof(GemmProblem), 256);
+  size_t base = gp_align_up(G * kl_item_bytes(), 256);
+  for (int s = 0; s < S_COUNT; s++) p->off_bwd[s] = base + s * slot_bytes;
+  const int64_t ldN = ldN_b(n);
+  size_t slab_off = 0;
+  for (int g = 0; g < G; g++) {
+    const PdgpGP& q = p->gps[g];
+    const CondTask& t = p->cb.tasks[g];
+    const BwdBufs& b = p->bw[g];
+    const int M = q.M;
+    const double* q_mu = params + q.off_qmu;
+    const double* q_sqrt = params + q.off_qsqrt;
+    const double* gm = p->gFmu + (size_t)g * n;
+    const double* gv = p->gFvar + (size_t)g * n;
+    auto P = [&](int slot) -> GemmProblem& {
+      GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + p->off_bwd[slot] + g * sizeof(GemmProblem));
+      memset(&r, 0, sizeof(r));
+      r.M = M; r.N = M; r.K = M; r.lda = M; r.ldb = M; r.ldc = M;
+      return r;
+    };
+    { GemmProblem& r = P(S_H); r.A = t.A; r.lda = ldN; r.B = t.A; r.ldb = ldN; r.K = n; r.v1 = gv; r.C = b.H;
+      r.o2 = p->slabs + slab_off; slab_off += gp_align_up((size_t)p->nsplit * M * M * sizeof(double), 256) / sizeof(double); }
+    { GemmProblem& r = P(S_U); r.A = t.A; r.lda = ldN; r.N = n; r.v0 = gm; r.o0 = b.u; r.o1 = grad + q.off_qmu; }
+    { GemmProblem& r = P(S_HLQ); r.A = b.H; r.B = q_sqrt; r.C = grad + q.off_qsqrt; }
+    { GemmProblem& r = P(S_E); r.A = q_sqrt; r.B = q_sqrt; r.C = b.E; }
+    { GemmProblem& r = P(S_EH); r.A = b.E; r.B = b.H; r.C = b.T1; }
+    { GemmProblem& r = P(S_WBAR); r.A = b.T1; r.B = t.L; r.C = b.Wbar; }
+    { GemmProblem& r = P(S_LU); r.A = t.L; r.v0 = b.u; r.o0 = b.Lu; }
+    { GemmProblem& r = P(S_RANK1); r.C = b.Wbar; r.v0 = q_mu; r.v1 = b.Lu; }
+    { GemmProblem& r = P(S_R); r.A = t.W; r.B = b.E; r.C = b.R; }
+    { GemmProblem& r = P(S_ALPHA); r.A = t.W; r.v0 = q_mu; r.o0 = b.alpha; }
+    { GemmProblem& r = P(S_G); r.A = b.R; r.B = t.A; r.ldb = ldN; r.N = n; r.v1 = gv; r.C = b.G; r.ldc = ldN; }
+    { GemmProblem& r = P(S_T2); r.A = t.W; r.B = b.Wbar; r.C = b.T2; }
+    { GemmProblem& r = P(S_LBAR); r.A = b.T2; r.B = t.W; r.C = b.T1; }
+    { GemmProblem& r = P(S_P); r.A = t.L; r.B = b.T1; r.C = b.T2; }
+    { GemmProblem& r = P(S_T3); r.A = t.W; r.B = b.T2; r.C = b.H; }
+    { GemmProblem& r = P(S_S); r.A = b.H; r.B = t.W; r.C = b.E; }
+  }
+  return GP_OK;
+}
+
+gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad) {
+  gp_handle h = p->h;
+  const int G = p->G, maxM = p->maxM;
+  const int64_t ldN = ldN_b(n);
+  auto D = [&](int slot) { return (const GemmProblem*)(p->d_misc + p->off_bwd[slot]); };
+  // H = A diag(2 gv) A^T  (symmetric, split-K over the frames)
+  GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
+  // u = A gm ; grad q_mu += u
+  GP_CHECK(launch_rowdot_batched(h, D(S_U), G, maxM));
+  // sum_n gv  (kdiag term)
+  for (int g = 0; g < G; g++)
+    GP_CHECK(launch_finish_sum(h, p->gFvar + (size_t)g * n, n, 1, 1, p->bw[g].gvsum, 1.0, 0));
+  GemmFlags f;
+  // grad q_sqrt += tril(H Lq)
+  f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
+  GP_CHECK(launch_gemm_batched(h, D(S_HLQ), G, maxM, maxM, f));
+  // E = Lq Lq^T - I
+  f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
+  GP_CHECK(launch_gemm_batched(h, D(S_E), G, maxM, maxM, f));
+  GP_CHECK(launch_sub_identity_batched(h, D(S_E), G, maxM));
+  // T1 = E H
+  f = GemmFlags();
+  GP_CHECK(launch_gemm_batched(h, D(S_EH), G, maxM, maxM, f));
+  // Wbar = tril(T1 L^T) + tril(mu (L u)^T)
+  f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D(S_WBAR), G, maxM, maxM, f));
+  GP_CHECK(launch_matvec_batched(h, D(S_LU), G, maxM, 0));
+  GP_CHECK(launch_rank1_tril_batched(h, D(S_RANK1), G, maxM));
+  // R = W^T E ; alpha = W^T mu
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
+  GP_CHECK(launch_gemm_batched(h, D(S_R), G, maxM, maxM, f));
+  GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), G, maxM, 1));
+  // Kuf_bar (dense part) = R (A diag(2 gv))
+  f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_STRIP_GEMM;
+  GP_CHECK(launch_gemm_batched(h, D(S_G), G, maxM, n, f));
+  // Kuu side: Lbar = -tril(W^T Wbar W^T); P = Phi(L^T Lbar); S = W^T P W
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D(S_T2), G, maxM, maxM, f));
+  f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
+  GP_CHECK(launch_gemm_batched(h, D(S_LBAR), G, maxM, maxM, f));
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D(S_P), G, maxM, maxM, f));
+  GP_CHECK(launch_phi_batched(h, D(S_P), G, maxM));
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D(S_T3), G, maxM, maxM, f));
+  f = GemmFlags(); f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D(S_S), G, maxM, maxM, f));
+  // hyper-parameter and inducing-input gradients
+  for (int g = 0; g < G; g++) {
+    const PdgpGP& q = p->gps[g];
+    const CondTask& t = p->cb.tasks[g];
+    const BwdBufs& b = p->bw[g];
+    const double* z = params + q.off_z;
+    const double* gm = p->gFmu + (size_t)g * n;
+    int np_uf = 0, np_uu = 0;
+    const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS, cb_uu = (q.M + HY_THREADS - 1) / HY_THREADS;
+    double* gz_uf = b.gz_part;
+    double* gz_uu = b.gz_part + (size_t)cb_uf * q.M;
+    GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, x, n, b.G, ldN, b.alpha, gm, 0, t.feat, b.hyp_part, &np_uf, gz_uf));
+    GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part, np_uf, b.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
+                                 grad + q.off_z));
+    GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, z, q.M, b.E, q.M, nullptr, nullptr, 1, t.feat, b.hyp_part_uu,
+                                   &np_uu, gz_uu));
+    GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part_uu, np_uu, nullptr, grad + q.off_theta, gz_uu, cb_uu, q.M,
+                                 grad + q.off_z));
+  }
+  return GP_OK;
+}

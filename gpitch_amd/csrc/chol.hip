@@ -1,0 +1,325 @@
+// chol.hip — dense fp64 Cholesky and triangular inverse on Kuu (gfx950).
+//
+// Replaces tf.cholesky / tf.matrix_triangular_solve on the M x M inducing covariance
+// (GPflow conditional from gpitch/pdgp.py:147; gpitch/sgpr_ss.py:44,48,51,53,89-94).
+//
+// One workgroup (8 wavefronts, two per SIMD) per matrix, many matrices per launch (one per latent GP).
+// Right-looking blocked factorisation, panel width 32:
+//   * the 32 x 32 diagonal block is factorised by ONE wavefront entirely in registers — lane i holds
+//     row i, pivots/columns are broadcast with v_readlane (no LDS round trips, no barriers);
+//   * the panel below is solved one row per lane against the factor held in LDS (broadcast reads);
+//   * the trailing SYRK update runs on the matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles
+//     dealt round-robin to the 8 wavefronts, lower triangle only.
+// The inverse W = L^-1 inverts the diagonal blocks in registers the same way, then each wavefront
+// walks one block column with MFMA products; a 16x16 f64 accumulator register r is exactly the
+// B-fragment of k-step r, so the chained product -W_ii * (sum_k L_ik W_kj) needs no data movement.
+#include "common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define CH_NB 32
+#define CH_THREADS 512
+#define CH_WAVES (CH_THREADS / 64)
+
+// broadcast lane `src` (a compile-time constant after unrolling) through SGPRs: v_readlane_b32 x2
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,
+                                                          const int* __restrict__ lds_, int* __restrict__ status,
+                                                          double* single_mat, int single_M, int single_ld) {
+  const int b = blockIdx.x;
+  double* A = mats ? mats[b] : single_mat;
+  const int M = mats ? Ms[b] : single_M;
+  const int64_t ld = mats ? lds_[b] : single_ld;
+  __shared__ double D[CH_NB][CH_NB + 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+  for (int k0 = 0; k0 < M; k0 += CH_NB) {
+    const int nb = min(CH_NB, M - k0);
+    // ---- diagonal block: one wavefront, rows in registers --------------------------------------
+    if (wave == 0) {
+      double row[CH_NB];
+      const int i = lane & 31;
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++)
+        row[c] = (i < nb && c <= i) ? A[(int64_t)(k0 + i) * ld + k0 + c] : (i == c ? 1.0 : 0.0);
+#pragma unroll
+      for (int j = 0; j < CH_NB; j++) {
+        double djj = lane_bcast(row[j], j);
+        if (!(djj > 0.0)) {  // non-positive or NaN pivot: report the first one, keep going finite
+          if (lane == 0 && j < nb) {
+            if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = k0 + j; status[2] = b; }
+          }
+          djj = 1.0;
+        }
+        double s = __dsqrt_rn(djj);
+        double lij = (i > j) ? row[j] / s : (i == j ? s : 0.0);
+        row[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < CH_NB; c++) {
+          double lcj = lane_bcast(lij, c);
+          row[c] = fma(-lij, lcj, row[c]);  // meaningful for i >= c only
+        }
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++)
+          if (i < nb && c <= i) A[(int64_t)(k0 + i) * ld + k0 + c] = row[c];
+      }
+      // inverse of the diagonal factor, column c in lane c: x[r] = (L_kk^-1)[r][c]
+      double x[CH_NB];
+#pragma unroll
+      for (int r = 0; r < CH_NB; r++) {
+        double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = 0; t < r; t++) acc = fma(-lane_bcast(row[t], r), x[t], acc);
+        x[r] = acc / lane_bcast(row[r], r);
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int r = 0; r < CH_NB; r++) D[r][i] = x[r];
+      }
+    }
+    __syncthreads();
+    const int r0 = k0 + nb;  // first trailing row
+    const int R = M - r0;
+    if (R <= 0) break;
+    // ---- panel: X = A_panel * L_kk^-T on the matrix cores, 16 rows per wavefront step ----------
+    {
+      const int kq = lane >> 4, lc = lane & 15;
+      for (int rg = wave; rg * 16 < R; rg += CH_WAVES) {
+        const int ra = r0 + rg * 16 + lc;
+        double af[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+          const int kc = kk * 4 + kq;
+          af[kk] = (ra < M && kc < nb) ? A[(int64_t)ra * ld + k0 + kc] : 0.0;
+        }
+        d4 o[2];
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+          o[tj] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 8; kk++)  // B[k][j] = (L_kk^-1)[j][k]
+            o[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], D[tj * 16 + lc][kk * 4 + kq], o[tj], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int rw = r0 + rg * 16 + kq + 4 * r, cw = tj * 16 + lc;
+            if (rw < M && cw < nb) A[(int64_t)rw * ld + k0 + cw] = o[tj][r];
+          }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- trailing update (lower triangle): A22 -= X X^T on the matrix cores --------------------
+    const int nt = (R + 15) >> 4;
+    const int ntiles = nt * (nt + 1) / 2;
+    for (int t = wave; t < ntiles; t += CH_WAVES) {
+      // linear index -> (ti >= tj)
+      int ti = (int)((__dsqrt_rn(8.0 * t + 1.0) - 1.0) * 0.5);
+      while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+      while (ti * (ti + 1) / 2 > t) ti--;
+      const int tj = t - ti * (ti + 1) / 2;
+      const int ra = r0 + ti * 16 + (lane & 15);
+      const int rb = r0 + tj * 16 + (lane & 15);
+      const int kq = lane >> 4;
+      double af[8], bf[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        const int kc = kk * 4 + kq;
+        af[kk] = (ra < M && kc < nb) ? A[(int64_t)ra * ld + k0 + kc] : 0.0;
+        bf[kk] = (rb < M && kc < nb) ? A[(int64_t)rb * ld + k0 + kc] : 0.0;
+      }
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], acc, 0, 0, 0);
+      const int cc = r0 + tj * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rw = r0 + ti * 16 + (lane >> 4) + 4 * r;
+        if (rw < M && cc < M && cc <= rw) A[(int64_t)rw * ld + cc] -= acc[r];
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // zero the strictly-upper triangle so L can be used as a dense operand
+  for (int64_t idx = tid; idx < (int64_t)M * M; idx += CH_THREADS) {
+    int i = (int)(idx / M), j = (int)(idx % M);
+    if (j > i) A[(int64_t)i * ld + j] = 0.0;
+  }
+}
+
+// W = L^-1 (lower), one workgroup per matrix.
+__global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* const* __restrict__ Ls,
+                                                                 double* const* __restrict__ Ws,
+                                                                 const int* __restrict__ Ms,
+                                                                 const int* __restrict__ lds_, const double* single_L,
+                                                                 double* single_W, int single_M, int single_ld) {
+  const int b = blockIdx.x;
+  const double* L = Ls ? Ls[b] : single_L;
+  double* W = Ws ? Ws[b] : single_W;
+  const int M = Ls ? Ms[b] : single_M;
+  const int64_t ld = Ls ? lds_[b] : single_ld;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int T = (M + CH_NB - 1) / CH_NB;
+
+  // zero-fill W (upper part and everything not yet written)
+  for (int64_t idx = tid; idx < (int64_t)M * M; idx += CH_THREADS) {
+    int i = (int)(idx / M), j = (int)(idx % M);
+    W[(int64_t)i * ld + j] = 0.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- step A: invert the diagonal blocks in registers -----------------------------------------
+  for (int d = wave; d < T; d += CH_WAVES) {
+    const int d0 = d * CH_NB;
+    const int nb = min(CH_NB, M - d0);
+    const int i = lane & 31;
+    double lrow[CH_NB];  // lane i: row i of the diagonal block of L (identity-padded)
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++)
+      lrow[c] = (i < nb && c <= i) ? L[(int64_t)(d0 + i) * ld + d0 + c] : (i == c ? 1.0 : 0.0);
+    double x[CH_NB];  // lane c: column c of the inverse, x[t] = X[t][c]
+#pragma unroll
+    for (int r = 0; r < CH_NB; r++) {
+      double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+      for (int t = 0; t < r; t++) acc = fma(-lane_bcast(lrow[t], r), x[t], acc);
+      x[r] = acc / lane_bcast(lrow[r], r);
+    }
+    if (lane < 32 && i < nb) {
+#pragma unroll
+      for (int r = 0; r < CH_NB; r++)
+        if (r < nb && r >= i) W[(int64_t)(d0 + r) * ld + d0 + i] = x[r];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- step B: block columns; W_ij = -W_ii * sum_{k=j}^{i-1} L_ik W_kj ---------------------------
+  const int kq = lane >> 4, lc = lane & 15;
+  for (int j = wave; j < T; j += CH_WAVES) {
+    const int c0 = j * CH_NB;
+    for (int i = j + 1; i < T; i++) {
+      const int i0 = i * CH_NB;
+      d4 S[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) S[a][c] = d4{0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < i; k++) {
+        const int kb = k * CH_NB;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+          const int kcol = kb + kk * 4 + kq;  // < M always (k < i <= T-1 so block k is full)
+          double a0, a1, b0, b1;
+          {
+            int ra = i0 + lc, rb = i0 + 16 + lc;
+            a0 = (ra < M) ? L[(int64_t)ra * ld + kcol] : 0.0;
+            a1 = (rb < M) ? L[(int64_t)rb * ld + kcol] : 0.0;
+            b0 = W[(int64_t)kcol * ld + c0 + lc];
+            b1 = W[(int64_t)kcol * ld + c0 + 16 + lc];
+          }
+          S[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, S[0][0], 0, 0, 0);
+          S[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, S[0][1], 0, 0, 0);
+          S[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, S[1][0], 0, 0, 0);
+          S[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, S[1][1], 0, 0, 0);
+        }
+      }
+      // out(ta, tc) = - sum_{tk, kk} Wii(ta, tk)[., 4kk + kq] * S[tk][tc].reg[kk]
+      d4 O[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) O[a][c] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int tk = 0; tk < 2; tk++) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const int kcol = i0 + tk * 16 + kk * 4 + kq;
+          int ra = i0 + lc, rb = i0 + 16 + lc;
+          double a0 = (ra < M && kcol < M) ? W[(int64_t)ra * ld + kcol] : 0.0;
+          double a1 = (rb < M && kcol < M) ? W[(int64_t)rb * ld + kcol] : 0.0;
+          O[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, S[tk][0][kk], O[0][0], 0, 0, 0);
+          O[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, S[tk][1][kk], O[0][1], 0, 0, 0);
+          O[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, S[tk][0][kk], O[1][0], 0, 0, 0);
+          O[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, S[tk][1][kk], O[1][1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            int rw = i0 + a * 16 + kq + 4 * r, cw = c0 + c * 16 + lc;
+            if (rw < M) W[(int64_t)rw * ld + cw] = -O[a][c][r];
+          }
+      __threadfence_block();  // this wave re-reads the block it just wrote as the next B operand
+    }
+  }
+}
+
+gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
+                                  int maxM) {
+  (void)maxM;
+  if (batch <= 0) return GP_OK;
+  GpTimerScope ts(h, GP_TIMER_CHOL);
+  hipLaunchKernelGGL(chol_kernel, dim3(batch), dim3(CH_THREADS), 0, h->stream, d_mats, d_M, d_ld, h->d_status,
+                     (double*)nullptr, 0, 0);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld) {
+  if (M <= 0) return GP_OK;
+  GpTimerScope ts(h, GP_TIMER_CHOL);
+  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(CH_THREADS), 0, h->stream, (double* const*)nullptr,
+                     (const int*)nullptr, (const int*)nullptr, h->d_status, A, M, (int)ld);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+gp_status launch_tri_inverse_single(gp_handle h, const double* L, double* Linv, int M, int64_t ld) {
+  if (M <= 0) return GP_OK;
+  GpTimerScope ts(h, GP_TIMER_CHOL);
+  hipLaunchKernelGGL(tri_inverse_kernel, dim3(1), dim3(CH_THREADS), 0, h->stream, (const double* const*)nullptr,
+                     (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, L, Linv, M, (int)ld);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, double* const* d_W, const int* d_M,
+                                     const int* d_ld, int batch) {
+  if (batch <= 0) return GP_OK;
+  GpTimerScope ts(h, GP_TIMER_CHOL);
+  hipLaunchKernelGGL(tri_inverse_kernel, dim3(batch), dim3(CH_THREADS), 0, h->stream, d_L, d_W, d_M, d_ld,
+                     (const double*)nullptr, (double*)nullptr, 0, 0);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// Reads the device status word (syncs the stream).  Clears it afterwards.
+gp_status check_not_pd(gp_handle h) {
+  int32_t st[4] = {0, 0, 0, 0};
+  GP_HIP_CHECK(h, hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  if (st[0] != 0) {
+    h->not_pd_index = st[1];
+    char buf[160];
+    snprintf(buf, sizeof(buf), "Cholesky failed: matrix %d is not positive definite (pivot %d)", st[2], st[1]);
+    h->last_error = buf;
+    GP_HIP_CHECK(h, hipMemsetAsync(h->d_status, 0, sizeof(st), h->stream));
+    return GP_ERR_NOT_PD;
+  }
+  return GP_OK;
+}

@@ -1,0 +1,160 @@
+// common.h — shared host/device declarations for libgpitch_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/gpitch_abi.h"
+
+#define GP_WAVE 64
+
+struct gp_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+  int32_t not_pd_index = -1;
+  int32_t* d_status = nullptr;   // device int[4]: {not_pd_flag, pivot_index, gp_index, spare}
+  int num_cus = 256;
+  // timers
+  bool timers_on = false;
+  struct TimerRec { hipEvent_t e0, e1; int which; };
+  std::vector<TimerRec> pending;
+  std::vector<hipEvent_t> event_pool;
+  double timer_ms[GP_TIMER_COUNT] = {0};
+  int64_t timer_n[GP_TIMER_COUNT] = {0};
+};
+
+#define GP_HIP_CHECK(h, expr)                                                                  \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      char _b[512];                                                                            \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+               __LINE__);                                                                      \
+      (h)->last_error = _b;                                                                    \
+      return GP_ERR_HIP;                                                                       \
+    }                                                                                          \
+  } while (0)
+
+#define GP_CHECK(expr)                   \
+  do {                                   \
+    gp_status _s = (expr);               \
+    if (_s != GP_OK) return _s;          \
+  } while (0)
+
+static inline gp_status gp_fail(gp_handle h, gp_status s, const char* msg) {
+  if (h) h->last_error = msg;
+  return s;
+}
+
+// scoped timer for a kernel class; records HIP events on the handle's stream when enabled
+struct GpTimerScope {
+  gp_handle h;
+  int which;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  GpTimerScope(gp_handle h_, int which_);
+  ~GpTimerScope();
+};
+
+static inline size_t gp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// simple bump allocator over a caller-provided workspace
+struct GpArena {
+  char* base = nullptr;
+  size_t size = 0, off = 0;
+  bool ok = true;
+  GpArena(void* p, size_t n) : base((char*)p), size(n) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = gp_align_up(count * sizeof(T), 256);
+    if (off + bytes > size) { ok = false; return nullptr; }
+    T* r = (T*)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// device-side kernel descriptor (passed by value in kernel args)
+struct DevKern {
+  int type;
+  int m;
+  const double* theta;  // [variance, lengthscales, e_0.., f_0..]
+};
+static inline DevKern dev_kern(const gp_kernel_desc* k) { return DevKern{k->type, k->num_partials, k->theta}; }
+
+// ---------------------------------------------------------------------------------------------
+// launchers implemented across the .hip files (all enqueue on h->stream)
+
+// cov.hip
+gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
+                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws);
+size_t kernel_build_feat_ws_doubles(int m, int n1, int n2);
+gp_status launch_kernel_diag(gp_handle h, DevKern k, int n, double* out, int accumulate);
+
+// chol.hip
+gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
+                                  int maxM);
+gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld);
+gp_status launch_tri_inverse_single(gp_handle h, const double* L, double* Linv, int M, int64_t ld);
+gp_status check_not_pd(gp_handle h);  // syncs; turns the device flag into GP_ERR_NOT_PD
+
+// gemm.hip
+struct GemmProblem {
+  const double* A; const double* B; double* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  // epilogue / prologue extras (meaning depends on the launch variant)
+  const double* v0; const double* v1; const double* v2;
+  double* o0; double* o1; double* o2;
+  DevKern kern;           // for epilogues that re-evaluate the covariance (hyper-gradient)
+  const double* xa; const double* xb;  // kernel inputs (z, x) for those epilogues
+};
+enum GemmTri { TRI_NONE = 0, TRI_LOWER = 1, TRI_UPPER = 2 };
+struct GemmFlags {
+  int transA = 0, transB = 0;
+  int triA = TRI_NONE;   // structure of op(A) (M x K)
+  int triB = TRI_NONE;   // structure of op(B) (K x N)
+  int triC = TRI_NONE;   // TRI_LOWER: tiles strictly above the diagonal are skipped, upper part zeroed
+  double alpha = 1.0, beta = 0.0;
+  int big_tiles = 0;     // 128x128 tiles (strip GEMMs) instead of 64x64
+  int epilogue = 1;      // bitmask of GemmEpi
+  int scale_mode = 0;    // 0 none; 1: opB(B)(k,n) *= v1[n]; 2: opB(B)(k,n) *= v1[k]
+  int timer = GP_TIMER_SMALL_GEMM;
+};
+enum GemmEpi {
+  EPI_STORE = 1,     // C = alpha*acc + beta*C
+  EPI_COLSUMSQ = 2,  // o0[rowblk*N + n] = sum over the tile's rows of (alpha*acc)^2
+  EPI_COLDOT = 4     // o1[rowblk*N + n] = sum over the tile's rows of alpha*acc * v0[row]
+};
+// Batched: d_probs is a device array of `batch` problems; maxM/maxN bound the grid.
+gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN,
+                              const GemmFlags& f);
+// H = (X * diag(d)) * Y^T over the long dimension with split-K partial slabs + reduction (deterministic).
+//   prob.A = X (M x Nlong, lda), prob.B = Y (M x Nlong, ldb), prob.v1 = d (Nlong, when scale_by_k), prob.C = H (M x M, ldc)
+//   prob.M = prob.N = M, prob.K = Nlong; prob.o2 = slab workspace (nsplit * M * M doubles).  Only the lower triangle is computed when sym != 0
+//   (upper mirrored).
+gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
+                                        int nsplit, int sym, int scale_by_k, double alpha);
+gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, double* const* d_W, const int* d_M,
+                                     const int* d_ld, int batch);
+int gemm_nt_nsplit(int M, int Nlong);
+int gemm_rowblocks(int M, int big_tiles);
+
+// lik.hip
+gp_status launch_mpd_lik(gp_handle h, const double* Fmu, const double* Fvar, int64_t f_rs, int64_t f_cs,
+                         const double* y, int N, int P, int nlin, const double* noise_var, double scale,
+                         double* per_frame, double* partial_sums, int* num_partials_out,
+                         double* gFmu, double* gFvar);
+gp_status launch_finish_sum(gp_handle h, const double* partials, int count, int stride, int nsums, double* out,
+                            double mul, int accumulate);
+
+// opt.hip
+gp_status launch_transform_forward(gp_handle h, const double* free_state, const uint8_t* tcode, int64_t n,
+                                   double* params);
+gp_status launch_transform_backward(gp_handle h, const double* params, const uint8_t* tcode, int64_t n,
+                                    double* free_state);
+gp_status launch_adam(gp_handle h, double* free_state, double* params, const double* grad, const uint8_t* tcode,
+                      double* m, double* v, int64_t n, int64_t t, double lr, double b1, double b2, double eps);

@@ -1,0 +1,233 @@
+// cov.hip — covariance (Kuu / Kuf) assembly kernels for gfx950.
+//
+// Replaces the TF op sequence behind `Kern.K(X, X2)`:
+//   MercerMatern12sm.K   gpitch/matern12_spectral_mixture.py:102-117 (+ phi_features :123-133)
+//   Matern12sm.K         gpitch/matern12_spectral_mixture.py:38-56
+//   GPflow Stationary.K  Matern12/32/52/RBF via euclid_dist
+//
+// HBM-bound by design: one pass, every output element written exactly once with 16-byte stores,
+// row-major M x N with the long (frame) dimension contiguous so a wave writes 1 KiB per store.
+// The squared distance keeps the reference's matmul-expansion and rounding order
+//   r2 = ((-2*(a*b)) + a*a) + b*b,  a = x/l, b = x'/l     (each op rounded separately, no FMA)
+// so that coincident inducing/data points give r = sqrt(r2 + 1e-12) exactly as TF does.
+#include "common.h"
+
+#define COV_THREADS 256
+#define COV_ROWS 32  // rows (inducing points) handled per block
+
+__device__ __forceinline__ double stat_profile(int type, double r2, double var) {
+  // r2 is the literal expansion; the kernels below follow GPflow 0.5 Stationary subclasses
+  if (type == GP_KERN_RBF) return var * exp(-r2 * 0.5);
+  double r = __dsqrt_rn(__dadd_rn(r2, 1e-12));
+  if (type == GP_KERN_MATERN12) return var * exp(-r);
+  if (type == GP_KERN_MATERN32) {
+    const double s3 = 1.7320508075688772;
+    return var * (1.0 + s3 * r) * exp(-s3 * r);
+  }
+  // Matern52
+  const double s5 = 2.23606797749979;
+  return var * (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r);
+}
+
+__device__ __forceinline__ double r2_expand(double a, double aa, double b, double bb) {
+  return __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b), aa), bb);
+}
+
+// Precompute spectral-mixture features: f[k][j] = sqrt(e_k) cos(2 pi f_k x_j), f[m+k][j] = ... sin(...)
+__global__ void __launch_bounds__(256) sm_features_kernel(DevKern k, const double* __restrict__ x, int n,
+                                                          double* __restrict__ f) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = blockIdx.y;
+  if (j >= n) return;
+  const double* th = k.theta;
+  double e = th[2 + p], fr = th[2 + k.m + p];
+  double arg = __dmul_rn(__dmul_rn(6.283185307179586, fr), x[j]);
+  double s, c;
+  sincos(arg, &s, &c);
+  double se = __dsqrt_rn(e);
+  f[(size_t)p * n + j] = se * c;
+  f[(size_t)(p + k.m) * n + j] = se * s;
+}
+
+// MODE 0: stationary (Matern12/32/52/RBF); MODE 1: Mercer Matern-1/2 SM (feature form);
+// MODE 2: Matern12sm (broadcast cosine form).  CPT = columns per thread (16-byte stores when 2).
+template <int MODE, int CPT>
+__global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const double* __restrict__ x1, int n1,
+                                                                const double* __restrict__ x2, int n2,
+                                                                double* __restrict__ out, int64_t ld,
+                                                                int accumulate, double diag_add,
+                                                                const double* __restrict__ f1,
+                                                                const double* __restrict__ f2, int vec_ok) {
+  extern __shared__ double smem[];  // MODE 1: z-features for this block's rows [COV_ROWS][2m]
+  const double* th = k.theta;
+  const double var = th[0];
+  const double ls = th[1];
+  const int m = k.m;
+  const int j0 = (blockIdx.x * COV_THREADS + threadIdx.x) * CPT;
+  const int i0 = blockIdx.y * COV_ROWS;
+  const int iend = min(i0 + COV_ROWS, n1);
+
+  if (MODE == 1) {
+    // stage this block's row features: smem[(i - i0) * 2m + q] = f1[q][i]
+    for (int t = threadIdx.x; t < COV_ROWS * 2 * m; t += COV_THREADS) {
+      int q = t / COV_ROWS, ii = t % COV_ROWS;
+      smem[ii * 2 * m + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
+    }
+    __syncthreads();
+  }
+  if (j0 >= n2) return;
+
+  double b[CPT], bb[CPT], xb[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; c++) {
+    int j = min(j0 + c, n2 - 1);
+    xb[c] = x2[j];
+    b[c] = xb[c] / ls;
+    bb[c] = __dmul_rn(b[c], b[c]);
+  }
+
+  if (MODE == 1) {
+    // column features live in registers for the whole row loop (2m <= 64 values per column)
+    constexpr int QMAX = 64;
+    double fx[CPT][QMAX];
+    // (runtime m: unrolled by the compiler up to QMAX via the guarded loop below)
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) {
+#pragma unroll
+      for (int c = 0; c < CPT; c++) {
+        int j = min(j0 + c, n2 - 1);
+        fx[c][q] = (q < 2 * m) ? f2[(size_t)q * n2 + j] : 0.0;
+      }
+    }
+    for (int i = i0; i < iend; i++) {
+      double xa = x1[i];
+      double a = xa / ls, aa = __dmul_rn(a, a);
+      const double* fz = &smem[(i - i0) * 2 * m];
+      double acc[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; c++) acc[c] = 0.0;
+#pragma unroll
+      for (int q = 0; q < QMAX; q++) {
+        if (q < 2 * m) {
+          double z = fz[q];
+#pragma unroll
+          for (int c = 0; c < CPT; c++) acc[c] = fma(z, fx[c][q], acc[c]);
+        }
+      }
+      double res[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; c++) {
+        double r = __dsqrt_rn(__dadd_rn(r2_expand(a, aa, b[c], bb[c]), 1e-12));
+        res[c] = var * exp(-r) * acc[c];
+        if (x2 == x1 && i == j0 + c) res[c] += diag_add;
+      }
+      double* o = out + (size_t)i * ld + j0;
+      if (CPT == 2 && vec_ok && j0 + 1 < n2) {
+        double2 v = make_double2(res[0], res[1]);
+        if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
+        *reinterpret_cast<double2*>(o) = v;
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+          if (j0 + c < n2) o[c] = accumulate ? o[c] + res[c] : res[c];
+      }
+    }
+    return;
+  }
+
+  for (int i = i0; i < iend; i++) {
+    double xa = x1[i];
+    double res[CPT];
+    if (MODE == 0) {
+      double a = xa / ls, aa = __dmul_rn(a, a);
+#pragma unroll
+      for (int c = 0; c < CPT; c++) res[c] = stat_profile(k.type, r2_expand(a, aa, b[c], bb[c]), var);
+    } else {
+      // Matern12sm (m12sm.py:46-56): r = sqrt((x - x' + 1e-12)^2)
+#pragma unroll
+      for (int c = 0; c < CPT; c++) {
+        double d = __dadd_rn(__dadd_rn(xa, -xb[c]), 1e-12);
+        double r = __dsqrt_rn(__dmul_rn(d, d));
+        double s = 0.0;
+        for (int p = 0; p < m; p++)
+          s += th[2 + p] * cos(__dmul_rn(__dmul_rn(6.283185307179586, th[2 + m + p]), r));
+        res[c] = var * exp(-(r / ls)) * s;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; c++)
+      if (x2 == x1 && i == j0 + c) res[c] += diag_add;
+    double* o = out + (size_t)i * ld + j0;
+    if (CPT == 2 && vec_ok && j0 + 1 < n2) {
+      double2 v = make_double2(res[0], res[1]);
+      if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
+      *reinterpret_cast<double2*>(o) = v;
+    } else {
+#pragma unroll
+      for (int c = 0; c < CPT; c++)
+        if (j0 + c < n2) o[c] = accumulate ? o[c] + res[c] : res[c];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) cov_diag_kernel(DevKern k, int n, double* __restrict__ out, int accumulate) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double* th = k.theta;
+  double v = th[0];
+  if (k.type == GP_KERN_MERCER_MATERN12SM || k.type == GP_KERN_MATERN12SM) {
+    double s = th[2];
+    for (int p = 1; p < k.m; p++) s += th[2 + p];
+    v = v * s;
+  }
+  out[j] = accumulate ? out[j] + v : v;
+}
+
+size_t kernel_build_feat_ws_doubles(int m, int n1, int n2) {
+  if (m <= 0) return 0;
+  return gp_align_up((size_t)2 * m * n1, 32) + gp_align_up((size_t)2 * m * n2, 32);
+}
+
+gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
+                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws) {
+  if (n1 <= 0 || n2 <= 0) return GP_OK;
+  if (x2 == nullptr) { x2 = x1; n2 = n1; }
+  const int vec_ok = ((ld % 2) == 0) && ((((uintptr_t)out) & 15) == 0);
+  GpTimerScope ts(h, GP_TIMER_KUF_BUILD);
+  if (k.type == GP_KERN_MERCER_MATERN12SM) {
+    if (k.m < 1 || k.m > 32) return gp_fail(h, GP_ERR_UNSUPPORTED, "num_partials must be in [1, 32]");
+    if (!feat_ws) return gp_fail(h, GP_ERR_WORKSPACE, "feature workspace missing");
+    double* f1 = feat_ws;
+    double* f2 = (x2 == x1) ? f1 : feat_ws + gp_align_up((size_t)2 * k.m * n1, 32);
+    dim3 g1((n1 + 255) / 256, k.m);
+    hipLaunchKernelGGL(sm_features_kernel, g1, dim3(256), 0, h->stream, k, x1, n1, f1);
+    if (x2 != x1) {
+      dim3 g2((n2 + 255) / 256, k.m);
+      hipLaunchKernelGGL(sm_features_kernel, g2, dim3(256), 0, h->stream, k, x2, n2, f2);
+    }
+    dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + COV_ROWS - 1) / COV_ROWS);
+    size_t sh = (size_t)COV_ROWS * 2 * k.m * sizeof(double);
+    hipLaunchKernelGGL((cov_build_kernel<1, 1>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out, ld,
+                       accumulate, diag_add, f1, f2, vec_ok);
+  } else if (k.type == GP_KERN_MATERN12SM) {
+    if (k.m < 1) return gp_fail(h, GP_ERR_BAD_ARG, "num_partials must be >= 1");
+    dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + COV_ROWS - 1) / COV_ROWS);
+    hipLaunchKernelGGL((cov_build_kernel<2, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
+                       accumulate, diag_add, nullptr, nullptr, vec_ok);
+  } else if (k.type >= GP_KERN_MATERN12 && k.type <= GP_KERN_RBF) {
+    dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
+    hipLaunchKernelGGL((cov_build_kernel<0, 2>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
+                       accumulate, diag_add, nullptr, nullptr, vec_ok);
+  } else {
+    return gp_fail(h, GP_ERR_BAD_ARG, "unknown kernel type");
+  }
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+gp_status launch_kernel_diag(gp_handle h, DevKern k, int n, double* out, int accumulate) {
+  if (n <= 0) return GP_OK;
+  hipLaunchKernelGGL(cov_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, k, n, out, accumulate);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}

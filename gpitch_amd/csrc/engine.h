@@ -1,0 +1,68 @@
+// engine.h — batched sparse-GP conditional engine shared by the Pdgp / SGPR plans and the one-shot
+// C-ABI operators.  Host-side orchestration only; all arithmetic is in the .hip kernels.
+#pragma once
+#include "common.h"
+
+// lik.hip helpers
+size_t cond_finish_item_bytes();
+void cond_finish_fill(void* host_item, const double* s1, int rb1, const double* s2, int rb2, const double* dot,
+                      int rbdot, DevKern k, double* fmean, double* fvar);
+gp_status launch_cond_finish(gp_handle h, const void* d_items, int count, int N);
+size_t kl_item_bytes();
+void kl_item_fill(void* host_item, const double* q_mu, const double* q_sqrt, int M, double* out, double* g_mu,
+                  double* g_sqrt);
+gp_status launch_kl_white(gp_handle h, const void* d_items, int count);
+gp_status launch_elbo_finish(gp_handle h, const double* lik_partials, int nblocks, const double* kl, int nkl,
+                             double* elbo, double* g_noise);
+gp_status launch_mean_source(gp_handle h, const double* fmean, int P, int n, int nlin, double* out);
+
+// bwd.hip helpers
+gp_status launch_rowdot_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM);
+gp_status launch_sub_identity_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM);
+gp_status launch_phi_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM);
+gp_status launch_rank1_tril_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM);
+gp_status launch_matvec_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int trans);
+gp_status launch_addvec_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM);
+gp_status launch_tril_add_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM);
+gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
+                                const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
+                                const double* feat, double* partials, int* nparts, double* gz_partials);
+gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, int nparts, const double* gv_sum,
+                              double* g_theta, const double* gz_partials, int ncolblocks, int n1, double* g_z);
+int hyper_num_sums(int m);
+
+// One latent GP inside a batch of conditionals.
+struct CondTask {
+  DevKern kern;
+  const double* z = nullptr; int M = 0;
+  const double* q_mu = nullptr; const double* q_sqrt = nullptr;  // q_sqrt may be null (no variational covariance)
+  // workspace (device)
+  double* L = nullptr;    // M x M  Kuu -> chol
+  double* W = nullptr;    // M x M  L^-1
+  double* Kuf = nullptr;  // M x N
+  double* A = nullptr;    // M x N  W Kuf
+  double* A2 = nullptr;   // M x N  W^T A (unwhitened only)
+  double* feat = nullptr; // spectral-mixture features (2m x (M + N))
+  double* s1 = nullptr; double* s2 = nullptr; double* dot = nullptr;  // [rowblocks][N] partials
+  double* fmean = nullptr; double* fvar = nullptr;                    // N each
+};
+
+struct CondBatch {
+  std::vector<CondTask> tasks;
+  int N = 0;
+  int maxM = 0;
+  // device descriptor storage (inside the caller's workspace)
+  char* d_desc = nullptr; size_t desc_bytes = 0;
+  std::vector<char> h_desc;
+  // offsets of the descriptor arrays inside d_desc
+  size_t off_chol_ptrs = 0, off_w_ptrs = 0, off_Ms = 0, off_lds = 0, off_f1 = 0, off_f1u = 0, off_f2 = 0, off_finish = 0;
+  bool uploaded = false;
+};
+
+size_t cond_task_workspace_doubles(int M, int N, int num_partials, bool whiten);
+size_t cond_batch_desc_bytes(int count);
+// carve the per-task buffers out of the arena
+bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten);
+gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten);
+// run: Kuu -> chol -> W ; Kuf ; A = W Kuf ; (A2 = W^T A) ; Lq^T A ; reductions -> fmean, fvar
+gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter);

@@ -1,0 +1,152 @@
+// engine.hip — host orchestration of a batch of sparse-GP conditionals (see engine.h).
+// Follows GPflow-0.5 `conditionals.conditional` as called from gpitch/pdgp.py:147-155:
+//   Kmm = K(z)+jitter I; Lm = chol; A = Lm^-1 Kmn; fvar = Kdiag - sum A^2; [A = Lm^-T A]; fmean = A^T f;
+//   LTA = tril(q_sqrt)^T A; fvar += sum LTA^2.
+#include "engine.h"
+#include <string.h>
+
+static inline int ldN_of(int N) { return (N + 1) & ~1; }
+
+size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten) {
+  const size_t ldN = ldN_of(N);
+  const int rb = gemm_rowblocks(M, 1);
+  size_t d = 0;
+  auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
+  add((size_t)M * M); add((size_t)M * M);          // L, W
+  add((size_t)M * ldN); add((size_t)M * ldN);      // Kuf, A
+  if (!whiten) add((size_t)M * ldN);               // A2
+  if (m > 0) add(kernel_build_feat_ws_doubles(m, M, N));
+  add((size_t)rb * N); add((size_t)rb * N); add((size_t)rb * N);  // s1, s2, dot
+  return d;
+}
+
+bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten) {
+  const size_t ldN = ldN_of(N);
+  const int rb = gemm_rowblocks(t.M, 1);
+  t.L = ar.take<double>((size_t)t.M * t.M);
+  t.W = ar.take<double>((size_t)t.M * t.M);
+  t.Kuf = ar.take<double>((size_t)t.M * ldN);
+  t.A = ar.take<double>((size_t)t.M * ldN);
+  t.A2 = whiten ? nullptr : ar.take<double>((size_t)t.M * ldN);
+  t.feat = (t.kern.m > 0 && t.kern.type == GP_KERN_MERCER_MATERN12SM)
+               ? ar.take<double>(kernel_build_feat_ws_doubles(t.kern.m, t.M, N)) : nullptr;
+  t.s1 = ar.take<double>((size_t)rb * N);
+  t.s2 = ar.take<double>((size_t)rb * N);
+  t.dot = ar.take<double>((size_t)rb * N);
+  return ar.ok;
+}
+
+size_t cond_batch_desc_bytes(int count) {
+  size_t b = 0;
+  b += gp_align_up(count * sizeof(double*), 256) * 2;  // chol ptrs, W ptrs
+  b += gp_align_up(count * sizeof(int), 256) * 2;      // Ms, lds
+  b += gp_align_up(count * sizeof(GemmProblem), 256) * 3;
+  b += gp_align_up(count * cond_finish_item_bytes(), 256);
+  return b;
+}
+
+gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten) {
+  const int G = (int)cb.tasks.size();
+  const int N = cb.N;
+  const int64_t ldN = ldN_of(N);
+  size_t need = cond_batch_desc_bytes(G);
+  if (cb.desc_bytes < need || !cb.d_desc) return gp_fail(h, GP_ERR_WORKSPACE, "descriptor workspace too small");
+  cb.h_desc.assign(need, 0);
+  size_t off = 0;
+  auto region = [&](size_t bytes) { size_t o = off; off += gp_align_up(bytes, 256); return o; };
+  cb.off_chol_ptrs = region(G * sizeof(double*));
+  cb.off_w_ptrs = region(G * sizeof(double*));
+  cb.off_Ms = region(G * sizeof(int));
+  cb.off_lds = region(G * sizeof(int));
+  cb.off_f1 = region(G * sizeof(GemmProblem));
+  cb.off_f1u = region(G * sizeof(GemmProblem));
+  cb.off_f2 = region(G * sizeof(GemmProblem));
+  cb.off_finish = region(G * cond_finish_item_bytes());
+  double** cp = (double**)(cb.h_desc.data() + cb.off_chol_ptrs);
+  double** wp = (double**)(cb.h_desc.data() + cb.off_w_ptrs);
+  int* Ms = (int*)(cb.h_desc.data() + cb.off_Ms);
+  int* lds = (int*)(cb.h_desc.data() + cb.off_lds);
+  GemmProblem* f1 = (GemmProblem*)(cb.h_desc.data() + cb.off_f1);
+  GemmProblem* f1u = (GemmProblem*)(cb.h_desc.data() + cb.off_f1u);
+  GemmProblem* f2 = (GemmProblem*)(cb.h_desc.data() + cb.off_f2);
+  char* fin = cb.h_desc.data() + cb.off_finish;
+  cb.maxM = 0;
+  for (int g = 0; g < G; g++) {
+    const CondTask& t = cb.tasks[g];
+    if (t.M > cb.maxM) cb.maxM = t.M;
+    cp[g] = t.L; wp[g] = t.W; Ms[g] = t.M; lds[g] = t.M;
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = t.W; p.lda = t.M; p.B = t.Kuf; p.ldb = ldN; p.C = t.A; p.ldc = ldN;
+    p.M = t.M; p.N = N; p.K = t.M;
+    p.v0 = t.q_mu; p.o0 = t.s1; p.o1 = t.dot;
+    f1[g] = p;
+    memset(&p, 0, sizeof(p));
+    p.A = t.W; p.lda = t.M; p.B = t.A; p.ldb = ldN; p.C = t.A2; p.ldc = ldN;
+    p.M = t.M; p.N = N; p.K = t.M;
+    p.v0 = t.q_mu; p.o1 = t.dot;
+    f1u[g] = p;
+    memset(&p, 0, sizeof(p));
+    p.A = t.q_sqrt; p.lda = t.M; p.B = whiten ? t.A : t.A2; p.ldb = ldN; p.C = nullptr; p.ldc = ldN;
+    p.M = t.M; p.N = N; p.K = t.M;
+    p.o0 = t.s2;
+    f2[g] = p;
+    const int rb = gemm_rowblocks(t.M, 1);
+    cond_finish_fill(fin + g * cond_finish_item_bytes(), t.s1, rb, t.s2, t.q_sqrt ? rb : 0, t.dot, rb, t.kern,
+                     t.fmean, t.fvar);
+  }
+  GP_HIP_CHECK(h, hipMemcpyAsync(cb.d_desc, cb.h_desc.data(), need, hipMemcpyHostToDevice, h->stream));
+  cb.uploaded = true;
+  return GP_OK;
+}
+
+gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter) {
+  const int G = (int)cb.tasks.size();
+  if (G == 0 || N <= 0) return GP_OK;
+  if (!cb.uploaded || cb.N != N) return gp_fail(h, GP_ERR_BAD_ARG, "conditional batch descriptors not uploaded");
+  const int64_t ldN = ldN_of(N);
+  // 1. Kuu + jitter I
+  for (int g = 0; g < G; g++) {
+    const CondTask& t = cb.tasks[g];
+    GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat));
+  }
+  // 2. Cholesky and inverse (one workgroup per GP)
+  GP_CHECK(launch_cholesky_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                   (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
+                                   cb.maxM));
+  GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                      (double* const*)(cb.d_desc + cb.off_w_ptrs),
+                                      (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G));
+  // 3. Kuf
+  for (int g = 0; g < G; g++) {
+    const CondTask& t = cb.tasks[g];
+    GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, x, N, t.Kuf, ldN, 0, 0.0, t.feat));
+  }
+  // 4. A = W Kuf (+ column reductions)
+  {
+    GemmFlags f;
+    f.triA = TRI_LOWER; f.big_tiles = 1; f.timer = GP_TIMER_STRIP_GEMM;
+    f.epilogue = EPI_STORE | EPI_COLSUMSQ | (whiten ? EPI_COLDOT : 0);
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, f));
+  }
+  if (!whiten) {
+    GemmFlags f;
+    f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_STRIP_GEMM;
+    f.epilogue = EPI_STORE | EPI_COLDOT;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1u), G, cb.maxM, N, f));
+  }
+  // 5. LTA = tril(q_sqrt)^T A  (only its column sums of squares are needed)
+  bool any_qsqrt = false;
+  for (int g = 0; g < G; g++) any_qsqrt |= (cb.tasks[g].q_sqrt != nullptr);
+  if (any_qsqrt) {
+    for (int g = 0; g < G; g++)
+      if (!cb.tasks[g].q_sqrt) return gp_fail(h, GP_ERR_UNSUPPORTED, "mixed null/non-null q_sqrt in one batch");
+    GemmFlags f;
+    f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_STRIP_GEMM;
+    f.epilogue = EPI_COLSUMSQ;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
+  }
+  // 6. fmean / fvar
+  GP_CHECK(launch_cond_finish(h, cb.d_desc + cb.off_finish, G, N));
+  return GP_OK;
+}

@@ -1,0 +1,394 @@
+// gemm.hip — batched fp64 matrix-core GEMM family for the sparse-GP conditional (gfx950).
+//
+// Replaces the dense TF ops inside GPflow `conditional` and `SGPR` as called from
+// gpitch/pdgp.py:147-155 and gpitch/sgpr_ss.py:48-53:
+//   tf.matrix_triangular_solve(Lm, Kmn)   ->  A   = W * Kuf        (W = Lm^-1 lower, tri-aware)
+//   tf.matmul(L_q^T, A)                   ->  LTA = Lq^T * A       (upper-from-lower, tri-aware)
+//   reduce_sum(square(.), 0), A^T q_mu    ->  fused column reductions in the epilogue
+//   tf.matmul(A, A, transpose_b=True)     ->  split-K "NT" product over the frame dimension
+// plus every M x M x M product of the backward pass (Cholesky adjoint etc.).
+//
+// Design for CDNA4: 256-thread workgroups (4 wavefronts as 2 x 2), v_mfma_f64_16x16x4_f64,
+// 128 x 128 (strip) or 64 x 64 (small) output tiles, BK = 16, operands staged global -> registers ->
+// LDS with one barrier per K-tile (double-buffered LDS, next tile's global loads in flight during the
+// MFMAs), LDS strides padded so that every fragment read is bank-conflict free for ds_read_b64
+// (64-bank modulus): k-contiguous tiles use stride BK+2, row-contiguous tiles use stride B+16.
+// Triangular operands skip whole K-tiles that are structurally zero and mask inside the diagonal
+// tile; workgroups are renumbered so that the row-blocks sharing one operand strip sit on the same
+// XCD (shared L2).  Two workgroups are resident per CU (<= 256 VGPRs, 2 x 72 KiB LDS).
+#include "common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define GEMM_THREADS 256
+#define GEMM_BK 16
+
+struct GemmDevFlags {
+  int triA, triB, triC;
+  double alpha, beta;
+  int epi;         // bitmask: 1 store, 2 colsumsq -> o0, 4 coldot(v0) -> o1
+  int scale_mode;  // 0 none, 1: B(k,n) *= v1[n], 2: B(k,n) *= v1[k]
+  int ksplit;      // >1: split-K, slabs written to o2 + s*M*N (ldc = N), epi forced to plain store
+  int tilesM, tilesN;
+};
+
+template <int BM, int BN, bool TA, bool TB>
+struct GemmSmem {
+  static constexpr int SA = TA ? (BM + 16) : (GEMM_BK + 2);
+  static constexpr int SB = TB ? (GEMM_BK + 2) : (BN + 16);
+  static constexpr int A_ELEMS = TA ? GEMM_BK * SA : BM * SA;
+  static constexpr int B_ELEMS = TB ? BN * SB : GEMM_BK * SB;
+  static constexpr int STAGE = A_ELEMS + B_ELEMS;
+  static constexpr size_t BYTES = (size_t)2 * STAGE * sizeof(double);
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmProblem* __restrict__ probs,
+                                                                    GemmDevFlags f) {
+  using S = GemmSmem<BM, BN, TA, TB>;
+  constexpr int WM = BM / 2, WN = BN / 2;   // per-wave tile
+  constexpr int TM = WM / 16, TN = WN / 16; // MFMA tiles per wave
+  constexpr int EA = BM * GEMM_BK / GEMM_THREADS;  // elements per thread, A tile
+  constexpr int EB = BN * GEMM_BK / GEMM_THREADS;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const GemmProblem p = probs[blockIdx.z];
+  // XCD-aware renumbering: blocks b and b+8 share an XCD; give each XCD a contiguous range of logical
+  // tiles so that the row-blocks that read the same B strip hit the same L2.
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tm = bid % f.tilesM, tn = bid / f.tilesM;
+  const int i0 = tm * BM, j0 = tn * BN;
+  if (i0 >= p.M || j0 >= p.N) return;
+  if (f.triC == TRI_LOWER && j0 > i0 + BM - 1) return;
+
+  int kbeg = 0, kend = p.K;
+  if (f.triA == TRI_LOWER) kend = min(kend, i0 + BM);
+  if (f.triA == TRI_UPPER) kbeg = max(kbeg, i0);
+  if (f.triB == TRI_LOWER) kbeg = max(kbeg, j0);
+  if (f.triB == TRI_UPPER) kend = min(kend, j0 + BN);
+  kbeg = (kbeg / GEMM_BK) * GEMM_BK;
+  if (f.ksplit > 1) {
+    int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    int per = (nk + f.ksplit - 1) / f.ksplit;
+    int s = blockIdx.y;
+    int b0 = kbeg + s * per * GEMM_BK;
+    kend = min(kend, b0 + per * GEMM_BK);
+    kbeg = b0;
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lc = lane & 15, kq = lane >> 4;
+
+  // ---- global -> register staging ---------------------------------------------------------------
+  double ra[EA], rb[EB];
+  // A tile coordinates for this thread
+  int a_i, a_k;  // tile-local (row, k) of the first element; EA elements contiguous along memory order
+  if (TA) { constexpr int TPR = BM / EA; a_k = tid / TPR; a_i = (tid % TPR) * EA; }
+  else    { constexpr int TPR = GEMM_BK / EA; a_i = tid / TPR; a_k = (tid % TPR) * EA; }
+  int b_k, b_n;
+  if (TB) { constexpr int TPR = GEMM_BK / EB; b_n = tid / TPR; b_k = (tid % TPR) * EB; }
+  else    { constexpr int TPR = BN / EB; b_k = tid / TPR; b_n = (tid % TPR) * EB; }
+  const bool a_vec = ((p.lda & 1) == 0) && ((((uintptr_t)p.A) & 15) == 0);
+  const bool b_vec = ((p.ldb & 1) == 0) && ((((uintptr_t)p.B) & 15) == 0);
+
+  auto load_tiles = [&](int kt) {
+    // A
+    if (TA) {
+      const int k = kt + a_k, i = i0 + a_i;
+      const double* src = p.A + (int64_t)k * p.lda + i;
+      if (k < kend && i + EA <= p.M && a_vec) {
+#pragma unroll
+        for (int e = 0; e < EA; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); ra[e] = v.x; ra[e + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EA; e++) ra[e] = (k < kend && i + e < p.M) ? src[e] : 0.0;
+      }
+      if (f.triA != TRI_NONE) {
+#pragma unroll
+        for (int e = 0; e < EA; e++) {
+          bool z = (f.triA == TRI_LOWER) ? (k > i + e) : (k < i + e);
+          if (z) ra[e] = 0.0;
+        }
+      }
+    } else {
+      const int i = i0 + a_i, k = kt + a_k;
+      const double* src = p.A + (int64_t)i * p.lda + k;
+      if (i < p.M && k + EA <= kend && a_vec) {
+#pragma unroll
+        for (int e = 0; e < EA; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); ra[e] = v.x; ra[e + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EA; e++) ra[e] = (i < p.M && k + e < kend) ? src[e] : 0.0;
+      }
+      if (f.triA != TRI_NONE) {
+#pragma unroll
+        for (int e = 0; e < EA; e++) {
+          bool z = (f.triA == TRI_LOWER) ? (k + e > i) : (k + e < i);
+          if (z) ra[e] = 0.0;
+        }
+      }
+    }
+    // B
+    if (TB) {
+      const int n = j0 + b_n, k = kt + b_k;
+      const double* src = p.B + (int64_t)n * p.ldb + k;
+      if (n < p.N && k + EB <= kend && b_vec) {
+#pragma unroll
+        for (int e = 0; e < EB; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); rb[e] = v.x; rb[e + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EB; e++) rb[e] = (n < p.N && k + e < kend) ? src[e] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < EB; e++) {
+        if (f.triB != TRI_NONE) {
+          bool z = (f.triB == TRI_LOWER) ? (n > k + e) : (k + e > n);
+          if (z) rb[e] = 0.0;
+        }
+        if (f.scale_mode == 1) rb[e] *= (n < p.N) ? p.v1[n] : 0.0;
+        if (f.scale_mode == 2) rb[e] *= (k + e < kend) ? p.v1[k + e] : 0.0;
+      }
+    } else {
+      const int k = kt + b_k, n = j0 + b_n;
+      const double* src = p.B + (int64_t)k * p.ldb + n;
+      if (k < kend && n + EB <= p.N && b_vec) {
+#pragma unroll
+        for (int e = 0; e < EB; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); rb[e] = v.x; rb[e + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EB; e++) rb[e] = (k < kend && n + e < p.N) ? src[e] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < EB; e++) {
+        if (f.triB != TRI_NONE) {
+          bool z = (f.triB == TRI_LOWER) ? (n + e > k) : (k > n + e);
+          if (z) rb[e] = 0.0;
+        }
+        if (f.scale_mode == 1) rb[e] *= (n + e < p.N) ? p.v1[n + e] : 0.0;
+        if (f.scale_mode == 2) rb[e] *= (k < kend) ? p.v1[k] : 0.0;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    double* As = smem + buf * S::STAGE;
+    double* Bs = As + S::A_ELEMS;
+    double* da = TA ? (As + a_k * S::SA + a_i) : (As + a_i * S::SA + a_k);
+#pragma unroll
+    for (int e = 0; e < EA; e += 2) *reinterpret_cast<double2*>(da + e) = make_double2(ra[e], ra[e + 1]);
+    double* db = TB ? (Bs + b_n * S::SB + b_k) : (Bs + b_k * S::SB + b_n);
+#pragma unroll
+    for (int e = 0; e < EB; e += 2) *reinterpret_cast<double2*>(db + e) = make_double2(rb[e], rb[e + 1]);
+  };
+
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+  if (kbeg < kend) {
+    load_tiles(kbeg);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kbeg; kt < kend; kt += GEMM_BK) {
+      const bool more = (kt + GEMM_BK < kend);
+      if (more) load_tiles(kt + GEMM_BK);
+      const double* As = smem + buf * S::STAGE;
+      const double* Bs = As + S::A_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < GEMM_BK / 4; ks++) {
+        double af[TM], bf[TN];
+        const int k = ks * 4 + kq;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+          const int i = wr * WM + a * 16 + lc;
+          af[a] = TA ? As[k * S::SA + i] : As[i * S::SA + k];
+        }
+#pragma unroll
+        for (int b = 0; b < TN; b++) {
+          const int n = wc * WN + b * 16 + lc;
+          bf[b] = TB ? Bs[n * S::SB + k] : Bs[k * S::SB + n];
+        }
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+          for (int b = 0; b < TN; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  if (f.ksplit > 1) {
+    double* slab = p.o2 + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+      for (int b = 0; b < TN; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + wr * WM + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
+          if (i < p.M && j < p.N) slab[(int64_t)i * p.N + j] = acc[a][b][r];
+        }
+    return;
+  }
+  if (f.epi & 1) {
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+      for (int b = 0; b < TN; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + wr * WM + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
+          if (i < p.M && j < p.N) {
+            double v = f.alpha * acc[a][b][r];
+            double* c = p.C + (int64_t)i * p.ldc + j;
+            if (f.beta != 0.0) v += f.beta * (*c);
+            if (f.triC == TRI_LOWER && j > i) v = 0.0;
+            *c = v;
+          }
+        }
+  }
+  if (f.epi & 6) {
+    // per-column reductions over this tile's rows: sum acc^2 and sum acc * v0[row]
+    __syncthreads();  // all waves are past their last LDS read
+    double* red = smem;  // [2 kinds][2 wave-rows][BN]
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+      double s2 = 0.0, sd = 0.0;
+#pragma unroll
+      for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + wr * WM + a * 16 + kq + 4 * r;
+          const double v = f.alpha * acc[a][b][r];  // rows >= M hold exact zeros
+          s2 = fma(v, v, s2);
+          if (f.epi & 4) sd = fma(v, (i < p.M) ? p.v0[i] : 0.0, sd);
+        }
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
+      if (kq == 0) {
+        const int n = wc * WN + b * 16 + lc;
+        red[(0 * 2 + wr) * BN + n] = s2;
+        red[(1 * 2 + wr) * BN + n] = sd;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int j = j0 + tid;
+      if (j < p.N) {
+        if (f.epi & 2) p.o0[(int64_t)tm * p.N + j] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
+        if (f.epi & 4) p.o1[(int64_t)tm * p.N + j] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+      }
+    }
+  }
+}
+
+// Sum split-K slabs (deterministic order) into C; optional symmetric mirror of the lower triangle.
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const GemmProblem* __restrict__ probs, int nsplit, int sym,
+                                                          double alpha) {
+  const GemmProblem p = probs[blockIdx.z];
+  const int64_t total = (int64_t)p.M * p.N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int i = (int)(idx / p.N), j = (int)(idx % p.N);
+    int si = i, sj = j;
+    if (sym && j > i) { si = j; sj = i; }
+    double s = 0.0;
+    for (int k = 0; k < nsplit; k++) s += p.o2[(int64_t)k * total + (int64_t)si * p.N + sj];
+    p.C[(int64_t)i * p.ldc + j] = alpha * s;
+  }
+}
+
+int gemm_rowblocks(int M, int big_tiles) { int bm = big_tiles ? 128 : 64; return (M + bm - 1) / bm; }
+
+template <int BM, int BN, bool TA, bool TB>
+static gp_status launch_one(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, GemmDevFlags df,
+                            int ksplit) {
+  using S = GemmSmem<BM, BN, TA, TB>;
+  df.tilesM = (maxM + BM - 1) / BM;
+  df.tilesN = (maxN + BN - 1) / BN;
+  df.ksplit = ksplit;
+  dim3 grid(df.tilesM * df.tilesN, ksplit > 1 ? ksplit : 1, batch);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f64_kernel<BM, BN, TA, TB>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, TA, TB>), grid, dim3(GEMM_THREADS), S::BYTES, h->stream, d_probs, df);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+template <int B>
+static gp_status dispatch_trans(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN,
+                                const GemmFlags& f, GemmDevFlags df, int ksplit) {
+  if (!f.transA && !f.transB) return launch_one<B, B, false, false>(h, d_probs, batch, maxM, maxN, df, ksplit);
+  if (f.transA && !f.transB) return launch_one<B, B, true, false>(h, d_probs, batch, maxM, maxN, df, ksplit);
+  if (!f.transA && f.transB) return launch_one<B, B, false, true>(h, d_probs, batch, maxM, maxN, df, ksplit);
+  return launch_one<B, B, true, true>(h, d_probs, batch, maxM, maxN, df, ksplit);
+}
+
+static GemmDevFlags to_dev(const GemmFlags& f) {
+  GemmDevFlags df;
+  df.triA = f.triA; df.triB = f.triB; df.triC = f.triC;
+  df.alpha = f.alpha; df.beta = f.beta;
+  df.epi = f.epilogue;
+  df.scale_mode = f.scale_mode;
+  df.ksplit = 1; df.tilesM = df.tilesN = 1;
+  return df;
+}
+
+gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN,
+                              const GemmFlags& f) {
+  if (batch <= 0 || maxM <= 0 || maxN <= 0) return GP_OK;
+  GpTimerScope ts(h, f.timer);
+  GemmDevFlags df = to_dev(f);
+  if (f.big_tiles) return dispatch_trans<128>(h, d_probs, batch, maxM, maxN, f, df, 1);
+  return dispatch_trans<64>(h, d_probs, batch, maxM, maxN, f, df, 1);
+}
+
+int gemm_nt_nsplit(int M, int Nlong) {
+  // enough K-slices that (tiles x slices) covers the chip a few times over, each slice >= 512 deep
+  int tiles = ((M + 127) / 128);
+  tiles = tiles * (tiles + 1) / 2;
+  int want = (4 * 256 + tiles - 1) / tiles;
+  int maxs = (Nlong + 511) / 512;
+  int s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return s;
+}
+
+gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
+                                        int nsplit, int sym, int scale_by_k, double alpha) {
+  if (batch <= 0 || maxM <= 0) return GP_OK;
+  (void)maxNlong;
+  {
+    GpTimerScope ts(h, GP_TIMER_NT_GEMM);
+    GemmFlags f;
+    f.transA = 0; f.transB = 1;
+    f.triC = sym ? TRI_LOWER : TRI_NONE;
+    f.scale_mode = scale_by_k ? 2 : 0;
+    GemmDevFlags df = to_dev(f);
+    df.epi = 1;
+    GP_CHECK((launch_one<128, 128, false, true>(h, d_probs, batch, maxM, maxM, df, nsplit > 1 ? nsplit : 2)));
+  }
+  {
+    GpTimerScope ts(h, GP_TIMER_SMALL_GEMM);
+    int blocks = (int)(((int64_t)maxM * maxM + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1, batch), dim3(256), 0, h->stream, d_probs,
+                       nsplit > 1 ? nsplit : 2, sym, alpha);
+    GP_HIP_CHECK(h, hipGetLastError());
+  }
+  return GP_OK;
+}

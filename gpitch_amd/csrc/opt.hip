@@ -1,0 +1,73 @@
+// opt.hip — GPflow free-state transforms and the TF-1.2 Adam update, on device (gfx950).
+//
+// Replaces the host side of gpflow Model.optimize(method=tf.train.AdamOptimizer) as driven by
+// demos/scripts/demo-modgp.py:44-45: Param free-state packing with transforms.positive (Log1pe,
+// lower = 1e-6; used at gpitch/likelihoods.py:283, gpitch/matern12_spectral_mixture.py:26-32,86-94)
+// and the Adam slots.  HBM-bound elementwise pass over the flat parameter vector, 16-byte friendly.
+#include "common.h"
+
+__device__ __forceinline__ double softplus_pos(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))) + 1e-6; }
+
+__global__ void __launch_bounds__(256) transform_fwd_kernel(const double* __restrict__ fs, const uint8_t* __restrict__ tc,
+                                                            int64_t n, double* __restrict__ params) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    params[i] = (tc[i] == 1) ? softplus_pos(fs[i]) : fs[i];
+}
+
+__global__ void __launch_bounds__(256) transform_bwd_kernel(const double* __restrict__ params, const uint8_t* __restrict__ tc,
+                                                            int64_t n, double* __restrict__ fs) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double y = params[i];
+    if (tc[i] == 1) { y -= 1e-6; y = y + log(-expm1(-y)); }
+    fs[i] = y;
+  }
+}
+
+// maximise ELBO: minimise -ELBO.  g = -(dELBO/dparam) * dparam/dfree.
+__global__ void __launch_bounds__(256) adam_kernel(double* __restrict__ fs, double* __restrict__ params,
+                                                   const double* __restrict__ grad, const uint8_t* __restrict__ tc,
+                                                   double* __restrict__ m, double* __restrict__ v, int64_t n, double lr_t,
+                                                   double b1, double b2, double eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint8_t t = tc[i];
+    if (t == 2) continue;
+    double x = fs[i];
+    double g = -grad[i];
+    if (t == 1) g *= 1.0 / (1.0 + exp(-x));
+    double mi = b1 * m[i] + (1.0 - b1) * g;
+    double vi = b2 * v[i] + (1.0 - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    x -= lr_t * mi / (sqrt(vi) + eps);
+    fs[i] = x;
+    params[i] = (t == 1) ? softplus_pos(x) : x;
+  }
+}
+
+static int ew_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+gp_status launch_transform_forward(gp_handle h, const double* fs, const uint8_t* tc, int64_t n, double* params) {
+  if (n <= 0) return GP_OK;
+  hipLaunchKernelGGL(transform_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, fs, tc, n, params);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+gp_status launch_transform_backward(gp_handle h, const double* params, const uint8_t* tc, int64_t n, double* fs) {
+  if (n <= 0) return GP_OK;
+  hipLaunchKernelGGL(transform_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, params, tc, n, fs);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+gp_status launch_adam(gp_handle h, double* fs, double* params, const double* grad, const uint8_t* tc, double* m,
+                      double* v, int64_t n, int64_t t, double lr, double b1, double b2, double eps) {
+  if (n <= 0) return GP_OK;
+  const double lr_t = lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t));
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, fs, params, grad, tc, m, v, n, lr_t, b1,
+                     b2, eps);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}

@@ -1,0 +1,232 @@
+// pdgp.hip — the Pdgp model plan: ELBO forward / backward and predictions behind the C-ABI.
+// Mirrors gpitch/pdgp.py:48-208 (Pdgp.build_prior_kl :113-131, build_likelihood :133-170,
+// predict_act / predict_com / predict_act_n_com :172-208).
+#include "pdgp_plan.h"
+#include <string.h>
+
+static inline int64_t ldN_of64(int N) { return (N + 1) & ~1; }
+
+static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
+  size_t d = 0;
+  auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
+  for (int g = 0; g < p->G; g++) {
+    const size_t M = p->gps[g].M;
+    for (int i = 0; i < 6; i++) add(M * M);
+    add(M * (size_t)ldN_of64(p->maxN));
+    add(M); add(M); add(M);
+    const size_t ns = hyper_num_sums(p->gps[g].m);
+    const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
+    add(ns * colblocks * rowblocks);
+    add(ns * ((M + 255) / 256 + 1) * rowblocks);
+    add(colblocks * M + ((M + 255) / 256 + 1) * M);
+    add(8);
+  }
+  return d;
+}
+
+extern "C" {
+
+gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* out) {
+  if (!h || !out) return GP_ERR_BAD_ARG;
+  *out = nullptr;
+  if (!cfg || cfg->num_sources < 1 || cfg->max_batch < 1 || !cfg->M_act || !cfg->M_com || !cfg->kern_type_act ||
+      !cfg->kern_type_com || !cfg->partials_act || !cfg->partials_com || cfg->nlin < 0 || cfg->nlin > 2)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_create: bad config");
+  gp_pdgp_plan p = new gp_pdgp_plan_s();
+  p->h = h; p->P = cfg->num_sources; p->G = 2 * p->P; p->whiten = cfg->whiten ? 1 : 0; p->nlin = cfg->nlin;
+  p->maxN = cfg->max_batch; p->jitter = cfg->jitter;
+  p->gps.resize(p->G);
+  int64_t off = 1;  // [0] = noise variance
+  for (int g = 0; g < p->G; g++) {
+    PdgpGP& q = p->gps[g];
+    const bool act = g < p->P;
+    const int i = act ? g : g - p->P;
+    q.M = act ? cfg->M_act[i] : cfg->M_com[i];
+    q.ktype = act ? cfg->kern_type_act[i] : cfg->kern_type_com[i];
+    q.m = act ? cfg->partials_act[i] : cfg->partials_com[i];
+    const bool sm = (q.ktype == GP_KERN_MERCER_MATERN12SM || q.ktype == GP_KERN_MATERN12SM);
+    if (q.M < 1 || q.ktype < 0 || q.ktype > GP_KERN_MATERN12SM || (sm && (q.m < 1 || q.m > 32)) || (!sm && q.m != 0)) {
+      delete p;
+      return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_create: bad per-GP config");
+    }
+    q.off_theta = off; off += GP_THETA_LEN(q.m);
+    q.off_z = off; off += q.M;
+    q.off_qmu = off; off += q.M;
+    // keep q_sqrt 16-byte aligned inside the vector so it can be a vectorised GEMM operand
+    if (off & 1) off += 1;
+    q.off_qsqrt = off; off += (int64_t)q.M * q.M;
+    if (q.M > p->maxM) p->maxM = q.M;
+    if (q.m > p->maxm) p->maxm = q.m;
+  }
+  p->nparams = off;
+  *out = p;
+  return GP_OK;
+}
+
+gp_status gp_pdgp_destroy(gp_pdgp_plan p) { delete p; return GP_OK; }
+int64_t gp_pdgp_num_params(gp_pdgp_plan p) { return p ? p->nparams : 0; }
+
+gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t* off_z, int64_t* off_qmu,
+                         int64_t* off_qsqrt) {
+  if (!p || g < 0 || g >= p->G) return GP_ERR_BAD_ARG;
+  if (off_theta) *off_theta = p->gps[g].off_theta;
+  if (off_z) *off_z = p->gps[g].off_z;
+  if (off_qmu) *off_qmu = p->gps[g].off_qmu;
+  if (off_qsqrt) *off_qsqrt = p->gps[g].off_qsqrt;
+  return GP_OK;
+}
+
+static size_t pdgp_misc_bytes(const gp_pdgp_plan_s* p) {
+  return gp_align_up(p->G * kl_item_bytes(), 256) + 16 * gp_align_up(p->G * sizeof(GemmProblem), 256);
+}
+
+size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
+  if (!p) return 0;
+  size_t d = 0;
+  for (int g = 0; g < p->G; g++) d += cond_task_workspace_doubles(p->gps[g].M, p->maxN, p->gps[g].m, p->whiten != 0);
+  auto addd = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
+  for (int i = 0; i < 4; i++) addd((size_t)p->G * p->maxN);
+  addd(p->G);
+  addd(2 * ((size_t)(p->maxN + 255) / 256) + 8);
+  if (p->whiten) {
+    d += pdgp_bwd_doubles(p);
+    int ns = gemm_nt_nsplit(p->maxM, p->maxN);
+    if (ns < 2) ns = 2;
+    size_t slab = 0;
+    for (int g = 0; g < p->G; g++) slab += gp_align_up((size_t)ns * p->gps[g].M * p->gps[g].M * sizeof(double), 256) / sizeof(double);
+    d += slab;
+  }
+  return d * sizeof(double) + cond_batch_desc_bytes(p->G) + pdgp_misc_bytes(p) + 8192;
+}
+
+gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
+  if (!p) return GP_ERR_BAD_ARG;
+  if (!workspace || bytes < gp_pdgp_workspace_bytes(p) || (((uintptr_t)workspace) & 255))
+    return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_pdgp_set_workspace: workspace too small or not 256-byte aligned");
+  p->ws = workspace; p->ws_bytes = bytes;
+  GpArena ar(workspace, bytes);
+  p->cb.tasks.assign(p->G, CondTask());
+  p->cb.desc_bytes = cond_batch_desc_bytes(p->G);
+  p->cb.d_desc = ar.take<char>(p->cb.desc_bytes);
+  p->misc_bytes = pdgp_misc_bytes(p);
+  p->d_misc = ar.take<char>(p->misc_bytes);
+  p->fmean = ar.take<double>((size_t)p->G * p->maxN);
+  p->fvar = ar.take<double>((size_t)p->G * p->maxN);
+  p->gFmu = ar.take<double>((size_t)p->G * p->maxN);
+  p->gFvar = ar.take<double>((size_t)p->G * p->maxN);
+  p->kl = ar.take<double>(p->G);
+  p->lik_partials = ar.take<double>(2 * ((size_t)(p->maxN + 255) / 256) + 8);
+  for (int g = 0; g < p->G; g++) {
+    CondTask& t = p->cb.tasks[g];
+    t.M = p->gps[g].M;
+    t.kern = DevKern{p->gps[g].ktype, p->gps[g].m, nullptr};
+    if (!cond_task_carve(ar, t, p->maxN, p->whiten != 0)) return gp_fail(p->h, GP_ERR_WORKSPACE, "workspace carve failed");
+  }
+  p->bw.assign(p->G, BwdBufs());
+  if (p->whiten) {
+    p->nsplit = gemm_nt_nsplit(p->maxM, p->maxN);
+    if (p->nsplit < 2) p->nsplit = 2;
+    for (int g = 0; g < p->G; g++) {
+      const size_t M = p->gps[g].M;
+      BwdBufs& b = p->bw[g];
+      b.H = ar.take<double>(M * M); b.E = ar.take<double>(M * M); b.T1 = ar.take<double>(M * M);
+      b.T2 = ar.take<double>(M * M); b.Wbar = ar.take<double>(M * M); b.R = ar.take<double>(M * M);
+      b.G = ar.take<double>(M * (size_t)ldN_of64(p->maxN));
+      b.u = ar.take<double>(M); b.Lu = ar.take<double>(M); b.alpha = ar.take<double>(M);
+      const size_t ns = hyper_num_sums(p->gps[g].m);
+      const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
+      b.hyp_part = ar.take<double>(ns * colblocks * rowblocks);
+      b.hyp_part_uu = ar.take<double>(ns * ((M + 255) / 256 + 1) * rowblocks);
+      b.gz_part = ar.take<double>(colblocks * M + ((M + 255) / 256 + 1) * M);
+      b.gvsum = ar.take<double>(8);
+    }
+    size_t slab_total = 0;
+    for (int g = 0; g < p->G; g++) slab_total += gp_align_up((size_t)p->nsplit * p->gps[g].M * p->gps[g].M * sizeof(double), 256) / sizeof(double);
+    p->slabs = ar.take<double>(slab_total);
+  }
+  if (!ar.ok) return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_pdgp_set_workspace: arena exhausted");
+  p->last_params = nullptr; p->last_n = -1;
+  return GP_OK;
+}
+
+}  // extern "C"
+
+gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad);  // bwd.hip
+gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad);
+
+// (re)bind the parameter vector / batch to the device descriptors
+static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad,
+                           double* fmean, double* fvar) {
+  gp_handle h = p->h;
+  const bool same = (p->last_params == params && p->last_x == x && p->last_n == n && p->last_grad == grad &&
+                     p->cb.tasks[0].fmean == fmean);
+  if (same && p->cb.uploaded) return GP_OK;
+  for (int g = 0; g < p->G; g++) {
+    CondTask& t = p->cb.tasks[g];
+    const PdgpGP& q = p->gps[g];
+    t.kern.theta = params + q.off_theta;
+    t.z = params + q.off_z;
+    t.q_mu = params + q.off_qmu;
+    t.q_sqrt = params + q.off_qsqrt;
+    t.fmean = fmean + (size_t)g * n;
+    t.fvar = fvar + (size_t)g * n;
+  }
+  p->cb.N = n;
+  GP_CHECK(cond_batch_upload(h, p->cb, p->whiten != 0));
+  // KL items
+  p->h_misc.assign(p->misc_bytes, 0);
+  p->off_kl_items = 0;
+  for (int g = 0; g < p->G; g++) {
+    const PdgpGP& q = p->gps[g];
+    kl_item_fill(p->h_misc.data() + p->off_kl_items + g * kl_item_bytes(), params + q.off_qmu, params + q.off_qsqrt, q.M,
+                 p->kl + g, grad ? grad + q.off_qmu : nullptr, grad ? grad + q.off_qsqrt : nullptr);
+  }
+  if (grad && p->whiten) GP_CHECK(pdgp_upload_bwd(p, params, x, n, grad));
+  GP_HIP_CHECK(h, hipMemcpyAsync(p->d_misc, p->h_misc.data(), p->misc_bytes, hipMemcpyHostToDevice, h->stream));
+  p->last_params = params; p->last_x = x; p->last_n = n; p->last_grad = grad;
+  return GP_OK;
+}
+
+extern "C" {
+
+gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                       double num_data, double* elbo_dev, double* elbo_host, double* grad) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo: workspace not set");
+  if (!params || !x || !y || !elbo_dev || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo: bad argument");
+  if (grad && !p->whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo: gradient needs whiten=1");
+  GP_CHECK(pdgp_bind(p, params, x, n, grad, p->fmean, p->fvar));
+  if (grad) GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
+  GP_CHECK(cond_batch_run(h, p->cb, x, n, p->whiten != 0, p->jitter));
+  int nb = 0;
+  const double scale = num_data / (double)n;
+  GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
+                          grad ? p->gFmu : nullptr, grad ? p->gFvar : nullptr));
+  if (p->whiten) {
+    GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl_items, p->G));
+  } else {
+    return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo: whiten=0 ELBO not implemented yet");
+  }
+  GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G, elbo_dev, grad ? grad : nullptr));
+  if (grad) GP_CHECK(pdgp_backward(p, params, x, n, grad));
+  if (elbo_host) {
+    GP_HIP_CHECK(h, hipMemcpyAsync(elbo_host, elbo_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GP_CHECK(check_not_pd(h));
+  }
+  return GP_OK;
+}
+
+gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n, double* fmean,
+                          double* fvar, double* mean_source) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_predict: workspace not set");
+  if (!params || !xnew || !fmean || !fvar || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_predict: bad argument");
+  GP_CHECK(pdgp_bind(p, params, xnew, n, nullptr, fmean, fvar));
+  GP_CHECK(cond_batch_run(h, p->cb, xnew, n, p->whiten != 0, p->jitter));
+  if (mean_source) GP_CHECK(launch_mean_source(h, fmean, p->P, n, p->nlin, mean_source));
+  return check_not_pd(h);
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// pdgp_plan.h — Pdgp plan object shared by pdgp.hip (forward) and bwd.hip (backward).
+#pragma once
+#include "engine.h"
+
+struct PdgpGP {
+  int M = 0, ktype = 0, m = 0;
+  int64_t off_theta = 0, off_z = 0, off_qmu = 0, off_qsqrt = 0;
+};
+
+struct BwdBufs {  // per-GP backward workspace (device)
+  double* H = nullptr;      // M x M   A D A^T
+  double* E = nullptr;      // M x M   Lq Lq^T - I
+  double* T1 = nullptr;     // M x M   scratch
+  double* T2 = nullptr;     // M x M   scratch
+  double* Wbar = nullptr;   // M x M
+  double* R = nullptr;      // M x M   W^T E
+  double* G = nullptr;      // M x N   K̄uf (dense part R (A D))
+  double* u = nullptr;      // M       A gm
+  double* Lu = nullptr;     // M       L u
+  double* alpha = nullptr;  // M       W^T q_mu
+  double* hyp_part = nullptr;   // hyper-gradient partial sums (Kuf side)
+  double* hyp_part_uu = nullptr;
+  double* gz_part = nullptr;    // z-gradient partials
+  double* gvsum = nullptr;      // sum_n gv
+};
+
+struct gp_pdgp_plan_s {
+  gp_handle h = nullptr;
+  int P = 0, G = 0, whiten = 1, nlin = 0, maxN = 0;
+  double jitter = 1e-6;
+  std::vector<PdgpGP> gps;
+  int64_t nparams = 0;
+  int maxM = 0, maxm = 0;
+  // workspace
+  void* ws = nullptr; size_t ws_bytes = 0;
+  CondBatch cb;
+  std::vector<BwdBufs> bw;
+  double* fmean = nullptr; double* fvar = nullptr;   // [G][maxN]
+  double* gFmu = nullptr; double* gFvar = nullptr;   // [G][maxN]
+  double* kl = nullptr;                              // [G]
+  double* lik_partials = nullptr;                    // [2 * blocks]
+  double* slabs = nullptr;                           // split-K slabs
+  char* d_misc = nullptr; size_t misc_bytes = 0;     // KL items + backward problem arrays
+  std::vector<char> h_misc;
+  size_t off_kl_items = 0;
+  size_t off_bwd[16] = {0};
+  int nsplit = 1;
+  // cache keys for the descriptor upload
+  const double* last_params = nullptr; const double* last_x = nullptr; double* last_grad = nullptr; int last_n = -1;
+  bool bwd_carved = false;
+};
+

@@ -1,0 +1,220 @@
+/*
+ * gpitch_abi.h — C-ABI of libgpitch_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the gpitch `pdgp` / `sgpr_ss` ELBO path.  The reference
+ * (PabloAlvarado/gpitch) has NO FFI boundary of its own: the path is Python objects over a
+ * TensorFlow graph.  Each entry point below therefore replaces the TF/GPflow op sequence behind one
+ * reference *operator* call; the reference interface it replaces is cited as file:line relative to
+ * the reference tree.  The ctypes binding a gpitch maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all array arguments are DEVICE pointers to float64 unless the
+ *    name ends in `_host`; matrices are row-major with explicit leading dimension where given;
+ *  - the caller allocates and owns every buffer (including workspaces); the library owns only the
+ *    opaque handle / plan objects;
+ *  - every call returns a gp_status; nothing throws across the boundary; calls enqueue work on the
+ *    handle's HIP stream and return immediately unless they produce a host scalar;
+ *  - a handle is bound to one (process, GPU) and is not thread-safe.
+ *  - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
+ *    GP_ERR_HIP / GP_ERR_NO_DEVICE.
+ */
+#ifndef GPITCH_ABI_H
+#define GPITCH_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPITCH_ABI_VERSION 1
+
+typedef int32_t gp_status;
+enum {
+  GP_OK = 0,
+  GP_ERR_BAD_ARG = 1,
+  GP_ERR_NOT_PD = 2,     /* Cholesky hit a non-positive pivot (TF InvalidArgumentError in the reference) */
+  GP_ERR_HIP = 3,        /* a HIP runtime call failed; gp_last_error() has the text */
+  GP_ERR_NO_DEVICE = 4,
+  GP_ERR_WORKSPACE = 5,  /* caller-provided workspace too small */
+  GP_ERR_UNSUPPORTED = 6
+};
+
+/* kernel (covariance function) types — the GPflow operator API `Kern.K(X, X2)`, `Kern.Kdiag(X)` */
+enum {
+  GP_KERN_MATERN12 = 0,          /* gpflow.kernels.Matern12  (init_models.py:83)                 */
+  GP_KERN_MATERN32 = 1,          /* gpflow.kernels.Matern32  (init_kernels.py:12, demo-modgp.py:32) */
+  GP_KERN_MATERN52 = 2,          /* gpflow.kernels.Matern52  (init_models.py:188)                */
+  GP_KERN_RBF = 3,               /* gpflow.kernels.RBF                                            */
+  GP_KERN_MERCER_MATERN12SM = 4, /* gpitch/matern12_spectral_mixture.py:70-133                    */
+  GP_KERN_MATERN12SM = 5         /* gpitch/matern12_spectral_mixture.py:14-67                     */
+};
+
+/* nonlinearities of the modulated likelihood — gpitch/methods.py:216-233 */
+enum { GP_NLIN_LOGISTIC = 0, GP_NLIN_SOFTPLUS = 1, GP_NLIN_GAUSS = 2 };
+
+/* Kernel descriptor.  `theta` is a DEVICE pointer to the constrained hyper-parameters
+ *   [variance, lengthscales, energy_0..energy_{m-1}, frequency_0..frequency_{m-1}]  (m = num_partials,
+ *   0 for the plain stationary kernels) — device-resident so an optimiser step never syncs the host. */
+typedef struct {
+  int32_t type;
+  int32_t num_partials;
+  const double* theta;
+} gp_kernel_desc;
+
+#define GP_THETA_LEN(m) (2 + 2 * (m))
+
+typedef struct gp_handle_s* gp_handle;
+typedef struct gp_pdgp_plan_s* gp_pdgp_plan;
+typedef struct gp_sgpr_plan_s* gp_sgpr_plan;
+
+/* ---- runtime -------------------------------------------------------------------------------- */
+/* replaces gpitch.init_settings / the global TF session (gpitch/methods.py:155-180).
+ * `stream` is the hipStream_t every call enqueues on; NULL = HIP's default (null) stream. */
+gp_status gp_create(int32_t device_id, void* stream, gp_handle* out);
+gp_status gp_destroy(gp_handle h);
+gp_status gp_sync(gp_handle h);
+const char* gp_last_error(gp_handle h);       /* text of the last failure on this handle */
+int32_t gp_abi_version(void);
+/* pivot index reported by the last GP_ERR_NOT_PD (−1 if none) */
+int32_t gp_last_not_pd_index(gp_handle h);
+
+/* ---- L2 operators: Kern.K / Kern.Kdiag --------------------------------------------------------
+ * replaces MercerMatern12sm.K (matern12_spectral_mixture.py:102-117), Matern12sm.K (:38-56) and GPflow
+ * Stationary.K for Matern12/32/52/RBF.  out[i*ld + j] = k(x1[i], x2[j]);  x2 == NULL means K(X) (x2 = x1).
+ * `accumulate` != 0 adds into `out` (GPflow `Add` kernel: sgpr_ss.py:42-43). */
+gp_status gp_kernel_build(gp_handle h, const gp_kernel_desc* kern, const double* x1, int32_t n1,
+                          const double* x2, int32_t n2, double* out, int64_t ld, int32_t accumulate);
+/* Kern.Kdiag(X): exact fill (matern12_spectral_mixture.py:58-62,119-121) */
+gp_status gp_kernel_diag(gp_handle h, const gp_kernel_desc* kern, int32_t n, double* out, int32_t accumulate);
+
+/* ---- GPflow conditional pieces ------------------------------------------------------------------
+ * Kmm = K(z) + jitter I ; Lm = chol(Kmm) ; Linv = Lm^-1   (GPflow conditional, from pdgp.py:147;
+ * sgpr_ss.py:43-44).  L and Linv are M x M row-major (ld = M), strictly-upper part zeroed.
+ * Either output may be NULL.  workspace: gp_chol_workspace_bytes(M). */
+size_t gp_chol_workspace_bytes(int32_t M);
+gp_status gp_kuu_cholesky(gp_handle h, const gp_kernel_desc* kern, const double* z, int32_t M, double jitter,
+                          double* L, double* Linv, void* workspace, size_t workspace_bytes);
+/* dense lower Cholesky of a caller-supplied SPD matrix (tf.cholesky: sgpr_ss.py:44,51,89), in place */
+gp_status gp_cholesky_inplace(gp_handle h, double* A, int32_t M, int64_t ld);
+
+/* gpflow.conditionals.conditional(Xnew, z, kern, f=q_mu, full_cov=False, q_sqrt, whiten)
+ * (call sites pdgp.py:147-155,176-178,185-187,199-205).  q_sqrt is the M x M (x1) matrix; its lower
+ * triangle is used (matrix_band_part).  fmean, fvar: N values each.  q_sqrt may be NULL.
+ * workspace: gp_conditional_workspace_bytes(N, M). */
+size_t gp_conditional_workspace_bytes(int32_t N, int32_t M);
+gp_status gp_conditional_diag(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N,
+                              const double* z, int32_t M, const double* q_mu, const double* q_sqrt,
+                              int32_t whiten, double jitter, double* fmean, double* fvar,
+                              void* workspace, size_t workspace_bytes);
+
+/* gpflow.kullback_leiblers.gauss_kl(q_mu, q_sqrt, K=None) (pdgp.py:120-121 whitened; :126-129 with
+ * K = kern.K(z) + jitter I built internally when kern != NULL).  Result to *out_host (syncs). */
+gp_status gp_gauss_kl(gp_handle h, const double* q_mu, const double* q_sqrt, int32_t M,
+                      const gp_kernel_desc* kern_or_null, const double* z, double jitter,
+                      double* out_host, void* workspace, size_t workspace_bytes);
+
+/* MpdLik.variational_expectations(Fmu, Fvar, Y) (likelihoods.py:422-447 + hermgauss1d :33-45 +
+ * log_lik_exp :47-68).  Fmu/Fvar are N x 2P row-major with columns [g_0..g_{P-1}, f_0..f_{P-1}]
+ * (pdgp.py:157-164).  noise_var is a device scalar.  per_frame (N values) may be NULL; the sum over
+ * frames is written to *sum_host when non-NULL (syncs). */
+gp_status gp_mpd_varexp(gp_handle h, const double* Fmu, const double* Fvar, const double* y, int32_t N,
+                        int32_t P, int32_t nlin, const double* noise_var, double* per_frame, double* sum_host);
+
+/* ---- L3 model: Pdgp (gpitch/pdgp.py:48-208) ---------------------------------------------------
+ * Parameter vector layout (float64, constrained space), offsets returned by gp_pdgp_layout:
+ *   [ noise_var | for g in (act_0..act_{P-1}, com_0..com_{P-1}):
+ *                   theta_g (2+2m_g) | z_g (M_g) | q_mu_g (M_g) | q_sqrt_g (M_g x M_g row-major) ]
+ * The same layout is used for the gradient vector, the free-state vector and the Adam moments. */
+typedef struct {
+  int32_t num_sources;            /* P */
+  int32_t whiten;                 /* pdgp.py:49 (only whiten=1 has a backward pass) */
+  int32_t nlin;                   /* GP_NLIN_* (pdgp.py:49 nlinfun) */
+  int32_t max_batch;              /* largest minibatch N the plan will see */
+  const int32_t* M_act;           /* host, P entries (pdgp.py:93) */
+  const int32_t* M_com;           /* host, P entries (pdgp.py:94) */
+  const int32_t* kern_type_act;   /* host, P entries GP_KERN_* */
+  const int32_t* kern_type_com;
+  const int32_t* partials_act;    /* host, P entries (0 for plain stationary) */
+  const int32_t* partials_com;
+  double jitter;                  /* settings.numerics.jitter_level = 1e-6 (pdgp.py:14) */
+} gp_pdgp_config;
+
+gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* out);
+gp_status gp_pdgp_destroy(gp_pdgp_plan p);
+int64_t gp_pdgp_num_params(gp_pdgp_plan p);
+/* offsets into the parameter vector for GP index g in [0, 2P): g < P activation i=g, else component */
+gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t* off_z, int64_t* off_qmu,
+                         int64_t* off_qsqrt);
+size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p);
+gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes);
+
+/* Pdgp.build_likelihood (pdgp.py:133-170) on the batch (x, y) of n frames:
+ *   elbo = (num_data / n) * sum_n varexp_n - KL.   Writes the scalar to elbo_dev[0] (device) and, when
+ * elbo_host != NULL, copies it to the host (syncs).  When grad != NULL also writes d elbo / d params
+ * (constrained space, layout above) — what TF reverse-mode provides through Model.optimize. */
+gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                       double num_data, double* elbo_dev, double* elbo_host, double* grad);
+
+/* Pdgp.predict_act / predict_com / predict_act_n_com (pdgp.py:172-208): conditionals at xnew for all 2P
+ * GPs.  fmean/fvar: 2P x n row-major (row g as in gp_pdgp_layout).  mean_source (P x n, may be NULL)
+ * = nlinfun(mean_act_i) * mean_com_i (pdgp.py:207). */
+gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n,
+                          double* fmean, double* fvar, double* mean_source);
+
+/* ---- optimiser on the free state (GPflow Model.optimize with tf.train.AdamOptimizer;
+ *      demo-modgp.py:44-45; transforms: GPflow Log1pe 'positive') -----------------------------------
+ * tcode[i]: 0 identity, 1 positive (y = log(1+e^x) + 1e-6), 2 fixed (identity, no update). */
+gp_status gp_transform_forward(gp_handle h, const double* free_state, const uint8_t* tcode, int64_t n,
+                               double* params);
+gp_status gp_transform_backward(gp_handle h, const double* params, const uint8_t* tcode, int64_t n,
+                                double* free_state);
+/* One Adam step maximising the ELBO: g_free = -(grad * dparams/dfree); TF-1.2 update rule; then
+ * params = transform(free).  t is the 1-based step count. */
+gp_status gp_adam_step(gp_handle h, double* free_state, double* params, const double* grad,
+                       const uint8_t* tcode, double* m, double* v, int64_t n, int64_t t, double lr,
+                       double beta1, double beta2, double eps);
+
+/* ---- L3 model: SGPRSS (gpitch/sgpr_ss.py:10-114) ---------------------------------------------- */
+typedef struct {
+  int32_t num_kernels;          /* P kernels in the GPflow Add (kern.kern_list) */
+  int32_t max_N;
+  int32_t M;
+  const int32_t* kern_type;     /* host, P entries */
+  const int32_t* partials;      /* host, P entries */
+  double jitter;
+  int32_t reg;                  /* sgpr_ss.py:64-68: subtract 1000 * sum |variance_p| */
+} gp_sgpr_config;
+/* parameter vector: [ noise_var | theta_0 | ... | theta_{P-1} ]  (Z is a DataHolder: sgpr_ss.py:26) */
+gp_status gp_sgpr_create(gp_handle h, const gp_sgpr_config* cfg, gp_sgpr_plan* out);
+gp_status gp_sgpr_destroy(gp_sgpr_plan p);
+int64_t gp_sgpr_num_params(gp_sgpr_plan p);
+size_t gp_sgpr_workspace_bytes(gp_sgpr_plan p);
+gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes);
+/* SGPRSS.build_likelihood (sgpr_ss.py:29-71), D = 1 output column.  bound_host may be NULL. */
+gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                        const double* Z, double* bound_dev, double* bound_host);
+/* GPflow SGPR.build_predict (predict_f; separation.py:306) at Xnew: mean, var (n values each) */
+gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                            const double* Z, const double* Xnew, int32_t n, double* mean, double* var);
+/* SGPRSS.build_predict_source / predict_s (sgpr_ss.py:73-114): exact GP with an N x N Cholesky;
+ * mean/var are P x n row-major.  workspace: gp_sgpr_predict_source_workspace_bytes(N, n). */
+size_t gp_sgpr_predict_source_workspace_bytes(int32_t N, int32_t n);
+gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const double* X, const double* Y,
+                                 int32_t N, const double* Xnew, int32_t n, double* mean, double* var,
+                                 void* workspace, size_t workspace_bytes);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------------
+ * HIP-event timing of the dominant kernels on the handle's own stream.  Returns the accumulated time of
+ * kernel class `which` since the last reset and the number of launches. */
+enum { GP_TIMER_KUF_BUILD = 0, GP_TIMER_STRIP_GEMM = 1, GP_TIMER_NT_GEMM = 2, GP_TIMER_CHOL = 3,
+       GP_TIMER_LIK = 4, GP_TIMER_SMALL_GEMM = 5, GP_TIMER_HYPER = 6, GP_TIMER_COUNT = 7 };
+gp_status gp_timers_enable(gp_handle h, int32_t on);
+gp_status gp_timers_reset(gp_handle h);
+gp_status gp_timers_read(gp_handle h, int32_t which, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPITCH_ABI_H */

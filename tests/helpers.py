@@ -1,0 +1,101 @@
+"""Shared test helpers (no GPU needed to import)."""
+import numpy as np
+
+
+def kernels_from_problem(prob):
+    """product kernel objects for the oracle-format kernel dicts of gpitch_amd.synth.make_problem"""
+    import gpitch_amd
+    from gpitch_amd.kernels import Matern12, Matern32, Matern52, RBF
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm, Matern12sm
+    cls = {"matern12": Matern12, "matern32": Matern32, "matern52": Matern52, "rbf": RBF}
+
+    def mk(d):
+        if d["type"] == "mercer_matern12sm":
+            return MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]),
+                                    variance=d["variance"], lengthscales=d["lengthscales"])
+        if d["type"] == "matern12sm":
+            return Matern12sm(1, variance=d["variance"], lengthscales=d["lengthscales"],
+                              energy=np.array(d["energy"]), frequency=np.array(d["frequency"]))
+        return cls[d["type"]](1, variance=d["variance"], lengthscales=d["lengthscales"])
+    return [[mk(d) for d in prob["kern_act"]], [mk(d) for d in prob["kern_com"]]]
+
+
+def pdgp_from_problem(prob, whiten=True, minibatch_size=None, nlinfun=None, handle=None):
+    import gpitch_amd
+    from gpitch_amd.pdgp import Pdgp
+    kern = kernels_from_problem(prob)
+    m = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kern, whiten=whiten, minibatch_size=minibatch_size,
+             nlinfun=nlinfun or gpitch_amd.logistic_tf, handle=handle)
+    for i in range(prob["P"]):
+        m.q_mu_act[i].value = prob["q_mu_act"][i]
+        m.q_mu_com[i].value = prob["q_mu_com"][i]
+        m.q_sqrt_act[i].value = prob["q_sqrt_act"][i]
+        m.q_sqrt_com[i].value = prob["q_sqrt_com"][i]
+    m.likelihood.variance = prob["noise_var"]
+    return m
+
+
+def oracle_elbo(prob, whiten=True, nlin_code=0, xp=None):
+    from oracle import gpflow05 as orc
+    from oracle.backend import NP
+    xp = xp or NP
+    return orc.pdgp_elbo(prob["x"], prob["y"], prob["za"], prob["zc"], prob["kern_act"], prob["kern_com"],
+                         prob["q_mu_act"], prob["q_sqrt_act"], prob["q_mu_com"], prob["q_sqrt_com"],
+                         prob["noise_var"], whiten=whiten, nlin_code=nlin_code, xp=xp)
+
+
+def oracle_elbo_and_grads(prob, nlin_code=0):
+    """ELBO and its gradient w.r.t. every constrained parameter by torch-CPU autograd through the
+    oracle's restatement (mirrors TF reverse-mode)."""
+    import torch
+    from oracle import gpflow05 as orc
+    from oracle.backend import TorchBackend
+    tb = TorchBackend()
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=True)
+    P = prob["P"]
+    leaves = {"noise": T(prob["noise_var"])}
+
+    def tk(d, name):
+        out = dict(d)
+        out["variance"] = leaves.setdefault(name + ".variance", T(d["variance"]))
+        out["lengthscales"] = leaves.setdefault(name + ".lengthscales", T(d["lengthscales"]))
+        out["energy"] = [leaves.setdefault("%s.energy%d" % (name, j), T(e)) for j, e in enumerate(d["energy"])]
+        out["frequency"] = [leaves.setdefault("%s.frequency%d" % (name, j), T(f)) for j, f in enumerate(d["frequency"])]
+        return out
+    ka = [tk(d, "act%d" % i) for i, d in enumerate(prob["kern_act"])]
+    kc = [tk(d, "com%d" % i) for i, d in enumerate(prob["kern_com"])]
+    za = [leaves.setdefault("za%d" % i, T(prob["za"][i])) for i in range(P)]
+    zc = [leaves.setdefault("zc%d" % i, T(prob["zc"][i])) for i in range(P)]
+    qma = [leaves.setdefault("q_mu_act%d" % i, T(prob["q_mu_act"][i])) for i in range(P)]
+    qmc = [leaves.setdefault("q_mu_com%d" % i, T(prob["q_mu_com"][i])) for i in range(P)]
+    qsa = [leaves.setdefault("q_sqrt_act%d" % i, T(prob["q_sqrt_act"][i])) for i in range(P)]
+    qsc = [leaves.setdefault("q_sqrt_com%d" % i, T(prob["q_sqrt_com"][i])) for i in range(P)]
+    x = torch.tensor(prob["x"]); y = torch.tensor(prob["y"])
+    elbo = orc.pdgp_elbo(x, y, za, zc, ka, kc, qma, qsa, qmc, qsc, leaves["noise"], whiten=True,
+                         nlin_code=nlin_code, xp=tb)
+    elbo.backward()
+    return float(elbo.detach()), {k: (v.grad.numpy().copy() if v.grad is not None else None) for k, v in leaves.items()}
+
+
+def model_grad_dict(m):
+    """the engine's gradient vector split by parameter name (same keys as oracle_elbo_and_grads)"""
+    g = m._grad.cpu().numpy()
+    P = m.num_sources
+    out = {"noise": g[0:1].copy()}
+    for gi in range(2 * P):
+        act = gi < P
+        i = gi if act else gi - P
+        name = ("act%d" if act else "com%d") % i
+        kern = (m.kern_act if act else m.kern_com)[i]
+        o_th, o_z, o_mu, o_sq = m._layout[gi]
+        mpart = int(kern.num_partials)
+        out[name + ".variance"] = g[o_th:o_th + 1].copy()
+        out[name + ".lengthscales"] = g[o_th + 1:o_th + 2].copy()
+        for j in range(mpart):
+            out["%s.energy%d" % (name, j)] = g[o_th + 2 + j:o_th + 3 + j].copy()
+            out["%s.frequency%d" % (name, j)] = g[o_th + 2 + mpart + j:o_th + 3 + mpart + j].copy()
+        M = (m.num_inducing_a if act else m.num_inducing_c)[i]
+        out[("za%d" if act else "zc%d") % i] = g[o_z:o_z + M].reshape(-1, 1).copy()
+        out[("q_mu_act%d" if act else "q_mu_com%d") % i] = g[o_mu:o_mu + M].reshape(-1, 1).copy()
+        out[("q_sqrt_act%d" if act else "q_sqrt_com%d") % i] = g[o_sq:o_sq + M * M].reshape(M, M, 1).copy()
+    return out

@@ -1,0 +1,154 @@
+"""GPU parity of the C-ABI operators against the oracle (run with -m gpu on an MI355X)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gpflow05 as orc  # noqa: E402  (checker only)
+
+
+def _theta(k):
+    return np.array([k["variance"], k["lengthscales"]] + list(k["energy"]) + list(k["frequency"]), dtype=np.float64)
+
+
+_KT = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3, "mercer_matern12sm": 4, "matern12sm": 5}
+
+
+def _desc(h, k):
+    from gpitch_amd import _lib
+    th = h.to_device(_theta(k))
+    d = _lib.KernelDesc(_KT[k["type"]], len(k["frequency"]), th.data_ptr())
+    return d, th
+
+
+KERNELS = [
+    {"type": "matern12", "variance": 1.3, "lengthscales": 0.7, "energy": [], "frequency": []},
+    {"type": "matern32", "variance": 3.5, "lengthscales": 1.0, "energy": [], "frequency": []},
+    {"type": "matern52", "variance": 0.8, "lengthscales": 0.3, "energy": [], "frequency": []},
+    {"type": "rbf", "variance": 2.0, "lengthscales": 0.25, "energy": [], "frequency": []},
+    {"type": "mercer_matern12sm", "variance": 1.1, "lengthscales": 0.1, "energy": [0.5, 0.3, 0.2],
+     "frequency": [261.6, 523.2, 784.9]},
+    {"type": "mercer_matern12sm", "variance": 1.0, "lengthscales": 0.1, "energy": [1. / 20] * 20,
+     "frequency": [261.6 * (i + 1) for i in range(20)]},
+    {"type": "matern12sm", "variance": 0.9, "lengthscales": 0.2, "energy": [0.6, 0.4], "frequency": [100., 205.]},
+]
+
+
+@pytest.mark.parametrize("kern", KERNELS, ids=lambda k: "%s_m%d" % (k["type"], len(k["frequency"])))
+@pytest.mark.parametrize("n1,n2", [(7, 13), (64, 513), (109, 1000)])
+def test_kernel_build_matches_oracle(gp_handle, kern, n1, n2):
+    h = gp_handle
+    rng = np.random.RandomState(n1 * 1000 + n2)
+    x2 = np.sort(rng.rand(n2, 1), 0) * 0.5
+    x1 = x2[rng.choice(n2, n1, replace=False)].copy() if n1 <= n2 else np.sort(rng.rand(n1, 1), 0)
+    d, th = _desc(h, kern)
+    dx1, dx2 = h.to_device(x1), h.to_device(x2)
+    out = h.empty(n1, n2)
+    h.check(h.lib.gp_kernel_build(h.h, C.byref(d), dx1.data_ptr(), n1, dx2.data_ptr(), n2, out.data_ptr(), n2, 0))
+    ref = orc.K(kern, x1, x2)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-11, atol=1e-12)
+    # K(X) form and accumulate
+    outs = h.empty(n1, n1)
+    h.check(h.lib.gp_kernel_build(h.h, C.byref(d), dx1.data_ptr(), n1, None, 0, outs.data_ptr(), n1, 0))
+    np.testing.assert_allclose(outs.cpu().numpy(), orc.K(kern, x1, None), rtol=1e-11, atol=1e-12)
+    h.check(h.lib.gp_kernel_build(h.h, C.byref(d), dx1.data_ptr(), n1, None, 0, outs.data_ptr(), n1, 1))
+    np.testing.assert_allclose(outs.cpu().numpy(), 2 * orc.K(kern, x1, None), rtol=1e-11, atol=1e-12)
+    kd = h.empty(n2)
+    h.check(h.lib.gp_kernel_diag(h.h, C.byref(d), n2, kd.data_ptr(), 0))
+    np.testing.assert_allclose(kd.cpu().numpy(), orc.Kdiag(kern, x2), rtol=1e-15)
+
+
+@pytest.mark.parametrize("M", [5, 32, 33, 64, 109, 256, 512])
+def test_kuu_cholesky_and_inverse(gp_handle, M):
+    h = gp_handle
+    kern = KERNELS[1]
+    z = np.linspace(0, 2.0, M).reshape(-1, 1)
+    d, th = _desc(h, kern)
+    dz = h.to_device(z)
+    L, W = h.empty(M, M), h.empty(M, M)
+    ws = h.workspace(h.lib.gp_chol_workspace_bytes(M))
+    h.check(h.lib.gp_kuu_cholesky(h.h, C.byref(d), dz.data_ptr(), M, 1e-6, L.data_ptr(), W.data_ptr(), ws.data_ptr(), ws.numel()))
+    Kuu = orc.K(kern, z, None) + 1e-6 * np.eye(M)
+    Lref = np.linalg.cholesky(Kuu)
+    Lg, Wg = L.cpu().numpy(), W.cpu().numpy()
+    assert np.all(np.triu(Lg, 1) == 0) and np.all(np.triu(Wg, 1) == 0)
+    # backward-stable factorisation: L L^T reproduces Kuu to rounding
+    np.testing.assert_allclose(Lg @ Lg.T, Kuu, rtol=0, atol=1e-12 * np.abs(Kuu).max() * M)
+    np.testing.assert_allclose(Lg, Lref, rtol=0, atol=1e-7 * np.abs(Lref).max())
+    np.testing.assert_allclose(Wg @ Lg, np.eye(M), rtol=0, atol=1e-8)
+
+
+def test_cholesky_reports_not_pd(gp_handle):
+    from gpitch_amd import _lib
+    h = gp_handle
+    A = np.eye(40)
+    A[17, 17] = -1.0
+    dA = h.to_device(A)
+    st = h.lib.gp_cholesky_inplace(h.h, dA.data_ptr(), 40, 40)
+    assert st == _lib.GP_ERR_NOT_PD
+    assert h.lib.gp_last_not_pd_index(h.h) == 17
+    with pytest.raises(_lib.NotPositiveDefiniteError):
+        h.check(st)
+
+
+@pytest.mark.parametrize("whiten", [True, False])
+@pytest.mark.parametrize("kern", [KERNELS[1], KERNELS[4], KERNELS[5]], ids=["matern32", "mercer3", "mercer20"])
+@pytest.mark.parametrize("N,M", [(50, 7), (1000, 109), (4096, 64), (3001, 256)])
+def test_conditional_matches_oracle(gp_handle, kern, whiten, N, M):
+    h = gp_handle
+    rng = np.random.RandomState(N + M)
+    x = np.linspace(0, (N - 1) / 16000., N).reshape(-1, 1)
+    z = x[:: max(N // M, 1)][:M].copy()
+    M = z.shape[0]
+    q_mu = 0.3 * rng.randn(M, 1)
+    q_sqrt = (np.eye(M) + 0.05 * rng.randn(M, M))[:, :, None]   # full matrix: upper part must be ignored
+    d, th = _desc(h, kern)
+    dx, dz, dmu, dsq = h.to_device(x), h.to_device(z), h.to_device(q_mu), h.to_device(q_sqrt[:, :, 0])
+    fm, fv = h.empty(N), h.empty(N)
+    ws = h.workspace(h.lib.gp_conditional_workspace_bytes(N, M))
+    h.check(h.lib.gp_conditional_diag(h.h, C.byref(d), dx.data_ptr(), N, dz.data_ptr(), M, dmu.data_ptr(), dsq.data_ptr(),
+                                      int(whiten), 1e-6, fm.data_ptr(), fv.data_ptr(), ws.data_ptr(), ws.numel()))
+    rm, rv = orc.conditional(x, z, kern, q_mu, q_sqrt, whiten)
+    scale = np.abs(rm).max() + 1e-300
+    # these inducing grids are far denser than the lengthscale: cond(Kuu) ~ 1e9 (jitter-limited), and the
+    # unwhitened form applies Kuu^-1 (not just L^-1), so both sides carry ~cond*eps error there.
+    tol = 2e-8 if whiten else 2e-6
+    np.testing.assert_allclose(fm.cpu().numpy(), rm[:, 0], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(fv.cpu().numpy(), rv[:, 0], rtol=0, atol=tol * np.abs(rv).max())
+
+
+@pytest.mark.parametrize("nlin", [0, 1, 2])
+@pytest.mark.parametrize("P", [1, 3, 12])
+def test_mpd_varexp_matches_oracle(gp_handle, nlin, P):
+    h = gp_handle
+    N = 1537
+    rng = np.random.RandomState(P * 10 + nlin)
+    Fmu = rng.randn(N, 2 * P) * 2.0 + 1.0
+    Fvar = rng.rand(N, 2 * P) * 3.0 + 1e-8
+    y = rng.randn(N, 1)
+    nv = h.to_device(np.array([0.37]))
+    pf = h.empty(N)
+    s = C.c_double()
+    dmu, dvar, dy = h.to_device(Fmu), h.to_device(Fvar), h.to_device(y)   # keep alive across the call
+    h.check(h.lib.gp_mpd_varexp(h.h, dmu.data_ptr(), dvar.data_ptr(), dy.data_ptr(), N, P, nlin,
+                                nv.data_ptr(), pf.data_ptr(), C.byref(s)))
+    ref = orc.mpd_variational_expectations(Fmu, Fvar, y, 0.37, P, nlin)
+    np.testing.assert_allclose(pf.cpu().numpy(), ref[:, 0], rtol=1e-11, atol=1e-11)
+    assert abs(s.value - ref.sum()) <= 1e-11 * abs(ref.sum())
+
+
+def test_gauss_kl_whitened(gp_handle):
+    h = gp_handle
+    M = 77
+    rng = np.random.RandomState(3)
+    q_mu = rng.randn(M, 1)
+    q_sqrt = (np.eye(M) + 0.1 * rng.randn(M, M))[:, :, None]
+    out = C.c_double()
+    ws = h.workspace(8192)
+    dmu, dsq = h.to_device(q_mu), h.to_device(q_sqrt[:, :, 0])
+    h.check(h.lib.gp_gauss_kl(h.h, dmu.data_ptr(), dsq.data_ptr(), M, None, None, 1e-6,
+                              C.byref(out), ws.data_ptr(), ws.numel()))
+    ref = orc.gauss_kl(q_mu, q_sqrt)
+    assert abs(out.value - ref) <= 1e-12 * abs(ref)

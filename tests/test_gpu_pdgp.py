@@ -1,0 +1,132 @@
+"""GPU parity of the Pdgp ELBO path (forward, gradient, prediction, Adam) against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from helpers import (pdgp_from_problem, oracle_elbo, oracle_elbo_and_grads, model_grad_dict)  # noqa: E402
+
+# float64 tolerance of north_star: ELBO and posterior means within 1e-4 relative; we hold 1e-9.
+ELBO_RTOL = 1e-9
+
+
+@pytest.mark.parametrize("N,M,P,m", [(64, 8, 1, 2), (500, 33, 2, 3), (4096, 64, 1, 5), (3000, 109, 3, 4)])
+def test_elbo_forward_matches_oracle(gp_handle, N, M, P, m):
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(N, M, P, num_partials=m, seed=N % 7)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    ref = float(oracle_elbo(prob))
+    assert abs(got - ref) <= ELBO_RTOL * abs(ref), (got, ref)
+
+
+def test_prior_elbo_identity_K1(gp_handle):
+    """at q_mu=0, q_sqrt=I (whitened) KL=0, fmean=0, fvar=Kdiag, so the ELBO has a closed
+    form independent of M, Z and lengthscales."""
+    from gpitch_amd.synth import make_problem
+    from oracle import gpflow05 as orc
+    prob = make_problem(1024, 32, 2, num_partials=3, seed=1, trivial_q=True)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    N, s2 = prob["N"], prob["noise_var"]
+    tot = np.sum(prob["y"] ** 2)
+    for i in range(prob["P"]):
+        vg = prob["kern_act"][i]["variance"]
+        vf = prob["kern_com"][i]["variance"] * sum(prob["kern_com"][i]["energy"])
+        _, E2 = orc.hermgauss1d(np.zeros((1, 1)), np.full((1, 1), vg), 20, orc.logistic)
+        tot += N * vf * E2[0, 0]
+    ref = -0.5 * tot / s2 - 0.5 * N * (np.log(2 * np.pi) + np.log(s2))
+    assert abs(got - ref) <= 1e-10 * abs(ref)
+
+
+@pytest.mark.parametrize("N,M,P,m", [(300, 16, 1, 2), (700, 40, 2, 3)])
+def test_elbo_gradient_matches_autograd(gp_handle, N, M, P, m):
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(N, M, P, num_partials=m, seed=3)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model._pack()
+    f = model._elbo(True)
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    assert abs(f - ref_f) <= ELBO_RTOL * abs(ref_f)
+    got_g = model_grad_dict(model)
+    for name, rg in ref_g.items():
+        gg = got_g[name]
+        if name.startswith("q_sqrt"):
+            rg = np.tril(rg[:, :, 0])[:, :, None]   # band_part: no gradient reaches the upper triangle
+            assert np.all(np.triu(gg[:, :, 0], 1) == 0)
+        scale = max(np.abs(rg).max(), 1e-12)
+        np.testing.assert_allclose(gg.reshape(rg.shape), rg, rtol=0, atol=2e-7 * scale, err_msg=name)
+
+
+def test_predict_matches_oracle(gp_handle):
+    from gpitch_amd.synth import make_problem
+    from oracle import gpflow05 as orc
+    prob = make_problem(2000, 50, 2, num_partials=3, seed=5)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    xt = prob["x"][::3].copy()
+    ma, va, mc, vc, ms = model.predict_act_n_com(xt)
+    r = orc.pdgp_predict_act_n_com(xt, prob["za"], prob["zc"], prob["kern_act"], prob["kern_com"], prob["q_mu_act"],
+                                   prob["q_sqrt_act"], prob["q_mu_com"], prob["q_sqrt_com"])
+    for got, ref in zip((ma, va, mc, vc, ms), r):
+        for i in range(prob["P"]):
+            np.testing.assert_allclose(got[i], ref[i], rtol=0, atol=1e-8 * max(np.abs(ref[i]).max(), 1e-3))
+    ma2, va2 = model.predict_act(xt)
+    np.testing.assert_array_equal(ma2[1], ma[1])
+
+
+def test_adam_steps_match_oracle_trajectory(gp_handle):
+    """three full-batch Adam steps on the free state reproduce the oracle's (autograd + TF-1.2 Adam)."""
+    import gpitch_amd
+    from gpitch_amd.synth import make_problem
+    from oracle import gpflow05 as orc
+    prob = make_problem(400, 12, 1, num_partials=2, seed=2)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model.za.fixed = True
+    model.zc.fixed = True
+    model.optimize(method=gpitch_amd.train.AdamOptimizer(0.01), maxiter=3)
+    # oracle trajectory over the same free-state coordinates
+    import copy
+    p = copy.deepcopy(prob)
+    names_pos = ["noise", "act0.variance", "act0.lengthscales", "com0.variance", "com0.lengthscales",
+                 "com0.energy0", "com0.energy1", "com0.frequency0", "com0.frequency1"]
+    def get(p, name):
+        if name == "noise": return np.array([p["noise_var"]])
+        k, f = name.split(".")
+        d = (p["kern_act"] if k.startswith("act") else p["kern_com"])[0]
+        if f.startswith("energy"): return np.array([d["energy"][int(f[6:])]])
+        if f.startswith("frequency"): return np.array([d["frequency"][int(f[9:])]])
+        return np.array([d[f]])
+    def put(p, name, v):
+        v = float(v[0])
+        if name == "noise": p["noise_var"] = v; return
+        k, f = name.split(".")
+        d = (p["kern_act"] if k.startswith("act") else p["kern_com"])[0]
+        if f.startswith("energy"): d["energy"][int(f[6:])] = v
+        elif f.startswith("frequency"): d["frequency"][int(f[9:])] = v
+        else: d[f] = v
+    ident = ["q_mu_act0", "q_mu_com0", "q_sqrt_act0", "q_sqrt_com0"]
+    state = {n: orc.positive_backward(get(p, n)) for n in names_pos}
+    for n in ident:
+        state[n] = p[n[:-1]][0].copy()
+    mom = {n: (np.zeros_like(v), np.zeros_like(v)) for n, v in state.items()}
+    for t in range(1, 4):
+        _, g = oracle_elbo_and_grads(p)
+        for n in state:
+            gc = g[n]
+            if n in names_pos:
+                gf = -gc.reshape(state[n].shape) / (1. + np.exp(-state[n]))
+            else:
+                gf = -gc
+                if n.startswith("q_sqrt"):
+                    gf = np.tril(gf[:, :, 0])[:, :, None]
+            x, m_, v_ = orc.adam_step(state[n], gf, mom[n][0], mom[n][1], t, 0.01)
+            state[n], mom[n] = x, (m_, v_)
+        for n in names_pos:
+            put(p, n, orc.positive_forward(state[n]))
+        for n in ident:
+            p[n[:-1]][0] = state[n]
+    np.testing.assert_allclose(model.q_mu_act[0].value, p["q_mu_act"][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(model.q_sqrt_com[0].value, p["q_sqrt_com"][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(model.likelihood.variance.value, [p["noise_var"]], rtol=1e-9)
+    np.testing.assert_allclose(model.kern_com[0].frequency[1].value, [p["kern_com"][0]["frequency"][1]], rtol=1e-10)
+    np.testing.assert_allclose(model.kern_act[0].lengthscales.value, [p["kern_act"][0]["lengthscales"]], rtol=1e-9)
