@@ -1,0 +1,206 @@
+"""bench.py — ELBO-steps/sec of the Pdgp hot path on MI355X (BASELINE.json metric).
+
+One step = what one iteration of gpflow Model.optimize(method=Adam) does in the reference
+(SURVEY §3.2): fresh (full-size, freshly permuted) batch -> forward ELBO -> gradient w.r.t. every
+non-fixed parameter -> Adam update of the free state.  Workload: N=32768 frames, M=512 inducing
+points per latent GP, P=12 pitches (24 latent GPs), float64, inputs resident in HBM.
+
+Multi-GPU (torchrun, one rank per GPU): the reference scales N by independent windows / segments
+(window_overlap.py:194, transcription.py:265-288), so every rank owns one independent 32768-frame
+window with the full 12-pitch model (weak scaling) and the scalar ELBO is all-reduced over RCCL each
+step; there is no other data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor sheet); bare MFMA loop measures ~48
+PEAK_HBM_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_model(args, rank):
+    import gpitch_amd
+    from gpitch_amd.pdgp import Pdgp
+    from gpitch_amd.synth import make_problem
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import pdgp_from_problem
+    prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=rank)
+    model = pdgp_from_problem(prob)
+    model.za.fixed = True      # as demos/scripts/demo-modgp.py:40-41
+    model.zc.fixed = True
+    return prob, model
+
+
+def cpu_baseline(args):
+    """The oracle's torch-CPU float64 restatement of the GPflow graph (autograd backward + Adam), timed
+    on this host's cores on a BOUNDED sample: one pitch (2 of the 2P latent GPs) at the full N and M;
+    a step over P pitches costs P times that (the 2P conditionals are independent and carry >95 %)."""
+    import torch
+    from gpitch_amd.synth import make_problem
+    from oracle import gpflow05 as orc
+    from oracle.backend import TorchBackend
+    tb = TorchBackend()
+    prob = make_problem(args.N, args.M, 1, num_partials=args.partials, seed=0)
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=True)
+    x, y = torch.tensor(prob["x"]), torch.tensor(prob["y"])
+    leaves = []
+
+    def tk(d):
+        out = dict(d)
+        for key in ("variance", "lengthscales"):
+            out[key] = T(d[key]); leaves.append(out[key])
+        out["energy"] = [T(e) for e in d["energy"]]; leaves.extend(out["energy"])
+        out["frequency"] = [T(f) for f in d["frequency"]]; leaves.extend(out["frequency"])
+        return out
+    ka, kc = [tk(prob["kern_act"][0])], [tk(prob["kern_com"][0])]
+    qma, qmc = [T(prob["q_mu_act"][0])], [T(prob["q_mu_com"][0])]
+    qsa, qsc = [T(prob["q_sqrt_act"][0])], [T(prob["q_sqrt_com"][0])]
+    nv = T(prob["noise_var"])
+    leaves += qma + qmc + qsa + qsc + [nv]
+    za, zc = [torch.tensor(prob["za"][0])], [torch.tensor(prob["zc"][0])]
+    mom = [(torch.zeros_like(l), torch.zeros_like(l)) for l in leaves]
+
+    def step(t):
+        for l in leaves:
+            l.grad = None
+        elbo = orc.pdgp_elbo(x, y, za, zc, ka, kc, qma, qsa, qmc, qsc, nv, whiten=True, xp=tb)
+        (-elbo).backward()
+        with torch.no_grad():
+            lr_t = 0.0025 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+            for l, (m, v) in zip(leaves, mom):
+                m.mul_(0.9).add_(l.grad, alpha=0.1)
+                v.mul_(0.999).addcmul_(l.grad, l.grad, value=0.001)
+                l.sub_(lr_t * m / (v.sqrt() + 1e-8) * 1e-3)   # tiny steps: stay in the positive region
+    step(1)
+    times = []
+    for t in range(2, 2 + args.cpu_steps):
+        t0 = time.perf_counter()
+        step(t)
+        times.append(time.perf_counter() - t0)
+    t1 = float(np.median(times))
+    return {"value": 1.0 / (t1 * args.P), "unit": "ELBO-steps/sec", "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": "median of %d steps of the P=1 sub-problem (2 of %d latent GPs) at N=%d, M=%d, m=%d, torch-CPU "
+                      "float64 + autograd + Adam (%.2f s each); scaled by 1/P for the P=%d step; host cpu_count=%d"
+                      % (args.cpu_steps, 2 * args.P, args.N, args.M, args.partials, t1, args.P, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--N", type=int, default=32768)
+    ap.add_argument("--M", type=int, default=512)
+    ap.add_argument("--P", type=int, default=12)
+    ap.add_argument("--partials", type=int, default=20)
+    ap.add_argument("--lr", type=float, default=0.0025)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import gpitch_amd
+    from gpitch_amd import _lib
+    prob, model = build_model(args, rank)
+    model._pack()
+    h = model._handle
+    opt = gpitch_amd.train.AdamOptimizer(args.lr)
+    elbo_sum = torch.zeros(1, dtype=torch.float64, device=h.device)
+
+    def step():
+        model._elbo(True, sync=False)
+        model._adam_t += 1
+        h.check(h.lib.gp_adam_step(h.h, model._free.data_ptr(), model._params.data_ptr(), model._grad.data_ptr(),
+                                   model._tcode.data_ptr(), model._adam_m.data_ptr(), model._adam_v.data_ptr(),
+                                   model._nparams, model._adam_t, opt.learning_rate, opt.beta1, opt.beta2, opt.epsilon))
+        if dist is not None:   # scalar ELBO of the whole job (north_star: all-reduce of the scalar ELBO)
+            elbo_sum.copy_(model._elbo_dev)
+            dist.all_reduce(elbo_sum)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    h.check(h.lib.gp_timers_enable(h.h, 1))
+    h.check(h.lib.gp_timers_reset(h.h))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    h.check(h.lib.gp_timers_enable(h.h, 0))
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=h.device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    elbo_final = float(model._elbo_dev.item())
+    timers = h.timers()
+
+    if rank == 0:
+        G, M, N, T = 2 * args.P, args.M, args.N, 8
+        m2n = float(M) * M * N
+        # algorithmic flops per launch (one launch = all 2P latent GPs); SURVEY §8d / DESIGN.md
+        alg = {"cond_A": G * m2n, "cond_LTA": G * m2n, "nt_gemm": G * m2n, "kuf_bar": G * 2.0 * m2n}
+        per_launch = {k: (ms / max(n, 1)) for k, (ms, n) in timers.items()}
+        dom = max(alg, key=lambda k: timers[k][0])
+        dom_ms = per_launch[dom]
+        achieved = alg[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        sym = {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
+               "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"}
+        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None, "kernel": sym[dom],
+                "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": alg[dom]}
+        kuf = {}
+        for name, mm in (("kuf_build", 0), ("kuf_build_sm", args.partials)):
+            ms, n = timers[name]
+            if n:
+                byts = T * (float(M) * N + N + M) + T * 2.0 * mm * (M + N)
+                a = byts / (ms / n * 1e-3) / 1e9
+                kuf[name] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
+                             "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": byts}
+        out = {
+            "metric": "ELBO-steps/sec", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "pdgp ELBO step (fwd + grad + Adam), N=%d frames x M=%d inducing x P=%d pitches "
+                                   "(2P=%d latent GPs), m=%d partials, float64, full batch; one independent window per GPU"
+                                   % (N, M, args.P, G, args.partials),
+                       "N": N, "M": M, "P": args.P, "partials": args.partials, "whiten": True,
+                       "parallelism": "window-per-gpu x%d" % world},
+            "roofline": roof,
+            "roofline_kuf_build": kuf,
+            "kernel_ms_per_step": {k: ms / args.steps for k, (ms, n) in timers.items()},
+            "elbo_final": elbo_final,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args)
+            out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,8 +16,10 @@ GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_HIP, GP_ERR_NO_DEVICE, GP_ERR_WORKS
 
 KERN_MATERN12, KERN_MATERN32, KERN_MATERN52, KERN_RBF, KERN_MERCER_MATERN12SM, KERN_MATERN12SM = range(6)
 NLIN_LOGISTIC, NLIN_SOFTPLUS, NLIN_GAUSS = range(3)
-TIMER_KUF_BUILD, TIMER_STRIP_GEMM, TIMER_NT_GEMM, TIMER_CHOL, TIMER_LIK, TIMER_SMALL_GEMM, TIMER_HYPER = range(7)
-TIMER_NAMES = ["kuf_build", "strip_gemm", "nt_gemm", "chol", "lik", "small_gemm", "hyper"]
+(TIMER_KUF_BUILD, TIMER_COND_A, TIMER_COND_LTA, TIMER_NT_GEMM, TIMER_KUF_BAR, TIMER_CHOL, TIMER_LIK, TIMER_SMALL_GEMM,
+ TIMER_HYPER, TIMER_KUF_BUILD_SM) = range(10)
+TIMER_NAMES = ["kuf_build", "cond_A", "cond_LTA", "nt_gemm", "kuf_bar", "chol", "lik", "small_gemm", "hyper",
+               "kuf_build_sm"]
 
 # every symbol include/gpitch_abi.h declares
 ABI_SYMBOLS = [

@@ -419,7 +419,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   GP_CHECK(launch_gemm_batched(h, D(S_R), G, maxM, maxM, f));
   GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), G, maxM, 1));
   // Kuf_bar (dense part) = R (A diag(2 gv))
-  f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_STRIP_GEMM;
+  f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
   GP_CHECK(launch_gemm_batched(h, D(S_G), G, maxM, n, f));
   // Kuu side: Lbar = -tril(W^T Wbar W^T); P = Phi(L^T Lbar); S = W^T P W
   f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;

@@ -123,6 +123,7 @@ struct GemmFlags {
   int epilogue = 1;      // bitmask of GemmEpi
   int scale_mode = 0;    // 0 none; 1: opB(B)(k,n) *= v1[n]; 2: opB(B)(k,n) *= v1[k]
   int timer = GP_TIMER_SMALL_GEMM;
+  int role = 0;          // 1 cond_A, 2 cond_LTA (needs transA), 3 kuf_bar: dedicated 128x128 instantiations
 };
 enum GemmEpi {
   EPI_STORE = 1,     // C = alpha*acc + beta*C

@@ -193,7 +193,9 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
   if (n1 <= 0 || n2 <= 0) return GP_OK;
   if (x2 == nullptr) { x2 = x1; n2 = n1; }
   const int vec_ok = ((ld % 2) == 0) && ((((uintptr_t)out) & 15) == 0);
-  GpTimerScope ts(h, GP_TIMER_KUF_BUILD);
+  const bool big = (int64_t)n1 * n2 >= (1 << 20);   // M x N strips; the small Kuu builds are booked elsewhere
+  GpTimerScope ts(h, !big ? GP_TIMER_SMALL_GEMM
+                          : (k.type == GP_KERN_MERCER_MATERN12SM ? GP_TIMER_KUF_BUILD_SM : GP_TIMER_KUF_BUILD));
   if (k.type == GP_KERN_MERCER_MATERN12SM) {
     if (k.m < 1 || k.m > 32) return gp_fail(h, GP_ERR_UNSUPPORTED, "num_partials must be in [1, 32]");
     if (!feat_ws) return gp_fail(h, GP_ERR_WORKSPACE, "feature workspace missing");

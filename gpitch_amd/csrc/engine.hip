@@ -125,13 +125,13 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   // 4. A = W Kuf (+ column reductions)
   {
     GemmFlags f;
-    f.triA = TRI_LOWER; f.big_tiles = 1; f.timer = GP_TIMER_STRIP_GEMM;
+    f.triA = TRI_LOWER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A; f.role = 1;
     f.epilogue = EPI_STORE | EPI_COLSUMSQ | (whiten ? EPI_COLDOT : 0);
     GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, f));
   }
   if (!whiten) {
     GemmFlags f;
-    f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_STRIP_GEMM;
+    f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A;
     f.epilogue = EPI_STORE | EPI_COLDOT;
     GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1u), G, cb.maxM, N, f));
   }
@@ -142,7 +142,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     for (int g = 0; g < G; g++)
       if (!cb.tasks[g].q_sqrt) return gp_fail(h, GP_ERR_UNSUPPORTED, "mixed null/non-null q_sqrt in one batch");
     GemmFlags f;
-    f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_STRIP_GEMM;
+    f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_LTA; f.role = 2;
     f.epilogue = EPI_COLSUMSQ;
     GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
   }

@@ -208,8 +208,14 @@ gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const dou
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * HIP-event timing of the dominant kernels on the handle's own stream.  Returns the accumulated time of
  * kernel class `which` since the last reset and the number of launches. */
-enum { GP_TIMER_KUF_BUILD = 0, GP_TIMER_STRIP_GEMM = 1, GP_TIMER_NT_GEMM = 2, GP_TIMER_CHOL = 3,
-       GP_TIMER_LIK = 4, GP_TIMER_SMALL_GEMM = 5, GP_TIMER_HYPER = 6, GP_TIMER_COUNT = 7 };
+enum { GP_TIMER_KUF_BUILD = 0,   /* cov_build_kernel<0,2>: stationary Kuf assembly (HBM-bound)                 */
+       GP_TIMER_COND_A = 1,      /* gemm_f64_kernel<..,1>: A = L^-1 Kuf (tri-aware, M^2 N flops per GP)        */
+       GP_TIMER_COND_LTA = 2,    /* gemm_f64_kernel<..,2>: Lq^T A column sums (tri-aware, M^2 N)               */
+       GP_TIMER_NT_GEMM = 3,     /* gemm_f64_kernel<..,4>: H = A D A^T split-K over frames (M^2 N, symmetric)  */
+       GP_TIMER_KUF_BAR = 4,     /* gemm_f64_kernel<..,3>: Kuf_bar = R (A D) (dense, 2 M^2 N)                  */
+       GP_TIMER_CHOL = 5, GP_TIMER_LIK = 6, GP_TIMER_SMALL_GEMM = 7, GP_TIMER_HYPER = 8,
+       GP_TIMER_KUF_BUILD_SM = 9, /* cov_build_kernel<1,..>: spectral-mixture Kuf (features + build)              */
+       GP_TIMER_COUNT = 10 };
 gp_status gp_timers_enable(gp_handle h, int32_t on);
 gp_status gp_timers_reset(gp_handle h);
 gp_status gp_timers_read(gp_handle h, int32_t which, double* total_ms, int64_t* launches);
