@@ -130,3 +130,34 @@ def test_adam_steps_match_oracle_trajectory(gp_handle):
     np.testing.assert_allclose(model.likelihood.variance.value, [p["noise_var"]], rtol=1e-9)
     np.testing.assert_allclose(model.kern_com[0].frequency[1].value, [p["kern_com"][0]["frequency"][1]], rtol=1e-10)
     np.testing.assert_allclose(model.kern_act[0].lengthscales.value, [p["kern_act"][0]["lengthscales"]], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["pdgp_small_logistic", "pdgp_small_softplus", "pdgp_small_gauss"])
+def test_hip_path_matches_committed_golden(gp_handle, name):
+    """HIP ELBO / conditionals against the 50-digit golden vectors (tests/golden/*.npz): 1e-9 relative."""
+    import gpitch_amd
+    from gpitch_amd.pdgp import Pdgp
+    from gpitch_amd.conditionals import conditional
+    from test_oracle_golden import load_pdgp
+    from helpers import kernels_from_problem
+    prob, d = load_pdgp(name)
+    nl = [gpitch_amd.logistic_tf, gpitch_amd.softplus_tf, gpitch_amd.gaussfun_tf][prob["nlin"]]
+    kern = kernels_from_problem(prob)
+    m = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kern, whiten=True, nlinfun=nl, handle=gp_handle)
+    P = prob["P"]
+    for i in range(P):
+        m.q_mu_act[i].value = prob["q_mu_act"][i]; m.q_mu_com[i].value = prob["q_mu_com"][i]
+        m.q_sqrt_act[i].value = prob["q_sqrt_act"][i]; m.q_sqrt_com[i].value = prob["q_sqrt_com"][i]
+    m.likelihood.variance = prob["noise_var"]
+    got = m.compute_log_likelihood()
+    ref = float(d["elbo_white"])
+    assert abs(got - ref) <= 1e-9 * abs(ref)
+    assert abs(m.build_prior_kl() - float(d["kl_white"])) <= 1e-9 * abs(float(d["kl_white"]))
+    ma, va, mc, vc, _ = m.predict_act_n_com(prob["x"])
+    for i in range(P):
+        np.testing.assert_allclose(ma[i][:, 0], d["fmean_white"][:, i], rtol=0, atol=1e-9 * np.abs(d["fmean_white"]).max())
+        np.testing.assert_allclose(vc[i][:, 0], d["fvar_white"][:, P + i], rtol=0, atol=1e-9 * np.abs(d["fvar_white"]).max())
+        # unwhitened conditional through the operator API
+        fm, fv = conditional(prob["x"], prob["zc"][i], kern[1][i], prob["q_mu_com"][i], q_sqrt=prob["q_sqrt_com"][i], whiten=False)
+        np.testing.assert_allclose(fm[:, 0], d["fmean_unwhite"][:, P + i], rtol=0, atol=1e-9 * np.abs(d["fmean_unwhite"]).max())
+        np.testing.assert_allclose(fv[:, 0], d["fvar_unwhite"][:, P + i], rtol=0, atol=1e-9 * np.abs(d["fvar_unwhite"]).max())
