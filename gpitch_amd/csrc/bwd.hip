@@ -78,6 +78,19 @@ __global__ void __launch_bounds__(64) matvec_kernel(const GemmProblem* __restric
   if (threadIdx.x == 0) p.o0[r] = acc;
 }
 
+// out[g] = sum_n v[g * stride + n]   (one block per row; fixed reduction order)
+__global__ void __launch_bounds__(256) batched_sum_kernel(const double* __restrict__ v, int64_t stride, int n,
+                                                          double* __restrict__ out) {
+  const double* row = v + (int64_t)blockIdx.x * stride;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += row[i];
+  __shared__ double red[4];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 static int ew_grid(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 512 ? 512 : (b < 1 ? 1 : b)); }
 
 gp_status launch_rowdot_batched(gp_handle h, const GemmProblem* d, int batch, int maxM) {
@@ -117,7 +130,9 @@ gp_status launch_matvec_batched(gp_handle h, const GemmProblem* d, int batch, in
 
 int hyper_num_sums(int m) { return 2 + 2 * m; }
 
-template <int MMAX>
+// MPAD = spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded, so the
+// inner loop carries no guards); SM = Mercer Matern-1/2 SM kernel; GZ = also produce the inducing-input gradient.
+template <int MPAD, bool SM, bool GZ>
 __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, const double* __restrict__ x1, int n1,
                                                                     const double* __restrict__ x2, int n2,
                                                                     const double* __restrict__ G, int64_t ldg,
@@ -127,21 +142,22 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
                                                                     const double* __restrict__ f2,
                                                                     double* __restrict__ partials,
                                                                     double* __restrict__ gz_part) {
-  extern __shared__ double smem[];  // [HY_ROWS][2m] row features, then reduction scratch
+  extern __shared__ double smem[];  // [HY_ROWS][2*MPAD] row features | omega[MPAD] | reduction scratch
   const double* th = k.theta;
   const double var = th[0], ls = th[1];
   const int m = k.m;
   const int j = blockIdx.x * HY_THREADS + threadIdx.x;
   const int i0 = blockIdx.y * HY_ROWS;
   const int iend = min(i0 + HY_ROWS, n1);
-  const bool sm = (k.type == GP_KERN_MERCER_MATERN12SM);
   double* fzs = smem;
-  double* red = smem + (sm ? HY_ROWS * 2 * m : 0);  // [4 waves][max(2+2m, HY_ROWS)]
-  if (sm) {
-    for (int t = threadIdx.x; t < HY_ROWS * 2 * m; t += HY_THREADS) {
+  double* omega = smem + (SM ? HY_ROWS * 2 * MPAD : 0);
+  double* red = omega + (SM ? MPAD : 0);  // [4 waves][max(2+2m, HY_ROWS)]
+  if (SM) {
+    for (int t = threadIdx.x; t < HY_ROWS * 2 * MPAD; t += HY_THREADS) {
       int q = t / HY_ROWS, ii = t % HY_ROWS;
-      fzs[ii * 2 * m + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
+      fzs[ii * 2 * MPAD + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
     }
+    if ((int)threadIdx.x < MPAD) omega[threadIdx.x] = ((int)threadIdx.x < m) ? 6.283185307179586 * th[2 + m + threadIdx.x] : 0.0;
   }
   __syncthreads();
   const bool live = (j < n2);
@@ -149,17 +165,17 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   const double xb = x2[jc];
   const double b = xb / ls, bb = __dmul_rn(b, b);
   const double gmj = (gm && live) ? gm[jc] : 0.0;
-  double fxc[MMAX], fxs[MMAX];  // column features: sqrt(e_q) cos / sin (static indices only)
+  double fxc[MPAD], fxs[MPAD];  // column features (static indices only)
+  double acc_e[MPAD], acc_f[MPAD];
 #pragma unroll
-  for (int q = 0; q < MMAX; q++) {
-    fxc[q] = (sm && q < m) ? f2[(size_t)q * n2 + jc] : 0.0;
-    fxs[q] = (sm && q < m) ? f2[(size_t)(q + m) * n2 + jc] : 0.0;
+  for (int q = 0; q < MPAD; q++) {
+    fxc[q] = SM ? f2[(size_t)q * n2 + jc] : 0.0;
+    fxs[q] = SM ? f2[(size_t)(q + MPAD) * n2 + jc] : 0.0;
+    acc_e[q] = 0.0; acc_f[q] = 0.0;
   }
   double acc_v = 0.0, acc_l = 0.0;
-  double acc_e[MMAX], acc_f[MMAX];
-#pragma unroll
-  for (int q = 0; q < MMAX; q++) { acc_e[q] = 0.0; acc_f[q] = 0.0; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double inv_ls2 = 1.0 / (ls * ls);
 
   for (int i = i0; i < iend; i++) {
     const double xa = x1[i];
@@ -173,35 +189,33 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
     const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b), aa), bb);
     const double d = xa - xb;
     double dz = 0.0;  // w * dK/dx1
-    if (k.type == GP_KERN_RBF) {
+    if (!SM && k.type == GP_KERN_RBF) {
       const double e = exp(-0.5 * r2);
       acc_v = fma(w, e, acc_v);
       acc_l = fma(w, var * e * r2 / ls, acc_l);
-      dz = -w * var * e * d / (ls * ls);
+      if (GZ) dz = -w * var * e * d * inv_ls2;
     } else {
       const double r = __dsqrt_rn(__dadd_rn(r2, 1e-12));
-      if (sm) {
+      if (SM) {
         const double E = exp(-r);
-        double S = 0.0, Ssin = 0.0;
-        const double* fz = &fzs[(i - i0) * 2 * m];
         const double wvE = w * var * E;
+        const double wd = wvE * d;
+        const double* fz = &fzs[(i - i0) * 2 * MPAD];
+        double S = 0.0, Ssin = 0.0;
 #pragma unroll
-        for (int q = 0; q < MMAX; q++) {
-          if (q < m) {
-            const double zc = fz[q], zs = fz[q + m];
-            const double xc = fxc[q], xs = fxs[q];
-            const double cc = fma(zc, xc, zs * xs);   // e_q cos(w_q d)
-            const double ss = fma(zs, xc, -zc * xs);  // e_q sin(w_q d)
-            const double eq = th[2 + q], fq = th[2 + m + q];
-            S += cc;
-            Ssin = fma(ss, 6.283185307179586 * fq, Ssin);
-            acc_e[q] = fma(wvE, cc / eq, acc_e[q]);
-            acc_f[q] = fma(-wvE * 6.283185307179586 * d, ss, acc_f[q]);
-          }
+        for (int q = 0; q < MPAD; q++) {
+          const double zc = fz[q], zs = fz[q + MPAD];
+          const double cc = fma(zc, fxc[q], zs * fxs[q]);   // e_q cos(w_q d)
+          const double ss = fma(zs, fxc[q], -zc * fxs[q]);  // e_q sin(w_q d)
+          S += cc;
+          acc_e[q] = fma(wvE, cc, acc_e[q]);
+          acc_f[q] = fma(wd, ss, acc_f[q]);
+          if (GZ) Ssin = fma(ss, omega[q], Ssin);
         }
+        const double rinv = 1.0 / r;
         acc_v = fma(w * E, S, acc_v);
-        acc_l = fma(wvE * S, r2 / (ls * r), acc_l);
-        dz = wvE * (-S * d / (ls * ls * r) - Ssin);
+        acc_l = fma(wvE * S, r2 * rinv / ls, acc_l);
+        if (GZ) dz = wvE * (-S * d * inv_ls2 * rinv - Ssin);
       } else {
         double phi, dphi;  // K = var * phi(r), dphi = phi'(r)
         if (k.type == GP_KERN_MATERN12) { phi = exp(-r); dphi = -phi; }
@@ -212,17 +226,18 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
           const double s5 = 2.23606797749979, e = exp(-s5 * r);
           phi = (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e; dphi = -(5.0 / 3.0) * r * (1.0 + s5 * r) * e;
         }
+        const double rinv = 1.0 / r;
         acc_v = fma(w, phi, acc_v);
-        acc_l = fma(w * var * dphi, -r2 / (ls * r), acc_l);
-        dz = w * var * dphi * d / (ls * ls * r);
+        acc_l = fma(w * var * dphi, -r2 * rinv / ls, acc_l);
+        if (GZ) dz = w * var * dphi * d * inv_ls2 * rinv;
       }
     }
-    if (gz_part) {
+    if (GZ) {
       for (int o = 32; o > 0; o >>= 1) dz += __shfl_down(dz, o, 64);
       if (lane == 0) red[wave * HY_ROWS + (i - i0)] = dz;
     }
   }
-  if (gz_part) {
+  if (GZ) {
     __syncthreads();
     if (threadIdx.x < HY_ROWS && i0 + (int)threadIdx.x < n1) {
       const int t = threadIdx.x;
@@ -231,16 +246,20 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
     }
     __syncthreads();
   }
-  // block-reduce the (2 + 2m) sums
+  // block-reduce the (2 + 2m) sums; the energy sums carry a factor e_q (cc = e_q cos), the frequency sums
+  // a factor -1/(2 pi) relative to d/df_q
   const int ns = 2 + 2 * m;
   auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
   double rv = wred(acc_v), rl = wred(acc_l);
   if (lane == 0) { red[wave * ns + 0] = rv; red[wave * ns + 1] = rl; }
+  if (SM) {
 #pragma unroll
-  for (int q = 0; q < MMAX; q++) {
-    if (q < m) {
+    for (int q = 0; q < MPAD; q++) {
       double re = wred(acc_e[q]), rf = wred(acc_f[q]);
-      if (lane == 0) { red[wave * ns + 2 + q] = re; red[wave * ns + 2 + m + q] = rf; }
+      if (lane == 0 && q < m) {
+        red[wave * ns + 2 + q] = re / th[2 + q];
+        red[wave * ns + 2 + m + q] = -6.283185307179586 * rf;
+      }
     }
   }
   __syncthreads();
@@ -251,31 +270,44 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   }
 }
 
+template <int MPAD, bool SM>
+static void launch_hyper_t(gp_handle h, dim3 grid, size_t sh, DevKern k, const double* x1, int n1, const double* x2,
+                           int n2, const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
+                           const double* f1, const double* f2, double* partials, double* gz) {
+  if (gz)
+    hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, true>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2,
+                       G, ldg, alpha, gm, symmetric, f1, f2, partials, gz);
+  else
+    hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, false>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2,
+                       n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz);
+}
+
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
                                 const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
                                 const double* feat, double* partials, int* nparts, double* gz_partials) {
   if (k.type == GP_KERN_MATERN12SM) return gp_fail(h, GP_ERR_UNSUPPORTED, "gradient of Matern12sm is not implemented");
   GpTimerScope ts(h, GP_TIMER_HYPER);
   const bool sm = (k.type == GP_KERN_MERCER_MATERN12SM);
+  const int mp = sm ? sm_mpad(k.m) : 0;
   const double* f1 = feat;
-  const double* f2 = (x2 == x1 || !feat) ? feat : feat + gp_align_up((size_t)2 * k.m * n1, 32);
+  const double* f2 = (x2 == x1 || !feat) ? feat : feat + gp_align_up((size_t)2 * mp * n1, 32);
   dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + HY_ROWS - 1) / HY_ROWS);
   const int ns = 2 + 2 * k.m;
   const int redw = ns > HY_ROWS ? ns : HY_ROWS;
-  size_t sh = ((sm ? (size_t)HY_ROWS * 2 * k.m : 0) + 4 * (size_t)redw) * sizeof(double);
-  if (!sm || k.m <= 0) {
-    hipLaunchKernelGGL((hyper_contract_kernel<1>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
-  } else if (k.m <= 8) {
-    hipLaunchKernelGGL((hyper_contract_kernel<8>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
-  } else if (k.m <= 16) {
-    hipLaunchKernelGGL((hyper_contract_kernel<16>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
-  } else {
-    hipLaunchKernelGGL((hyper_contract_kernel<32>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                       alpha, gm, symmetric, f1, f2, partials, gz_partials);
+  size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
+#define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials
+  if (!sm) launch_hyper_t<1, false>(h, HY_ARGS);
+  else switch (mp) {
+    case 4: launch_hyper_t<4, true>(h, HY_ARGS); break;
+    case 8: launch_hyper_t<8, true>(h, HY_ARGS); break;
+    case 12: launch_hyper_t<12, true>(h, HY_ARGS); break;
+    case 16: launch_hyper_t<16, true>(h, HY_ARGS); break;
+    case 20: launch_hyper_t<20, true>(h, HY_ARGS); break;
+    case 24: launch_hyper_t<24, true>(h, HY_ARGS); break;
+    case 28: launch_hyper_t<28, true>(h, HY_ARGS); break;
+    default: launch_hyper_t<32, true>(h, HY_ARGS); break;
   }
+#undef HY_ARGS
   GP_HIP_CHECK(h, hipGetLastError());
   if (nparts) *nparts = grid.x * grid.y;
   return GP_OK;
@@ -396,8 +428,8 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   // u = A gm ; grad q_mu += u
   GP_CHECK(launch_rowdot_batched(h, D(S_U), G, maxM));
   // sum_n gv  (kdiag term)
-  for (int g = 0; g < G; g++)
-    GP_CHECK(launch_finish_sum(h, p->gFvar + (size_t)g * n, n, 1, 1, p->bw[g].gvsum, 1.0, 0));
+  hipLaunchKernelGGL(batched_sum_kernel, dim3(G), dim3(256), 0, h->stream, p->gFvar, (int64_t)n, n, p->bw[0].gvsum);
+  GP_HIP_CHECK(h, hipGetLastError());
   GemmFlags f;
   // grad q_sqrt += tril(H Lq)
   f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;

@@ -92,6 +92,7 @@ static inline DevKern dev_kern(const gp_kernel_desc* k) { return DevKern{k->type
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
                               double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws);
 size_t kernel_build_feat_ws_doubles(int m, int n1, int n2);
+int sm_mpad(int m);  // spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded)
 gp_status launch_kernel_diag(gp_handle h, DevKern k, int n, double* out, int accumulate);
 
 // chol.hip
@@ -141,7 +142,7 @@ gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs,
                                         int nsplit, int sym, int scale_by_k, double alpha);
 gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, double* const* d_W, const int* d_M,
                                      const int* d_ld, int batch);
-int gemm_nt_nsplit(int M, int Nlong);
+int gemm_nt_nsplit(int M, int Nlong, int batch);
 int gemm_rowblocks(int M, int big_tiles);
 
 // lik.hip

@@ -33,25 +33,29 @@ __device__ __forceinline__ double r2_expand(double a, double aa, double b, doubl
   return __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b), aa), bb);
 }
 
-// Precompute spectral-mixture features: f[k][j] = sqrt(e_k) cos(2 pi f_k x_j), f[m+k][j] = ... sin(...)
+// Precompute spectral-mixture features, zero-padded to MPAD partials so the consumers can unroll without
+// guards:  f[q][j] = sqrt(e_q) cos(2 pi f_q x_j),  f[MPAD + q][j] = sqrt(e_q) sin(2 pi f_q x_j),  q < m;  0 for q >= m.
 __global__ void __launch_bounds__(256) sm_features_kernel(DevKern k, const double* __restrict__ x, int n,
-                                                          double* __restrict__ f) {
+                                                          double* __restrict__ f, int mpad) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int p = blockIdx.y;
   if (j >= n) return;
-  const double* th = k.theta;
-  double e = th[2 + p], fr = th[2 + k.m + p];
-  double arg = __dmul_rn(__dmul_rn(6.283185307179586, fr), x[j]);
-  double s, c;
-  sincos(arg, &s, &c);
-  double se = __dsqrt_rn(e);
-  f[(size_t)p * n + j] = se * c;
-  f[(size_t)(p + k.m) * n + j] = se * s;
+  double c = 0.0, s = 0.0;
+  if (p < k.m) {
+    const double* th = k.theta;
+    double e = th[2 + p], fr = th[2 + k.m + p];
+    double arg = __dmul_rn(__dmul_rn(6.283185307179586, fr), x[j]);
+    sincos(arg, &s, &c);
+    double se = __dsqrt_rn(e);
+    c *= se; s *= se;
+  }
+  f[(size_t)p * n + j] = c;
+  f[(size_t)(p + mpad) * n + j] = s;
 }
 
 // MODE 0: stationary (Matern12/32/52/RBF); MODE 1: Mercer Matern-1/2 SM (feature form);
 // MODE 2: Matern12sm (broadcast cosine form).  CPT = columns per thread (16-byte stores when 2).
-template <int MODE, int CPT>
+template <int MODE, int CPT, int MPAD>
 __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const double* __restrict__ x1, int n1,
                                                                 const double* __restrict__ x2, int n2,
                                                                 double* __restrict__ out, int64_t ld,
@@ -68,10 +72,10 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   const int iend = min(i0 + COV_ROWS, n1);
 
   if (MODE == 1) {
-    // stage this block's row features: smem[(i - i0) * 2m + q] = f1[q][i]
-    for (int t = threadIdx.x; t < COV_ROWS * 2 * m; t += COV_THREADS) {
+    // stage this block's row features: smem[(i - i0) * 2*MPAD + q] = f1[q][i]
+    for (int t = threadIdx.x; t < COV_ROWS * 2 * MPAD; t += COV_THREADS) {
       int q = t / COV_ROWS, ii = t % COV_ROWS;
-      smem[ii * 2 * m + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
+      smem[ii * 2 * MPAD + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
     }
     __syncthreads();
   }
@@ -87,32 +91,28 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   }
 
   if (MODE == 1) {
-    // column features live in registers for the whole row loop (2m <= 64 values per column)
-    constexpr int QMAX = 64;
-    double fx[CPT][QMAX];
-    // (runtime m: unrolled by the compiler up to QMAX via the guarded loop below)
+    // column features live in registers for the whole row loop (2*MPAD values per column, no guards)
+    double fx[CPT][2 * MPAD];
 #pragma unroll
-    for (int q = 0; q < QMAX; q++) {
+    for (int q = 0; q < 2 * MPAD; q++) {
 #pragma unroll
       for (int c = 0; c < CPT; c++) {
         int j = min(j0 + c, n2 - 1);
-        fx[c][q] = (q < 2 * m) ? f2[(size_t)q * n2 + j] : 0.0;
+        fx[c][q] = f2[(size_t)q * n2 + j];
       }
     }
     for (int i = i0; i < iend; i++) {
       double xa = x1[i];
       double a = xa / ls, aa = __dmul_rn(a, a);
-      const double* fz = &smem[(i - i0) * 2 * m];
+      const double* fz = &smem[(i - i0) * 2 * MPAD];
       double acc[CPT];
 #pragma unroll
       for (int c = 0; c < CPT; c++) acc[c] = 0.0;
 #pragma unroll
-      for (int q = 0; q < QMAX; q++) {
-        if (q < 2 * m) {
-          double z = fz[q];
+      for (int q = 0; q < 2 * MPAD; q++) {
+        double z = fz[q];
 #pragma unroll
-          for (int c = 0; c < CPT; c++) acc[c] = fma(z, fx[c][q], acc[c]);
-        }
+        for (int c = 0; c < CPT; c++) acc[c] = fma(z, fx[c][q], acc[c]);
       }
       double res[CPT];
 #pragma unroll
@@ -183,9 +183,21 @@ __global__ void __launch_bounds__(256) cov_diag_kernel(DevKern k, int n, double*
   out[j] = accumulate ? out[j] + v : v;
 }
 
+int sm_mpad(int m) { return m <= 0 ? 0 : ((m + 3) / 4) * 4; }
+
 size_t kernel_build_feat_ws_doubles(int m, int n1, int n2) {
   if (m <= 0) return 0;
-  return gp_align_up((size_t)2 * m * n1, 32) + gp_align_up((size_t)2 * m * n2, 32);
+  const int mp = sm_mpad(m);
+  return gp_align_up((size_t)2 * mp * n1, 32) + gp_align_up((size_t)2 * mp * n2, 32);
+}
+
+template <int MPAD>
+static void launch_mercer(gp_handle h, dim3 grid, DevKern k, const double* x1, int n1, const double* x2, int n2,
+                          double* out, int64_t ld, int accumulate, double diag_add, const double* f1, const double* f2,
+                          int vec_ok) {
+  size_t sh = (size_t)COV_ROWS * 2 * MPAD * sizeof(double);
+  hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out, ld,
+                     accumulate, diag_add, f1, f2, vec_ok);
 }
 
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
@@ -199,26 +211,34 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
   if (k.type == GP_KERN_MERCER_MATERN12SM) {
     if (k.m < 1 || k.m > 32) return gp_fail(h, GP_ERR_UNSUPPORTED, "num_partials must be in [1, 32]");
     if (!feat_ws) return gp_fail(h, GP_ERR_WORKSPACE, "feature workspace missing");
+    const int mp = sm_mpad(k.m);
     double* f1 = feat_ws;
-    double* f2 = (x2 == x1) ? f1 : feat_ws + gp_align_up((size_t)2 * k.m * n1, 32);
-    dim3 g1((n1 + 255) / 256, k.m);
-    hipLaunchKernelGGL(sm_features_kernel, g1, dim3(256), 0, h->stream, k, x1, n1, f1);
+    double* f2 = (x2 == x1) ? f1 : feat_ws + gp_align_up((size_t)2 * mp * n1, 32);
+    dim3 g1((n1 + 255) / 256, mp);
+    hipLaunchKernelGGL(sm_features_kernel, g1, dim3(256), 0, h->stream, k, x1, n1, f1, mp);
     if (x2 != x1) {
-      dim3 g2((n2 + 255) / 256, k.m);
-      hipLaunchKernelGGL(sm_features_kernel, g2, dim3(256), 0, h->stream, k, x2, n2, f2);
+      dim3 g2((n2 + 255) / 256, mp);
+      hipLaunchKernelGGL(sm_features_kernel, g2, dim3(256), 0, h->stream, k, x2, n2, f2, mp);
     }
-    dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + COV_ROWS - 1) / COV_ROWS);
-    size_t sh = (size_t)COV_ROWS * 2 * k.m * sizeof(double);
-    hipLaunchKernelGGL((cov_build_kernel<1, 1>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out, ld,
-                       accumulate, diag_add, f1, f2, vec_ok);
+    dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
+    switch (mp) {
+      case 4: launch_mercer<4>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      case 8: launch_mercer<8>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      case 12: launch_mercer<12>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      case 16: launch_mercer<16>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      case 20: launch_mercer<20>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      case 24: launch_mercer<24>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+    }
   } else if (k.type == GP_KERN_MATERN12SM) {
     if (k.m < 1) return gp_fail(h, GP_ERR_BAD_ARG, "num_partials must be >= 1");
     dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + COV_ROWS - 1) / COV_ROWS);
-    hipLaunchKernelGGL((cov_build_kernel<2, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
+    hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
                        accumulate, diag_add, nullptr, nullptr, vec_ok);
   } else if (k.type >= GP_KERN_MATERN12 && k.type <= GP_KERN_RBF) {
     dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
-    hipLaunchKernelGGL((cov_build_kernel<0, 2>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
+    hipLaunchKernelGGL((cov_build_kernel<0, 2, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
                        accumulate, diag_add, nullptr, nullptr, vec_ok);
   } else {
     return gp_fail(h, GP_ERR_BAD_ARG, "unknown kernel type");

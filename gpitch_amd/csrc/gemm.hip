@@ -42,78 +42,120 @@ struct GemmSmem {
   static constexpr size_t BYTES = (size_t)2 * STAGE * sizeof(double);
 };
 
-// TAG only names the instantiation (one symbol per role, so profiles attribute time to the right product):
-// 0 generic, 1 cond_A (A = W Kuf), 2 cond_LTA (Lq^T A), 3 kuf_bar (R (A D)), 4 nt (A D A^T split-K)
+// TAG names the instantiation (one symbol per role, so profiles attribute time to the right product) and
+// fixes that role's operand structure at compile time:
+//   0 generic (structure from runtime flags), 1 cond_A (A = W Kuf, W lower), 2 cond_LTA (Lq^T A, upper),
+//   3 kuf_bar (R (A D), columns of B scaled by v1[n]), 4 nt (X D Y^T split-K, B scaled by v1[k])
+template <int TAG> struct RoleCfg { static constexpr int triA = -1, triB = -1, scale = -1; };
+template <> struct RoleCfg<1> { static constexpr int triA = TRI_LOWER, triB = TRI_NONE, scale = 0; };
+template <> struct RoleCfg<2> { static constexpr int triA = TRI_UPPER, triB = TRI_NONE, scale = 0; };
+template <> struct RoleCfg<3> { static constexpr int triA = TRI_NONE, triB = TRI_NONE, scale = 1; };
+template <> struct RoleCfg<4> { static constexpr int triA = TRI_NONE, triB = TRI_NONE, scale = 2; };
+
 template <int BM, int BN, bool TA, bool TB, int TAG>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmProblem* __restrict__ probs,
                                                                     GemmDevFlags f) {
   using S = GemmSmem<BM, BN, TA, TB>;
-  constexpr int WM = BM / 2, WN = BN / 2;   // per-wave tile
-  constexpr int TM = WM / 16, TN = WN / 16; // MFMA tiles per wave
+  // wave layout: 128-tiles use 1 x 4 (each wave owns all 128 rows of a 32-column slice, so triangular
+  // skipping inside the diagonal block is identical for every wave: no barrier imbalance); 64-tiles 2 x 2.
+  constexpr int WAVES_M = (BM == 128) ? 1 : 2, WAVES_N = 4 / WAVES_M;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int EA = BM * GEMM_BK / GEMM_THREADS;  // elements per thread, A tile
   constexpr int EB = BN * GEMM_BK / GEMM_THREADS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 
+  const int triA = RoleCfg<TAG>::triA >= 0 ? RoleCfg<TAG>::triA : f.triA;
+  const int triB = RoleCfg<TAG>::triB >= 0 ? RoleCfg<TAG>::triB : f.triB;
+  const int scale_mode = RoleCfg<TAG>::scale >= 0 ? RoleCfg<TAG>::scale : f.scale_mode;
+
   const GemmProblem p = probs[blockIdx.z];
-  // XCD-aware renumbering: blocks b and b+8 share an XCD; give each XCD a contiguous range of logical
-  // tiles so that the row-blocks that read the same B strip hit the same L2.
   int bid = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-  const int tm = bid % f.tilesM, tn = bid / f.tilesM;
+  int tm, tn, ksl = 0;
+  if (f.ksplit > 1) {
+    // split-K: consecutive workgroups take consecutive K-slices of one output tile; with a symmetric
+    // (lower) output only the tilesM(tilesM+1)/2 tiles on or below the diagonal are enumerated, so every
+    // launched workgroup has work (no statically idle XCD / shader engine).
+    ksl = bid % f.ksplit;
+    const int t = bid / f.ksplit;
+    if (f.triC == TRI_LOWER) {
+      tm = (int)((__dsqrt_rn(8.0 * t + 1.0) - 1.0) * 0.5);
+      while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
+      while (tm * (tm + 1) / 2 > t) tm--;
+      tn = t - tm * (tm + 1) / 2;
+    } else {
+      tm = t % f.tilesM; tn = t / f.tilesM;
+    }
+  } else {
+    // XCD-aware renumbering: blocks b and b+8 share an XCD; give each XCD a contiguous range of logical
+    // tiles so that the row-blocks that read the same B strip hit the same L2.
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    // Row-blocks of a triangular product differ ~7x in work and the hardware deals consecutive workgroups
+    // to the shader engines round-robin, so a fixed (bid % tilesM) would pin all the heavy row-blocks on
+    // one engine; rotating by the strip index keeps a strip's row-blocks adjacent but cycles who gets which.
+    tn = bid / f.tilesM;
+    tm = (bid % f.tilesM + tn) % f.tilesM;
+  }
   const int i0 = tm * BM, j0 = tn * BN;
   if (i0 >= p.M || j0 >= p.N) return;
   if (f.triC == TRI_LOWER && j0 > i0 + BM - 1) return;
 
   int kbeg = 0, kend = p.K;
-  if (f.triA == TRI_LOWER) kend = min(kend, i0 + BM);
-  if (f.triA == TRI_UPPER) kbeg = max(kbeg, i0);
-  if (f.triB == TRI_LOWER) kbeg = max(kbeg, j0);
-  if (f.triB == TRI_UPPER) kend = min(kend, j0 + BN);
+  if (triA == TRI_LOWER) kend = min(kend, i0 + BM);
+  if (triA == TRI_UPPER) kbeg = max(kbeg, i0);
+  if (triB == TRI_LOWER) kbeg = max(kbeg, j0);
+  if (triB == TRI_UPPER) kend = min(kend, j0 + BN);
   kbeg = (kbeg / GEMM_BK) * GEMM_BK;
   if (f.ksplit > 1) {
     int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
     int per = (nk + f.ksplit - 1) / f.ksplit;
-    int s = blockIdx.y;
-    int b0 = kbeg + s * per * GEMM_BK;
+    int b0 = kbeg + ksl * per * GEMM_BK;
     kend = min(kend, b0 + per * GEMM_BK);
     kbeg = b0;
   }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WAVES_N, wc = wave % WAVES_N;
   const int lc = lane & 15, kq = lane >> 4;
 
   // ---- global -> register staging ---------------------------------------------------------------
-  double ra[EA], rb[EB];
-  // A tile coordinates for this thread
-  int a_i, a_k;  // tile-local (row, k) of the first element; EA elements contiguous along memory order
-  if (TA) { constexpr int TPR = BM / EA; a_k = tid / TPR; a_i = (tid % TPR) * EA; }
-  else    { constexpr int TPR = GEMM_BK / EA; a_i = tid / TPR; a_k = (tid % TPR) * EA; }
+  // Row-contiguous tiles (op(A) transposed / op(B) plain) are dealt to threads in 16-byte pairs so that
+  // consecutive lanes hold consecutive pairs: coalesced 256-B row segments per load and conflict-free
+  // ds_write_b128.  k-contiguous tiles give each thread EA (EB) consecutive k of one row.
+  double ra[EA], rb[EB], rs[EB];
+  int a_i, a_k;
+  constexpr int TPR_A = TA ? (BM / EA) : (GEMM_BK / EA);
+  if (TA) { a_k = tid / TPR_A; a_i = (tid % TPR_A) * 2; }   // pairs at a_i + e/2 * (2*TPR_A)
+  else    { a_i = tid / TPR_A; a_k = (tid % TPR_A) * EA; }
   int b_k, b_n;
-  if (TB) { constexpr int TPR = GEMM_BK / EB; b_n = tid / TPR; b_k = (tid % TPR) * EB; }
-  else    { constexpr int TPR = BN / EB; b_k = tid / TPR; b_n = (tid % TPR) * EB; }
+  constexpr int TPR_B = TB ? (GEMM_BK / EB) : (BN / EB);
+  if (TB) { b_n = tid / TPR_B; b_k = (tid % TPR_B) * EB; }
+  else    { b_k = tid / TPR_B; b_n = (tid % TPR_B) * 2; }   // pairs at b_n + e/2 * (2*TPR_B)
   const bool a_vec = ((p.lda & 1) == 0) && ((((uintptr_t)p.A) & 15) == 0);
   const bool b_vec = ((p.ldb & 1) == 0) && ((((uintptr_t)p.B) & 15) == 0);
+  auto a_off = [&](int e) { return TA ? (a_i + (e >> 1) * (2 * TPR_A) + (e & 1)) : (a_k + e); };  // tile-local i (TA) or k
+  auto b_off = [&](int e) { return TB ? (b_k + e) : (b_n + (e >> 1) * (2 * TPR_B) + (e & 1)); };  // tile-local k (TB) or n
 
+  // per-column scale is invariant over the K loop: fetch it once
+  if (scale_mode == 1) {
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+      const int n = j0 + (TB ? b_n : b_off(e));
+      rs[e] = (n < p.N) ? p.v1[n] : 0.0;
+    }
+  }
+
+  // raw loads only: nothing here may consume a loaded value (the waits must sit after the MFMAs)
   auto load_tiles = [&](int kt) {
-    // A
     if (TA) {
-      const int k = kt + a_k, i = i0 + a_i;
-      const double* src = p.A + (int64_t)k * p.lda + i;
-      if (k < kend && i + EA <= p.M && a_vec) {
+      const int k = kt + a_k;
 #pragma unroll
-        for (int e = 0; e < EA; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); ra[e] = v.x; ra[e + 1] = v.y; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EA; e++) ra[e] = (k < kend && i + e < p.M) ? src[e] : 0.0;
-      }
-      if (f.triA != TRI_NONE) {
-#pragma unroll
-        for (int e = 0; e < EA; e++) {
-          bool z = (f.triA == TRI_LOWER) ? (k > i + e) : (k < i + e);
-          if (z) ra[e] = 0.0;
-        }
+      for (int e = 0; e < EA; e += 2) {
+        const int i = i0 + a_off(e);
+        const double* src = p.A + (int64_t)k * p.lda + i;
+        if (k < kend && i + 1 < p.M && a_vec) { double2 v = *reinterpret_cast<const double2*>(src); ra[e] = v.x; ra[e + 1] = v.y; }
+        else { ra[e] = (k < kend && i < p.M) ? src[0] : 0.0; ra[e + 1] = (k < kend && i + 1 < p.M) ? src[1] : 0.0; }
       }
     } else {
       const int i = i0 + a_i, k = kt + a_k;
@@ -125,15 +167,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
 #pragma unroll
         for (int e = 0; e < EA; e++) ra[e] = (i < p.M && k + e < kend) ? src[e] : 0.0;
       }
-      if (f.triA != TRI_NONE) {
-#pragma unroll
-        for (int e = 0; e < EA; e++) {
-          bool z = (f.triA == TRI_LOWER) ? (k + e > i) : (k + e < i);
-          if (z) ra[e] = 0.0;
-        }
-      }
     }
-    // B
     if (TB) {
       const int n = j0 + b_n, k = kt + b_k;
       const double* src = p.B + (int64_t)n * p.ldb + k;
@@ -144,46 +178,69 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
 #pragma unroll
         for (int e = 0; e < EB; e++) rb[e] = (n < p.N && k + e < kend) ? src[e] : 0.0;
       }
+      if (scale_mode == 2) {
 #pragma unroll
-      for (int e = 0; e < EB; e++) {
-        if (f.triB != TRI_NONE) {
-          bool z = (f.triB == TRI_LOWER) ? (n > k + e) : (k + e > n);
-          if (z) rb[e] = 0.0;
-        }
-        if (f.scale_mode == 1) rb[e] *= (n < p.N) ? p.v1[n] : 0.0;
-        if (f.scale_mode == 2) rb[e] *= (k + e < kend) ? p.v1[k + e] : 0.0;
+        for (int e = 0; e < EB; e++) rs[e] = (k + e < kend) ? p.v1[k + e] : 0.0;
       }
     } else {
-      const int k = kt + b_k, n = j0 + b_n;
-      const double* src = p.B + (int64_t)k * p.ldb + n;
-      if (k < kend && n + EB <= p.N && b_vec) {
+      const int k = kt + b_k;
 #pragma unroll
-        for (int e = 0; e < EB; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); rb[e] = v.x; rb[e + 1] = v.y; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EB; e++) rb[e] = (k < kend && n + e < p.N) ? src[e] : 0.0;
+      for (int e = 0; e < EB; e += 2) {
+        const int n = j0 + b_off(e);
+        const double* src = p.B + (int64_t)k * p.ldb + n;
+        if (k < kend && n + 1 < p.N && b_vec) { double2 v = *reinterpret_cast<const double2*>(src); rb[e] = v.x; rb[e + 1] = v.y; }
+        else { rb[e] = (k < kend && n < p.N) ? src[0] : 0.0; rb[e + 1] = (k < kend && n + 1 < p.N) ? src[1] : 0.0; }
       }
+      if (scale_mode == 2) {
+        const double sv = (k < kend) ? p.v1[k] : 0.0;
 #pragma unroll
-      for (int e = 0; e < EB; e++) {
-        if (f.triB != TRI_NONE) {
-          bool z = (f.triB == TRI_LOWER) ? (n + e > k) : (k > n + e);
-          if (z) rb[e] = 0.0;
-        }
-        if (f.scale_mode == 1) rb[e] *= (n + e < p.N) ? p.v1[n + e] : 0.0;
-        if (f.scale_mode == 2) rb[e] *= (k < kend) ? p.v1[k] : 0.0;
+        for (int e = 0; e < EB; e++) rs[e] = sv;
       }
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  // structural masks + scaling, then registers -> LDS (runs after the MFMAs of the current tile)
+  auto store_tiles = [&](int buf, int kt) {
     double* As = smem + buf * S::STAGE;
     double* Bs = As + S::A_ELEMS;
-    double* da = TA ? (As + a_k * S::SA + a_i) : (As + a_i * S::SA + a_k);
+    if (triA != TRI_NONE) {
 #pragma unroll
-    for (int e = 0; e < EA; e += 2) *reinterpret_cast<double2*>(da + e) = make_double2(ra[e], ra[e + 1]);
-    double* db = TB ? (Bs + b_n * S::SB + b_k) : (Bs + b_k * S::SB + b_n);
+      for (int e = 0; e < EA; e++) {
+        const int i = i0 + (TA ? a_off(e) : a_i), k = kt + (TA ? a_k : a_k + e);
+        const bool z = (triA == TRI_LOWER) ? (k > i) : (k < i);
+        if (z) ra[e] = 0.0;
+      }
+    }
+    if (triB != TRI_NONE) {
 #pragma unroll
-    for (int e = 0; e < EB; e += 2) *reinterpret_cast<double2*>(db + e) = make_double2(rb[e], rb[e + 1]);
+      for (int e = 0; e < EB; e++) {
+        const int n = j0 + (TB ? b_n : b_off(e)), k = kt + (TB ? b_k + e : b_k);
+        const bool z = (triB == TRI_LOWER) ? (n > k) : (k > n);
+        if (z) rb[e] = 0.0;
+      }
+    }
+    if (scale_mode != 0) {
+#pragma unroll
+      for (int e = 0; e < EB; e++) rb[e] *= rs[e];
+    }
+    if (TA) {
+#pragma unroll
+      for (int e = 0; e < EA; e += 2)
+        *reinterpret_cast<double2*>(As + a_k * S::SA + a_off(e)) = make_double2(ra[e], ra[e + 1]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EA; e += 2)
+        *reinterpret_cast<double2*>(As + a_i * S::SA + a_k + e) = make_double2(ra[e], ra[e + 1]);
+    }
+    if (TB) {
+#pragma unroll
+      for (int e = 0; e < EB; e += 2)
+        *reinterpret_cast<double2*>(Bs + b_n * S::SB + b_k + e) = make_double2(rb[e], rb[e + 1]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EB; e += 2)
+        *reinterpret_cast<double2*>(Bs + b_k * S::SB + b_off(e)) = make_double2(rb[e], rb[e + 1]);
+    }
   };
 
   d4 acc[TM][TN];
@@ -192,9 +249,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
 #pragma unroll
     for (int b = 0; b < TN; b++) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
+  const int rowbase = i0 + wr * WM;
   if (kbeg < kend) {
     load_tiles(kbeg);
-    store_tiles(0);
+    store_tiles(0, kbeg);
     __syncthreads();
     int buf = 0;
     for (int kt = kbeg; kt < kend; kt += GEMM_BK) {
@@ -202,27 +260,63 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       if (more) load_tiles(kt + GEMM_BK);
       const double* As = smem + buf * S::STAGE;
       const double* Bs = As + S::A_ELEMS;
+      // K-tiles strictly inside the non-zero part of a triangular op(A) run the straight-line body; only
+      // the K-tiles that cross the diagonal pay for the (wave-uniform) per-tile tests.
+      bool full = true;
+      if (triA == TRI_LOWER) full = (kt <= rowbase);
+      if (triA == TRI_UPPER) full = (kt >= rowbase + 16 * TM - 16);
+      if (full) {
 #pragma unroll
-      for (int ks = 0; ks < GEMM_BK / 4; ks++) {
-        double af[TM], bf[TN];
-        const int k = ks * 4 + kq;
+        for (int ks = 0; ks < GEMM_BK / 4; ks++) {
+          const int k = ks * 4 + kq;
+          double af[TM], bf[TN];
 #pragma unroll
-        for (int a = 0; a < TM; a++) {
-          const int i = wr * WM + a * 16 + lc;
-          af[a] = TA ? As[k * S::SA + i] : As[i * S::SA + k];
+          for (int b = 0; b < TN; b++) {
+            const int n = wc * WN + b * 16 + lc;
+            bf[b] = TB ? Bs[n * S::SB + k] : Bs[k * S::SB + n];
+          }
+#pragma unroll
+          for (int a = 0; a < TM; a++) {
+            const int i = wr * WM + a * 16 + lc;
+            af[a] = TA ? As[k * S::SA + i] : As[i * S::SA + k];
+          }
+#pragma unroll
+          for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int b = 0; b < TN; b++)
+              acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
+      } else {
 #pragma unroll
-        for (int b = 0; b < TN; b++) {
-          const int n = wc * WN + b * 16 + lc;
-          bf[b] = TB ? Bs[n * S::SB + k] : Bs[k * S::SB + n];
+        for (int ks = 0; ks < GEMM_BK / 4; ks++) {
+          const int k = ks * 4 + kq;
+          const int kg = kt + ks * 4;  // first global k of this MFMA step
+          // 16-row MFMA tiles of op(A) that are structurally zero for this k-step are skipped (wave-uniform)
+          int a_lo = 0, a_hi = TM;
+          if (triA == TRI_LOWER) a_lo = max(0, (kg - rowbase) >> 4);             // need rowbase+16a+15 >= kg
+          if (triA == TRI_UPPER) a_hi = min(TM, ((kg + 3 - rowbase) >> 4) + 1);  // need rowbase+16a <= kg+3
+          double af[TM], bf[TN];
+#pragma unroll
+          for (int b = 0; b < TN; b++) {
+            const int n = wc * WN + b * 16 + lc;
+            bf[b] = TB ? Bs[n * S::SB + k] : Bs[k * S::SB + n];
+          }
+#pragma unroll
+          for (int a = 0; a < TM; a++) {
+            const int i = wr * WM + a * 16 + lc;
+            af[a] = TA ? As[k * S::SA + i] : As[i * S::SA + k];
+          }
+#pragma unroll
+          for (int a = 0; a < TM; a++) {
+            if (a >= a_lo && a < a_hi) {
+#pragma unroll
+              for (int b = 0; b < TN; b++)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+          }
         }
-#pragma unroll
-        for (int a = 0; a < TM; a++)
-#pragma unroll
-          for (int b = 0; b < TN; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
-      if (more) store_tiles(buf ^ 1);
+      if (more) store_tiles(buf ^ 1, kt + GEMM_BK);
       __syncthreads();
       buf ^= 1;
     }
@@ -230,14 +324,14 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
 
   // ---- epilogue -------------------------------------------------------------------------------
   if (f.ksplit > 1) {
-    double* slab = p.o2 + (int64_t)blockIdx.y * p.M * p.N;
+    double* slab = p.o2 + (int64_t)ksl * p.M * p.N;
 #pragma unroll
     for (int a = 0; a < TM; a++)
 #pragma unroll
       for (int b = 0; b < TN; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = i0 + wr * WM + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
+          const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
           if (i < p.M && j < p.N) slab[(int64_t)i * p.N + j] = acc[a][b][r];
         }
     return;
@@ -249,7 +343,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       for (int b = 0; b < TN; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = i0 + wr * WM + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
+          const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
           if (i < p.M && j < p.N) {
             double v = f.alpha * acc[a][b][r];
             double* c = p.C + (int64_t)i * p.ldc + j;
@@ -261,8 +355,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
   }
   if (f.epi & 6) {
     // per-column reductions over this tile's rows: sum acc^2 and sum acc * v0[row]
-    __syncthreads();  // all waves are past their last LDS read
-    double* red = smem;  // [2 kinds][2 wave-rows][BN]
+    double* red = smem;  // [2 kinds][WAVES_M][BN]  (only needed when two wave-rows share a column)
+    if (WAVES_M > 1) __syncthreads();  // all waves are past their last LDS read
 #pragma unroll
     for (int b = 0; b < TN; b++) {
       double s2 = 0.0, sd = 0.0;
@@ -270,42 +364,52 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       for (int a = 0; a < TM; a++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = i0 + wr * WM + a * 16 + kq + 4 * r;
+          const int i = rowbase + a * 16 + kq + 4 * r;
           const double v = f.alpha * acc[a][b][r];  // rows >= M hold exact zeros
           s2 = fma(v, v, s2);
           if (f.epi & 4) sd = fma(v, (i < p.M) ? p.v0[i] : 0.0, sd);
         }
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
-      if (kq == 0) {
-        const int n = wc * WN + b * 16 + lc;
-        red[(0 * 2 + wr) * BN + n] = s2;
-        red[(1 * 2 + wr) * BN + n] = sd;
+      const int n = wc * WN + b * 16 + lc;
+      if (WAVES_M == 1) {
+        const int j = j0 + n;
+        if (kq == 0 && j < p.N) {
+          if (f.epi & 2) p.o0[(int64_t)tm * p.N + j] = s2;
+          if (f.epi & 4) p.o1[(int64_t)tm * p.N + j] = sd;
+        }
+      } else if (kq == 0) {
+        red[(0 * WAVES_M + wr) * BN + n] = s2;
+        red[(1 * WAVES_M + wr) * BN + n] = sd;
       }
     }
-    __syncthreads();
-    if (tid < BN) {
-      const int j = j0 + tid;
-      if (j < p.N) {
-        if (f.epi & 2) p.o0[(int64_t)tm * p.N + j] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
-        if (f.epi & 4) p.o1[(int64_t)tm * p.N + j] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+    if (WAVES_M > 1) {
+      __syncthreads();
+      if (tid < BN) {
+        const int j = j0 + tid;
+        if (j < p.N) {
+          if (f.epi & 2) p.o0[(int64_t)tm * p.N + j] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
+          if (f.epi & 4) p.o1[(int64_t)tm * p.N + j] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+        }
       }
     }
   }
 }
 
-// Sum split-K slabs (deterministic order) into C; optional symmetric mirror of the lower triangle.
+// Sum split-K slabs in a fixed order into C.  With sym != 0 only elements j <= i are summed (coalesced
+// reads of the lower triangle) and each result is also written to its mirror position.
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const GemmProblem* __restrict__ probs, int nsplit, int sym,
                                                           double alpha) {
   const GemmProblem p = probs[blockIdx.z];
   const int64_t total = (int64_t)p.M * p.N;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int i = (int)(idx / p.N), j = (int)(idx % p.N);
-    int si = i, sj = j;
-    if (sym && j > i) { si = j; sj = i; }
+    const int i = (int)(idx / p.N), j = (int)(idx % p.N);
+    if (sym && j > i) continue;
     double s = 0.0;
-    for (int k = 0; k < nsplit; k++) s += p.o2[(int64_t)k * total + (int64_t)si * p.N + sj];
-    p.C[(int64_t)i * p.ldc + j] = alpha * s;
+    for (int k = 0; k < nsplit; k++) s += p.o2[(int64_t)k * total + idx];
+    s *= alpha;
+    p.C[(int64_t)i * p.ldc + j] = s;
+    if (sym && j < i) p.C[(int64_t)j * p.ldc + i] = s;
   }
 }
 
@@ -318,7 +422,9 @@ static gp_status launch_one(gp_handle h, const GemmProblem* d_probs, int batch, 
   df.tilesM = (maxM + BM - 1) / BM;
   df.tilesN = (maxN + BN - 1) / BN;
   df.ksplit = ksplit;
-  dim3 grid(df.tilesM * df.tilesN, ksplit > 1 ? ksplit : 1, batch);
+  int ntiles = df.tilesM * df.tilesN;
+  if (ksplit > 1 && df.triC == TRI_LOWER) ntiles = df.tilesM * (df.tilesM + 1) / 2;
+  dim3 grid(ntiles * (ksplit > 1 ? ksplit : 1), 1, batch);
   static bool attr_set = false;
   if (!attr_set) {
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f64_kernel<BM, BN, TA, TB, TAG>,
@@ -362,15 +468,16 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
   return dispatch_trans<64>(h, d_probs, batch, maxM, maxN, f, df, 1);
 }
 
-int gemm_nt_nsplit(int M, int Nlong) {
-  // enough K-slices that (tiles x slices) covers the chip a few times over, each slice >= 512 deep
+int gemm_nt_nsplit(int M, int Nlong, int batch) {
+  // enough K-slices that (tiles x slices x batch) covers the chip ~4 times over (2 workgroups per CU), each
+  // slice >= 512 deep; fewer slices = less slab traffic
   int tiles = ((M + 127) / 128);
-  tiles = tiles * (tiles + 1) / 2;
-  int want = (4 * 256 + tiles - 1) / tiles;
+  tiles = tiles * (tiles + 1) / 2 * (batch > 0 ? batch : 1);
+  int want = (2048 + tiles - 1) / tiles;
   int maxs = (Nlong + 511) / 512;
   int s = want < maxs ? want : maxs;
-  if (s < 1) s = 1;
-  if (s > 256) s = 256;
+  if (s < 2) s = 2;
+  if (s > 64) s = 64;
   return s;
 }
 

@@ -19,8 +19,8 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
     add(ns * colblocks * rowblocks);
     add(ns * ((M + 255) / 256 + 1) * rowblocks);
     add(colblocks * M + ((M + 255) / 256 + 1) * M);
-    add(8);
   }
+  add(p->G + 8);
   return d;
 }
 
@@ -90,7 +90,7 @@ size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   addd(2 * ((size_t)(p->maxN + 255) / 256) + 8);
   if (p->whiten) {
     d += pdgp_bwd_doubles(p);
-    int ns = gemm_nt_nsplit(p->maxM, p->maxN);
+    int ns = gemm_nt_nsplit(p->maxM, p->maxN, p->G);
     if (ns < 2) ns = 2;
     size_t slab = 0;
     for (int g = 0; g < p->G; g++) slab += gp_align_up((size_t)ns * p->gps[g].M * p->gps[g].M * sizeof(double), 256) / sizeof(double);
@@ -124,7 +124,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
   }
   p->bw.assign(p->G, BwdBufs());
   if (p->whiten) {
-    p->nsplit = gemm_nt_nsplit(p->maxM, p->maxN);
+    p->nsplit = gemm_nt_nsplit(p->maxM, p->maxN, p->G);
     if (p->nsplit < 2) p->nsplit = 2;
     for (int g = 0; g < p->G; g++) {
       const size_t M = p->gps[g].M;
@@ -138,7 +138,10 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       b.hyp_part = ar.take<double>(ns * colblocks * rowblocks);
       b.hyp_part_uu = ar.take<double>(ns * ((M + 255) / 256 + 1) * rowblocks);
       b.gz_part = ar.take<double>(colblocks * M + ((M + 255) / 256 + 1) * M);
-      b.gvsum = ar.take<double>(8);
+    }
+    {  // sum_n gv per GP, contiguous so one launch fills all of them
+      double* gvs = ar.take<double>(p->G + 8);
+      for (int g = 0; g < p->G; g++) p->bw[g].gvsum = gvs + g;
     }
     size_t slab_total = 0;
     for (int g = 0; g < p->G; g++) slab_total += gp_align_up((size_t)p->nsplit * p->gps[g].M * p->gps[g].M * sizeof(double), 256) / sizeof(double);

@@ -60,9 +60,9 @@ __global__ void __launch_bounds__(256) rate_fma64(double* out, unsigned long lon
 int main() {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   int ncu = p.multiProcessorCount;
-  double* out; CK(hipMalloc(&out, 256 * 8 * 4096));
-  unsigned long long* st; CK(hipMalloc(&st, 16 * 4096));
-  std::vector<unsigned long long> hs(2 * 4096);
+  double* out; CK(hipMalloc(&out, 256 * 8 * 8192));
+  unsigned long long* st; CK(hipMalloc(&st, 16 * 8192));
+  std::vector<unsigned long long> hs(2 * 8192);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto report = [&](const char* name, int grid, double flops, float ms, double instr_per_wave) {
     hipMemcpy(hs.data(), st, 16 * grid, hipMemcpyDeviceToHost);
@@ -71,9 +71,9 @@ int main() {
     std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
     printf("%-28s grid %4d: %8.3f ms %7.1f TFLOP/s  in-kernel clk %.0f MHz  cyc/instr/wave %.1f\n", name, grid, ms, flops / ms * 1e-9, clk[grid / 2], cyc[grid / 2]);
   };
-  for (int rep = 0; rep < 2; rep++) {
-    for (int wpc = 1; wpc <= 2; wpc++) {
-      int grid = ncu * wpc, iters = 60000;
+  for (int rep = 0; rep < 1; rep++) {
+    for (int wpc = 1; wpc <= 8; wpc *= 2) {
+      int grid = ncu * wpc, iters = 30000;
       float ms;
       rate_f64<4><<<grid, 256>>>(out, st, 1000, 1.0); CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0)); rate_f64<4><<<grid, 256>>>(out, st, iters, 1.0); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
