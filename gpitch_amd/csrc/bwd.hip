@@ -382,6 +382,11 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
   for (int s = 0; s < S_COUNT; s++) p->off_bwd[s] = base + s * slot_bytes;
   const int64_t ldN = ldN_b(n);
   size_t slab_off = 0;
+  p->kgps.clear();
+  for (int g = 0; g < G; g++)
+    if (p->gps[g].need_theta || p->gps[g].need_z) p->kgps.push_back(g);
+  p->nK = (int)p->kgps.size();
+  int kslot = 0;
   for (int g = 0; g < G; g++) {
     const PdgpGP& q = p->gps[g];
     const CondTask& t = p->cb.tasks[g];
@@ -391,8 +396,14 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     const double* q_sqrt = params + q.off_qsqrt;
     const double* gm = p->gFmu + (size_t)g * n;
     const double* gv = p->gFvar + (size_t)g * n;
+    const bool kneed = (q.need_theta || q.need_z);
     auto P = [&](int slot) -> GemmProblem& {
-      GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + p->off_bwd[slot] + g * sizeof(GemmProblem));
+      // the kernel-gradient chain (slots S_R..S_S) is batched over the GPs that need it only
+      const bool kchain = (slot >= S_E);   // E, Wbar, R, alpha, Kuf_bar and the Cholesky-adjoint chain
+      static GemmProblem dummy;
+      if (kchain && !kneed) { memset(&dummy, 0, sizeof(dummy)); return dummy; }
+      const int idx = kchain ? kslot : g;
+      GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + p->off_bwd[slot] + idx * sizeof(GemmProblem));
       memset(&r, 0, sizeof(r));
       r.M = M; r.N = M; r.K = M; r.lda = M; r.ldb = M; r.ldc = M;
       return r;
@@ -414,6 +425,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     { GemmProblem& r = P(S_P); r.A = t.L; r.B = b.T1; r.C = b.T2; }
     { GemmProblem& r = P(S_T3); r.A = t.W; r.B = b.T2; r.C = b.H; }
     { GemmProblem& r = P(S_S); r.A = b.H; r.B = t.W; r.C = b.E; }
+    if (kneed) kslot++;
   }
   return GP_OK;
 }
@@ -434,39 +446,42 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   // grad q_sqrt += tril(H Lq)
   f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
   GP_CHECK(launch_gemm_batched(h, D(S_HLQ), G, maxM, maxM, f));
-  // E = Lq Lq^T - I
-  f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
-  GP_CHECK(launch_gemm_batched(h, D(S_E), G, maxM, maxM, f));
-  GP_CHECK(launch_sub_identity_batched(h, D(S_E), G, maxM));
-  // T1 = E H
-  f = GemmFlags();
-  GP_CHECK(launch_gemm_batched(h, D(S_EH), G, maxM, maxM, f));
-  // Wbar = tril(T1 L^T) + tril(mu (L u)^T)
-  f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D(S_WBAR), G, maxM, maxM, f));
-  GP_CHECK(launch_matvec_batched(h, D(S_LU), G, maxM, 0));
-  GP_CHECK(launch_rank1_tril_batched(h, D(S_RANK1), G, maxM));
-  // R = W^T E ; alpha = W^T mu
-  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
-  GP_CHECK(launch_gemm_batched(h, D(S_R), G, maxM, maxM, f));
-  GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), G, maxM, 1));
-  // Kuf_bar (dense part) = R (A diag(2 gv))
-  f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
-  GP_CHECK(launch_gemm_batched(h, D(S_G), G, maxM, n, f));
-  // Kuu side: Lbar = -tril(W^T Wbar W^T); P = Phi(L^T Lbar); S = W^T P W
-  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D(S_T2), G, maxM, maxM, f));
-  f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
-  GP_CHECK(launch_gemm_batched(h, D(S_LBAR), G, maxM, maxM, f));
-  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D(S_P), G, maxM, maxM, f));
-  GP_CHECK(launch_phi_batched(h, D(S_P), G, maxM));
-  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D(S_T3), G, maxM, maxM, f));
-  f = GemmFlags(); f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D(S_S), G, maxM, maxM, f));
+  const int nK = p->nK;   // latent GPs whose kernel hyper-parameters / inducing inputs are trainable
+  if (nK > 0) {
+    // E = Lq Lq^T - I
+    f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
+    GP_CHECK(launch_gemm_batched(h, D(S_E), nK, maxM, maxM, f));
+    GP_CHECK(launch_sub_identity_batched(h, D(S_E), nK, maxM));
+    // T1 = E H
+    f = GemmFlags();
+    GP_CHECK(launch_gemm_batched(h, D(S_EH), nK, maxM, maxM, f));
+    // Wbar = tril(T1 L^T) + tril(mu (L u)^T)
+    f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D(S_WBAR), nK, maxM, maxM, f));
+    GP_CHECK(launch_matvec_batched(h, D(S_LU), nK, maxM, 0));
+    GP_CHECK(launch_rank1_tril_batched(h, D(S_RANK1), nK, maxM));
+    // R = W^T E ; alpha = W^T mu
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
+    GP_CHECK(launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f));
+    GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), nK, maxM, 1));
+    // Kuf_bar (dense part) = R (A diag(2 gv))
+    f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
+    GP_CHECK(launch_gemm_batched(h, D(S_G), nK, maxM, n, f));
+    // Kuu side: Lbar = -tril(W^T Wbar W^T); P = Phi(L^T Lbar); S = W^T P W
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D(S_T2), nK, maxM, maxM, f));
+    f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
+    GP_CHECK(launch_gemm_batched(h, D(S_LBAR), nK, maxM, maxM, f));
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D(S_P), nK, maxM, maxM, f));
+    GP_CHECK(launch_phi_batched(h, D(S_P), nK, maxM));
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D(S_T3), nK, maxM, maxM, f));
+    f = GemmFlags(); f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D(S_S), nK, maxM, maxM, f));
+  }
   // hyper-parameter and inducing-input gradients
-  for (int g = 0; g < G; g++) {
+  for (int g : p->kgps) {
     const PdgpGP& q = p->gps[g];
     const CondTask& t = p->cb.tasks[g];
     const BwdBufs& b = p->bw[g];
@@ -474,8 +489,8 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     const double* gm = p->gFmu + (size_t)g * n;
     int np_uf = 0, np_uu = 0;
     const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS, cb_uu = (q.M + HY_THREADS - 1) / HY_THREADS;
-    double* gz_uf = b.gz_part;
-    double* gz_uu = b.gz_part + (size_t)cb_uf * q.M;
+    double* gz_uf = q.need_z ? b.gz_part : nullptr;
+    double* gz_uu = q.need_z ? b.gz_part + (size_t)cb_uf * q.M : nullptr;
     GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, x, n, b.G, ldN, b.alpha, gm, 0, t.feat, b.hyp_part, &np_uf, gz_uf));
     GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part, np_uf, b.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
                                  grad + q.off_z));

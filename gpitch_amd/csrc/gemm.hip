@@ -17,8 +17,16 @@
 // tile; workgroups are renumbered so that the row-blocks sharing one operand strip sit on the same
 // XCD (shared L2).  Two workgroups are resident per CU (<= 256 VGPRs, 2 x 72 KiB LDS).
 #include "common.h"
+#include <stdlib.h>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+// Pointers fetched from the problem descriptor are generic to the compiler, which then emits flat_load:
+// FLAT counts on lgkmcnt as well as vmcnt, so every LDS wait in the K loop would also wait for the
+// in-flight operand prefetch.  Typing them as address-space-1 gives global_load / global_store.
+typedef const double __attribute__((address_space(1))) * gcptr;
+typedef double __attribute__((address_space(1))) * gptr;
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef const dbl2 __attribute__((address_space(1))) * gcptr2;
 
 #define GEMM_THREADS 256
 #define GEMM_BK 16
@@ -70,6 +78,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
   const int scale_mode = RoleCfg<TAG>::scale >= 0 ? RoleCfg<TAG>::scale : f.scale_mode;
 
   const GemmProblem p = probs[blockIdx.z];
+  const gcptr gA = (gcptr)p.A, gB = (gcptr)p.B, gv0 = (gcptr)p.v0, gv1 = (gcptr)p.v1;
+  const gptr gC = (gptr)p.C, go0 = (gptr)p.o0, go1 = (gptr)p.o1, go2 = (gptr)p.o2;
   int bid = blockIdx.x;
   int tm, tn, ksl = 0;
   if (f.ksplit > 1) {
@@ -142,7 +152,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
 #pragma unroll
     for (int e = 0; e < EB; e++) {
       const int n = j0 + (TB ? b_n : b_off(e));
-      rs[e] = (n < p.N) ? p.v1[n] : 0.0;
+      rs[e] = (n < p.N) ? gv1[n] : 0.0;
     }
   }
 
@@ -153,16 +163,16 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
 #pragma unroll
       for (int e = 0; e < EA; e += 2) {
         const int i = i0 + a_off(e);
-        const double* src = p.A + (int64_t)k * p.lda + i;
-        if (k < kend && i + 1 < p.M && a_vec) { double2 v = *reinterpret_cast<const double2*>(src); ra[e] = v.x; ra[e + 1] = v.y; }
+        const gcptr src = gA + (int64_t)k * p.lda + i;
+        if (k < kend && i + 1 < p.M && a_vec) { dbl2 v = *(gcptr2)(src); ra[e] = v.x; ra[e + 1] = v.y; }
         else { ra[e] = (k < kend && i < p.M) ? src[0] : 0.0; ra[e + 1] = (k < kend && i + 1 < p.M) ? src[1] : 0.0; }
       }
     } else {
       const int i = i0 + a_i, k = kt + a_k;
-      const double* src = p.A + (int64_t)i * p.lda + k;
+      const gcptr src = gA + (int64_t)i * p.lda + k;
       if (i < p.M && k + EA <= kend && a_vec) {
 #pragma unroll
-        for (int e = 0; e < EA; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); ra[e] = v.x; ra[e + 1] = v.y; }
+        for (int e = 0; e < EA; e += 2) { dbl2 v = *(gcptr2)(src + e); ra[e] = v.x; ra[e + 1] = v.y; }
       } else {
 #pragma unroll
         for (int e = 0; e < EA; e++) ra[e] = (i < p.M && k + e < kend) ? src[e] : 0.0;
@@ -170,29 +180,29 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
     }
     if (TB) {
       const int n = j0 + b_n, k = kt + b_k;
-      const double* src = p.B + (int64_t)n * p.ldb + k;
+      const gcptr src = gB + (int64_t)n * p.ldb + k;
       if (n < p.N && k + EB <= kend && b_vec) {
 #pragma unroll
-        for (int e = 0; e < EB; e += 2) { double2 v = *reinterpret_cast<const double2*>(src + e); rb[e] = v.x; rb[e + 1] = v.y; }
+        for (int e = 0; e < EB; e += 2) { dbl2 v = *(gcptr2)(src + e); rb[e] = v.x; rb[e + 1] = v.y; }
       } else {
 #pragma unroll
         for (int e = 0; e < EB; e++) rb[e] = (n < p.N && k + e < kend) ? src[e] : 0.0;
       }
       if (scale_mode == 2) {
 #pragma unroll
-        for (int e = 0; e < EB; e++) rs[e] = (k + e < kend) ? p.v1[k + e] : 0.0;
+        for (int e = 0; e < EB; e++) rs[e] = (k + e < kend) ? gv1[k + e] : 0.0;
       }
     } else {
       const int k = kt + b_k;
 #pragma unroll
       for (int e = 0; e < EB; e += 2) {
         const int n = j0 + b_off(e);
-        const double* src = p.B + (int64_t)k * p.ldb + n;
-        if (k < kend && n + 1 < p.N && b_vec) { double2 v = *reinterpret_cast<const double2*>(src); rb[e] = v.x; rb[e + 1] = v.y; }
+        const gcptr src = gB + (int64_t)k * p.ldb + n;
+        if (k < kend && n + 1 < p.N && b_vec) { dbl2 v = *(gcptr2)(src); rb[e] = v.x; rb[e + 1] = v.y; }
         else { rb[e] = (k < kend && n < p.N) ? src[0] : 0.0; rb[e + 1] = (k < kend && n + 1 < p.N) ? src[1] : 0.0; }
       }
       if (scale_mode == 2) {
-        const double sv = (k < kend) ? p.v1[k] : 0.0;
+        const double sv = (k < kend) ? gv1[k] : 0.0;
 #pragma unroll
         for (int e = 0; e < EB; e++) rs[e] = sv;
       }
@@ -324,7 +334,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
 
   // ---- epilogue -------------------------------------------------------------------------------
   if (f.ksplit > 1) {
-    double* slab = p.o2 + (int64_t)ksl * p.M * p.N;
+    gptr slab = go2 + (int64_t)ksl * p.M * p.N;
 #pragma unroll
     for (int a = 0; a < TM; a++)
 #pragma unroll
@@ -346,7 +356,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
           const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
           if (i < p.M && j < p.N) {
             double v = f.alpha * acc[a][b][r];
-            double* c = p.C + (int64_t)i * p.ldc + j;
+            gptr c = gC + (int64_t)i * p.ldc + j;
             if (f.beta != 0.0) v += f.beta * (*c);
             if (f.triC == TRI_LOWER && j > i) v = 0.0;
             *c = v;
@@ -367,7 +377,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
           const int i = rowbase + a * 16 + kq + 4 * r;
           const double v = f.alpha * acc[a][b][r];  // rows >= M hold exact zeros
           s2 = fma(v, v, s2);
-          if (f.epi & 4) sd = fma(v, (i < p.M) ? p.v0[i] : 0.0, sd);
+          if (f.epi & 4) sd = fma(v, (i < p.M) ? gv0[i] : 0.0, sd);
         }
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
@@ -375,8 +385,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       if (WAVES_M == 1) {
         const int j = j0 + n;
         if (kq == 0 && j < p.N) {
-          if (f.epi & 2) p.o0[(int64_t)tm * p.N + j] = s2;
-          if (f.epi & 4) p.o1[(int64_t)tm * p.N + j] = sd;
+          if (f.epi & 2) go0[(int64_t)tm * p.N + j] = s2;
+          if (f.epi & 4) go1[(int64_t)tm * p.N + j] = sd;
         }
       } else if (kq == 0) {
         red[(0 * WAVES_M + wr) * BN + n] = s2;
@@ -388,8 +398,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       if (tid < BN) {
         const int j = j0 + tid;
         if (j < p.N) {
-          if (f.epi & 2) p.o0[(int64_t)tm * p.N + j] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
-          if (f.epi & 4) p.o1[(int64_t)tm * p.N + j] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+          if (f.epi & 2) go0[(int64_t)tm * p.N + j] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
+          if (f.epi & 4) go1[(int64_t)tm * p.N + j] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
         }
       }
     }

@@ -64,6 +64,16 @@ gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* o
 }
 
 gp_status gp_pdgp_destroy(gp_pdgp_plan p) { delete p; return GP_OK; }
+
+gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, int32_t need_z) {
+  if (!p || g < 0 || g >= p->G) return GP_ERR_BAD_ARG;
+  if (p->gps[g].need_theta != (need_theta != 0) || p->gps[g].need_z != (need_z != 0)) {
+    p->gps[g].need_theta = need_theta != 0;
+    p->gps[g].need_z = need_z != 0;
+    p->last_params = nullptr;   // force the backward descriptors to be rebuilt
+  }
+  return GP_OK;
+}
 int64_t gp_pdgp_num_params(gp_pdgp_plan p) { return p ? p->nparams : 0; }
 
 gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t* off_z, int64_t* off_qmu,

@@ -4,6 +4,7 @@
 
 struct PdgpGP {
   int M = 0, ktype = 0, m = 0;
+  int need_theta = 1, need_z = 1;   // gp_pdgp_set_grad_needs
   int64_t off_theta = 0, off_z = 0, off_qmu = 0, off_qsqrt = 0;
 };
 
@@ -45,6 +46,8 @@ struct gp_pdgp_plan_s {
   size_t off_kl_items = 0;
   size_t off_bwd[16] = {0};
   int nsplit = 1;
+  int nK = 0;                 // number of GPs whose kernel gradients are needed (compacted batch)
+  std::vector<int> kgps;      // their indices
   // cache keys for the descriptor upload
   const double* last_params = nullptr; const double* last_x = nullptr; double* last_grad = nullptr; int last_n = -1;
   bool bwd_carved = false;

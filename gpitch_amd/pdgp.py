@@ -163,6 +163,10 @@ class Pdgp(Parameterized):
             tc[off:off + v.size] = 2 if p.fixed else p.transform.code
         self._params.copy_(h.torch.as_tensor(host))
         self._tcode.copy_(h.torch.as_tensor(tc))
+        # `.fixed` Params drop out of the backward pass (GPflow removes them from the free state)
+        for g, (kern, z, q_mu, q_sqrt) in enumerate(self._gps()):
+            need_theta = any(not p.fixed for p in kern.theta_params())
+            h.check(h.lib.gp_pdgp_set_grad_needs(self._plan, g, int(need_theta), int(not z.fixed)))
         h.check(h.lib.gp_transform_backward(h.h, self._params.data_ptr(), self._tcode.data_ptr(), self._nparams,
                                             self._free.data_ptr()))
 

@@ -150,6 +150,13 @@ gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t*
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p);
 gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes);
 
+/* Which gradients the caller will use for latent GP g (0 = skip that work).  GPflow's `.fixed = True`
+ * (demo-modgp.py:40-41: m.za.fixed / m.zc.fixed; init_models.py:97-98: kern.fixed) removes a Param from the
+ * TF gradient; here it lets the backward pass skip the inducing-input contraction (need_z = 0) or, when the
+ * kernel hyper-parameters are fixed as well (need_theta = 0), the whole Kuf_bar / Kuu_bar chain of that GP.
+ * Skipped entries of the gradient vector are left at zero.  Default: everything needed. */
+gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, int32_t need_z);
+
 /* Pdgp.build_likelihood (pdgp.py:133-170) on the batch (x, y) of n frames:
  *   elbo = (num_data / n) * sum_n varexp_n - KL.   Writes the scalar to elbo_dev[0] (device) and, when
  * elbo_host != NULL, copies it to the host (syncs).  When grad != NULL also writes d elbo / d params

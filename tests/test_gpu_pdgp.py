@@ -161,3 +161,28 @@ def test_hip_path_matches_committed_golden(gp_handle, name):
         fm, fv = conditional(prob["x"], prob["zc"][i], kern[1][i], prob["q_mu_com"][i], q_sqrt=prob["q_sqrt_com"][i], whiten=False)
         np.testing.assert_allclose(fm[:, 0], d["fmean_unwhite"][:, P + i], rtol=0, atol=1e-9 * np.abs(d["fmean_unwhite"]).max())
         np.testing.assert_allclose(fv[:, 0], d["fvar_unwhite"][:, P + i], rtol=0, atol=1e-9 * np.abs(d["fvar_unwhite"]).max())
+
+
+def test_gradient_with_fixed_params_skips_work_but_stays_exact(gp_handle):
+    """`.fixed = True` on inducing inputs / a whole kernel removes those entries from the gradient (zeros)
+    and must leave every other entry unchanged."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(600, 24, 2, num_partials=3, seed=4)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model.za.fixed = True
+    model.zc.fixed = True
+    model.kern_act[1].fixed = True          # one latent GP needs no kernel gradient at all
+    model._pack()
+    f = model._elbo(True)
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    assert abs(f - ref_f) <= ELBO_RTOL * abs(ref_f)
+    got = model_grad_dict(model)
+    for name, rg in ref_g.items():
+        gg = got[name]
+        if name.startswith("z") or name.startswith("act1."):
+            assert np.all(gg == 0), name
+            continue
+        if name.startswith("q_sqrt"):
+            rg = np.tril(rg[:, :, 0])[:, :, None]
+        scale = max(np.abs(rg).max(), 1e-12)
+        np.testing.assert_allclose(gg.reshape(rg.shape), rg, rtol=0, atol=2e-7 * scale, err_msg=name)
