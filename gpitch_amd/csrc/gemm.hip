@@ -12,7 +12,7 @@
 // 128 x 128 (strip) or 64 x 64 (small) output tiles, BK = 16, operands staged global -> registers ->
 // LDS with one barrier per K-tile (double-buffered LDS, next tile's global loads in flight during the
 // MFMAs), LDS strides padded so that every fragment read is bank-conflict free for ds_read_b64
-// (64-bank modulus): k-contiguous tiles use stride BK+2, row-contiguous tiles use stride B+16.
+// (k-contiguous tiles use the odd stride BK+1, row-contiguous tiles use stride B+16).
 // Triangular operands skip whole K-tiles that are structurally zero and mask inside the diagonal
 // tile; workgroups are renumbered so that the row-blocks sharing one operand strip sit on the same
 // XCD (shared L2).  Two workgroups are resident per CU (<= 256 VGPRs, 2 x 72 KiB LDS).
@@ -42,8 +42,10 @@ struct GemmDevFlags {
 
 template <int BM, int BN, bool TA, bool TB>
 struct GemmSmem {
-  static constexpr int SA = TA ? (BM + 16) : (GEMM_BK + 2);
-  static constexpr int SB = TB ? (GEMM_BK + 2) : (BN + 16);
+  // k-contiguous tiles: odd stride (BK+1) so the 16-lane groups of the fused ds_read2_b64 fragment reads
+  // (32-bank rule) hit 16 distinct bank pairs; row-contiguous tiles: consecutive lanes read consecutive doubles.
+  static constexpr int SA = TA ? (BM + 16) : (GEMM_BK + 1);
+  static constexpr int SB = TB ? (GEMM_BK + 1) : (BN + 16);
   static constexpr int A_ELEMS = TA ? GEMM_BK * SA : BM * SA;
   static constexpr int B_ELEMS = TB ? BN * SB : GEMM_BK * SB;
   static constexpr int STAGE = A_ELEMS + B_ELEMS;
@@ -53,12 +55,12 @@ struct GemmSmem {
 // TAG names the instantiation (one symbol per role, so profiles attribute time to the right product) and
 // fixes that role's operand structure at compile time:
 //   0 generic (structure from runtime flags), 1 cond_A (A = W Kuf, W lower), 2 cond_LTA (Lq^T A, upper),
-//   3 kuf_bar (R (A D), columns of B scaled by v1[n]), 4 nt (X D Y^T split-K, B scaled by v1[k])
+//   3 kuf_bar (R (A D), columns of B scaled by v1[n]), 4 nt (X [D] Y^T split-K, B optionally scaled by v1[k])
 template <int TAG> struct RoleCfg { static constexpr int triA = -1, triB = -1, scale = -1; };
 template <> struct RoleCfg<1> { static constexpr int triA = TRI_LOWER, triB = TRI_NONE, scale = 0; };
 template <> struct RoleCfg<2> { static constexpr int triA = TRI_UPPER, triB = TRI_NONE, scale = 0; };
 template <> struct RoleCfg<3> { static constexpr int triA = TRI_NONE, triB = TRI_NONE, scale = 1; };
-template <> struct RoleCfg<4> { static constexpr int triA = TRI_NONE, triB = TRI_NONE, scale = 2; };
+template <> struct RoleCfg<4> { static constexpr int triA = TRI_NONE, triB = TRI_NONE, scale = -1; };  // scale: runtime (v1 may be absent)
 
 template <int BM, int BN, bool TA, bool TB, int TAG>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmProblem* __restrict__ probs,
@@ -239,13 +241,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
         *reinterpret_cast<double2*>(As + a_k * S::SA + a_off(e)) = make_double2(ra[e], ra[e + 1]);
     } else {
 #pragma unroll
-      for (int e = 0; e < EA; e += 2)
-        *reinterpret_cast<double2*>(As + a_i * S::SA + a_k + e) = make_double2(ra[e], ra[e + 1]);
+      for (int e = 0; e < EA; e++) As[a_i * S::SA + a_k + e] = ra[e];   // odd stride: 8-byte stores
     }
     if (TB) {
 #pragma unroll
-      for (int e = 0; e < EB; e += 2)
-        *reinterpret_cast<double2*>(Bs + b_n * S::SB + b_k + e) = make_double2(rb[e], rb[e + 1]);
+      for (int e = 0; e < EB; e++) Bs[b_n * S::SB + b_k + e] = rb[e];
     } else {
 #pragma unroll
       for (int e = 0; e < EB; e += 2)

@@ -1,34 +1,405 @@
-// sgpr.hip — SGPRSS plan (gpitch/sgpr_ss.py:10-114).  Entry points are declared in gpitch_abi.h.
+// sgpr.hip — SGPRSS plan: Titsias collapsed bound with a sum-of-pitch kernel, sparse predictions and the
+// per-source exact-GP posterior.  Mirrors gpitch/sgpr_ss.py:29-114 and GPflow-0.5 SGPR.build_predict.
+//   Kuf = sum_p K_p(Z,X); L = chol(Kuu + jitter I); A = L^-1 Kuf / sigma; B = A A^T + I; LB = chol(B);
+//   c = LB^-1 (A err) / sigma; bound = -N/2 log 2pi - sum log diag LB - N/2 log s2 - |err|^2/(2 s2)
+//                                     + |c|^2/2 - sum Kdiag/(2 s2) + tr(A A^T)/2  [- 1000 sum |v_p|]
+// Everything is assembled from the same kernels as the Pdgp path (cov.hip, chol.hip, gemm.hip); the only
+// new device code is the handful of small scalar/vector kernels below.
 #include "engine.h"
+#include <string.h>
 
 struct gp_sgpr_plan_s {
   gp_handle h = nullptr;
+  int P = 0, maxN = 0, M = 0, reg = 0;
+  double jitter = 1e-6;
+  std::vector<int> ktype, m;
+  std::vector<int64_t> off_theta;
+  int64_t nparams = 0;
+  int maxm = 0;
+  void* ws = nullptr; size_t ws_bytes = 0;
+  // workspace
+  double *L = nullptr, *W = nullptr, *Kuf = nullptr, *A = nullptr, *H = nullptr, *LB = nullptr, *WB = nullptr;
+  double *feat = nullptr, *s1 = nullptr, *s2 = nullptr, *dot = nullptr, *u = nullptr, *c = nullptr, *slabs = nullptr;
+  double *scal = nullptr;   // [0] bound, [1] sum err^2, [2] sum colsumsq(A'), [3] kdiag total per point, [4..] scratch
+  char* d_desc = nullptr; std::vector<char> h_desc[2];   // two descriptor blocks (training pass / prediction pass)
+  int nsplit = 2;
 };
+
+static inline int64_t ldN64(int N) { return (N + 1) & ~1; }
+static const size_t SG_DESC_BYTES = 16 * 1024;
+
+// ---- small kernels ----------------------------------------------------------------------------------
+// C[i][i] += mul * s[0] + add   (s may be null)
+__global__ void __launch_bounds__(256) add_diag_kernel(double* __restrict__ C, int M, int64_t ld,
+                                                       const double* __restrict__ s, double mul, double add) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < M) C[(int64_t)i * ld + i] += (s ? mul * s[0] : 0.0) + add;
+}
+
+// B = H / s2 + I
+__global__ void __launch_bounds__(256) sgpr_B_kernel(const double* __restrict__ H, double* __restrict__ B, int M,
+                                                     const double* __restrict__ s2) {
+  const double inv = 1.0 / s2[0];
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)M * M; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx / M), j = (int)(idx % M);
+    B[idx] = H[idx] * inv + (i == j ? 1.0 : 0.0);
+  }
+}
+
+// out[0] = sum_n v[n]^2 (one block)
+__global__ void __launch_bounds__(256) sumsq_kernel(const double* __restrict__ v, int n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a = fma(v[i], v[i], a);
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// out[0] = sum over [rb][N] partials (one block)
+__global__ void __launch_bounds__(256) sum_all_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) a += v[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// c = WB (u / s2)  and the bound scalar.  One block.
+__global__ void __launch_bounds__(256) sgpr_finish_kernel(const double* __restrict__ WB, const double* __restrict__ LB,
+                                                          const double* __restrict__ u, double* __restrict__ c, int M,
+                                                          int N, const double* __restrict__ params, int P,
+                                                          const int* __restrict__ toff, const int* __restrict__ ktype,
+                                                          const int* __restrict__ km, int reg,
+                                                          double* __restrict__ scal) {
+  __shared__ double red[256];
+  const double s2 = params[0];
+  double csq = 0.0, logd = 0.0;
+  for (int i = threadIdx.x; i < M; i += 256) {
+    double acc = 0.0;
+    for (int k = 0; k <= i; k++) acc = fma(WB[(int64_t)i * M + k], u[k], acc);
+    acc /= s2;
+    c[i] = acc;
+    csq = fma(acc, acc, csq);
+    logd += log(LB[(int64_t)i * M + i]);
+  }
+  red[threadIdx.x] = csq; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  csq = red[0]; __syncthreads();
+  red[threadIdx.x] = logd; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  logd = red[0];
+  if (threadIdx.x == 0) {
+    double kd = 0.0, vabs = 0.0;
+    for (int p = 0; p < P; p++) {
+      const double* th = params + toff[p];
+      double v = th[0];
+      vabs += fabs(v);
+      if (ktype[p] == GP_KERN_MERCER_MATERN12SM || ktype[p] == GP_KERN_MATERN12SM) {
+        double s = 0.0;
+        for (int q = 0; q < km[p]; q++) s += th[2 + q];
+        v *= s;
+      }
+      kd += v;
+    }
+    const double LOG2PI = 1.8378770664093453;
+    double b = -0.5 * N * LOG2PI;          // sgpr_ss.py:56
+    b += -logd;                            // :57  (output_dim = 1)
+    b -= 0.5 * N * log(s2);                // :58
+    b += -0.5 * scal[1] / s2;              // :59
+    b += 0.5 * csq;                        // :60
+    b += -0.5 * (N * kd) / s2;             // :61
+    b += 0.5 * scal[2] / s2;               // :62  tr(A A^T) with A = A'/sigma
+    if (reg) b -= 1000.0 * vabs;           // :64-68
+    scal[0] = b;
+    scal[3] = kd;
+  }
+}
+
+// mean[n] = sum_rb dot[rb][n];  var[n] = kd + sum_rb s2[rb][n] - sum_rb s1[rb][n]   (SGPR.build_predict)
+// src mode: var[n] = kd - sum_rb s1[rb][n]   (sgpr_ss.py:101)
+__global__ void __launch_bounds__(256) predict_finish_kernel(const double* __restrict__ dot, const double* __restrict__ s1,
+                                                             const double* __restrict__ s2p, int rb, int n,
+                                                             const double* __restrict__ kd, double* __restrict__ mean,
+                                                             double* __restrict__ var) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  double d = 0.0, a = 0.0, b = 0.0;
+  for (int r = 0; r < rb; r++) {
+    d += dot[(int64_t)r * n + j];
+    a += s1[(int64_t)r * n + j];
+    if (s2p) b += s2p[(int64_t)r * n + j];
+  }
+  mean[j] = d;
+  var[j] = s2p ? (kd[0] + b) - a : kd[0] - a;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
+  size_t d = 0;
+  auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
+  const size_t M = p->M, ld = ldN64(p->maxN);
+  const int rb = gemm_rowblocks(p->M, 1);
+  for (int i = 0; i < 5; i++) add(M * M);           // L, W, H, LB, WB
+  add(M * ld); add(M * ld);                          // Kuf, A
+  add(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, p->M, p->maxN));
+  add((size_t)rb * p->maxN); add((size_t)rb * p->maxN); add((size_t)rb * p->maxN);
+  add(M); add(M); add(64);
+  add((size_t)p->nsplit * M * M);
+  return d;
+}
 
 extern "C" {
 
 gp_status gp_sgpr_create(gp_handle h, const gp_sgpr_config* cfg, gp_sgpr_plan* out) {
-  (void)cfg; if (out) *out = nullptr;
-  return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_sgpr_create: not implemented yet");
+  if (!h || !out) return GP_ERR_BAD_ARG;
+  *out = nullptr;
+  if (!cfg || cfg->num_kernels < 1 || cfg->max_N < 1 || cfg->M < 1 || !cfg->kern_type || !cfg->partials)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_create: bad config");
+  gp_sgpr_plan p = new gp_sgpr_plan_s();
+  p->h = h; p->P = cfg->num_kernels; p->maxN = cfg->max_N; p->M = cfg->M; p->reg = cfg->reg; p->jitter = cfg->jitter;
+  int64_t off = 1;
+  for (int i = 0; i < p->P; i++) {
+    const int t = cfg->kern_type[i], m = cfg->partials[i];
+    const bool sm = (t == GP_KERN_MERCER_MATERN12SM || t == GP_KERN_MATERN12SM);
+    if (t < 0 || t > GP_KERN_MATERN12SM || (sm && (m < 1 || m > 32)) || (!sm && m != 0)) {
+      delete p;
+      return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_create: bad kernel config");
+    }
+    p->ktype.push_back(t); p->m.push_back(m); p->off_theta.push_back(off);
+    off += GP_THETA_LEN(m);
+    if (m > p->maxm) p->maxm = m;
+  }
+  p->nparams = off;
+  p->nsplit = gemm_nt_nsplit(p->M, p->maxN, 1);
+  *out = p;
+  return GP_OK;
 }
+
 gp_status gp_sgpr_destroy(gp_sgpr_plan p) { delete p; return GP_OK; }
-int64_t gp_sgpr_num_params(gp_sgpr_plan p) { (void)p; return 0; }
-size_t gp_sgpr_workspace_bytes(gp_sgpr_plan p) { (void)p; return 0; }
-gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) { (void)p; (void)workspace; (void)bytes; return GP_ERR_UNSUPPORTED; }
+int64_t gp_sgpr_num_params(gp_sgpr_plan p) { return p ? p->nparams : 0; }
+size_t gp_sgpr_workspace_bytes(gp_sgpr_plan p) { return p ? sgpr_ws_doubles(p) * sizeof(double) + 2 * SG_DESC_BYTES + 4096 : 0; }
+
+gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
+  if (!p) return GP_ERR_BAD_ARG;
+  if (!workspace || bytes < gp_sgpr_workspace_bytes(p) || (((uintptr_t)workspace) & 255))
+    return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: workspace too small or not 256-byte aligned");
+  GpArena ar(workspace, bytes);
+  const size_t M = p->M, ld = ldN64(p->maxN);
+  const int rb = gemm_rowblocks(p->M, 1);
+  p->d_desc = ar.take<char>(2 * SG_DESC_BYTES);
+  p->L = ar.take<double>(M * M); p->W = ar.take<double>(M * M); p->H = ar.take<double>(M * M);
+  p->LB = ar.take<double>(M * M); p->WB = ar.take<double>(M * M);
+  p->Kuf = ar.take<double>(M * ld); p->A = ar.take<double>(M * ld);
+  p->feat = ar.take<double>(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, p->M, p->maxN));
+  p->s1 = ar.take<double>((size_t)rb * p->maxN); p->s2 = ar.take<double>((size_t)rb * p->maxN);
+  p->dot = ar.take<double>((size_t)rb * p->maxN);
+  p->u = ar.take<double>(M); p->c = ar.take<double>(M); p->scal = ar.take<double>(64);
+  p->slabs = ar.take<double>((size_t)p->nsplit * M * M);
+  if (!ar.ok) return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: arena exhausted");
+  p->ws = workspace; p->ws_bytes = bytes;
+  return GP_OK;
+}
+
+}  // extern "C"
+
+static DevKern sg_kern(const gp_sgpr_plan_s* p, const double* params, int i) {
+  return DevKern{p->ktype[i], p->m[i], params + p->off_theta[i]};
+}
+
+// device descriptor upload helper: returns device pointers for up to 6 GemmProblems + 3 int arrays
+struct SgDesc { GemmProblem* probs; int* toff; int* ktype; int* km; };
+static gp_status sg_upload(gp_sgpr_plan p, const std::vector<GemmProblem>& probs, SgDesc* out, int slot) {
+  const size_t nb = probs.size() * sizeof(GemmProblem);
+  const size_t off_int = gp_align_up(8 * sizeof(GemmProblem), 256);
+  if (off_int + 3 * 256 * sizeof(int) > SG_DESC_BYTES || p->P > 256 || probs.size() > 8)
+    return gp_fail(p->h, GP_ERR_UNSUPPORTED, "sgpr: too many kernels/problems for the descriptor block");
+  std::vector<char>& hd = p->h_desc[slot];
+  char* dd = p->d_desc + (size_t)slot * SG_DESC_BYTES;
+  hd.assign(SG_DESC_BYTES, 0);
+  memcpy(hd.data(), probs.data(), nb);
+  int* hi = (int*)(hd.data() + off_int);
+  for (int i = 0; i < p->P; i++) { hi[i] = (int)p->off_theta[i]; hi[256 + i] = p->ktype[i]; hi[512 + i] = p->m[i]; }
+  GP_HIP_CHECK(p->h, hipMemcpyAsync(dd, hd.data(), SG_DESC_BYTES, hipMemcpyHostToDevice, p->h->stream));
+  out->probs = (GemmProblem*)dd;
+  out->toff = (int*)(dd + off_int); out->ktype = out->toff + 256; out->km = out->toff + 512;
+  return GP_OK;
+}
+
+// shared front part: L, W, Kuf, A' = W Kuf (+ colsumsq), H = A' A'^T, B, LB, WB, u = A' y, c, bound scalar
+static gp_status sgpr_common(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N,
+                             const double* Z, SgDesc* desc) {
+  gp_handle h = p->h;
+  const int M = p->M;
+  const int64_t ld = ldN64(N);
+  const int rb = gemm_rowblocks(M, 1);
+  std::vector<GemmProblem> probs(3);
+  memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
+  { GemmProblem& r = probs[0]; r.A = p->W; r.lda = M; r.B = p->Kuf; r.ldb = ld; r.C = p->A; r.ldc = ld; r.M = M; r.N = N; r.K = M; r.o0 = p->s1; }
+  { GemmProblem& r = probs[1]; r.A = p->A; r.lda = ld; r.B = p->A; r.ldb = ld; r.C = p->H; r.ldc = M; r.M = M; r.N = M; r.K = N; r.o2 = p->slabs; }
+  { GemmProblem& r = probs[2]; r.A = p->A; r.lda = ld; r.M = M; r.N = N; r.v0 = Y; r.o0 = p->u; }
+  GP_CHECK(sg_upload(p, probs, desc, 0));
+  // Kuu, Kuf: GPflow Add kernel = sum over kern_list (sgpr_ss.py:42-43)
+  for (int i = 0; i < p->P; i++) {
+    DevKern k = sg_kern(p, params, i);
+    GP_CHECK(launch_kernel_build(h, k, Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, p->feat));
+  }
+  GP_CHECK(launch_cholesky_single(h, p->L, M, M));
+  GP_CHECK(launch_tri_inverse_single(h, p->L, p->W, M, M));
+  for (int i = 0; i < p->P; i++) {
+    DevKern k = sg_kern(p, params, i);
+    GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat));
+  }
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ;
+    GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
+  hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, p->scal + 2);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, h->stream, Y, N, p->scal + 1);
+  GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
+  hipLaunchKernelGGL(sgpr_B_kernel, dim3(64), dim3(256), 0, h->stream, p->H, p->LB, M, params);
+  GP_CHECK(launch_cholesky_single(h, p->LB, M, M));
+  GP_CHECK(launch_tri_inverse_single(h, p->LB, p->WB, M, M));
+  GP_CHECK(launch_rowdot_batched(h, desc->probs + 2, 1, M));
+  hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->WB, p->LB, p->u, p->c, M, N, params, p->P,
+                     desc->toff, desc->ktype, desc->km, p->reg, p->scal);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+extern "C" {
+
 gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                         const double* Z, double* bound_dev, double* bound_host) {
-  (void)p; (void)params; (void)X; (void)Y; (void)N; (void)Z; (void)bound_dev; (void)bound_host; return GP_ERR_UNSUPPORTED;
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_bound: workspace not set");
+  if (!params || !X || !Y || !Z || N < 1 || N > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound: bad argument");
+  SgDesc d;
+  GP_CHECK(sgpr_common(p, params, X, Y, N, Z, &d));
+  if (bound_dev) GP_HIP_CHECK(h, hipMemcpyAsync(bound_dev, p->scal, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (bound_host) {
+    GP_HIP_CHECK(h, hipMemcpyAsync(bound_host, p->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return check_not_pd(h);
+  }
+  return GP_OK;
 }
+
 gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                             const double* Z, const double* Xnew, int32_t n, double* mean, double* var) {
-  (void)p; (void)params; (void)X; (void)Y; (void)N; (void)Z; (void)Xnew; (void)n; (void)mean; (void)var; return GP_ERR_UNSUPPORTED;
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_predict_f: workspace not set");
+  if (!params || !X || !Y || !Z || !Xnew || !mean || !var || N < 1 || N > p->maxN || n < 1 || n > p->maxN)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_predict_f: bad argument");
+  SgDesc d;
+  GP_CHECK(sgpr_common(p, params, X, Y, N, Z, &d));
+  const int M = p->M;
+  const int64_t ld = ldN64(n);
+  const int rb = gemm_rowblocks(M, 1);
+  // tmp1 = W Kus (stored in A; colsumsq -> s1); tmp2 = WB tmp1 (colsumsq -> s2, dot with c -> dot)
+  std::vector<GemmProblem> probs(2);
+  memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
+  { GemmProblem& r = probs[0]; r.A = p->W; r.lda = M; r.B = p->Kuf; r.ldb = ld; r.C = p->A; r.ldc = ld; r.M = M; r.N = n; r.K = M; r.o0 = p->s1; }
+  { GemmProblem& r = probs[1]; r.A = p->WB; r.lda = M; r.B = p->A; r.ldb = ld; r.M = M; r.N = n; r.K = M; r.v0 = p->c; r.o0 = p->s2; r.o1 = p->dot; }
+  SgDesc d2;
+  GP_CHECK(sg_upload(p, probs, &d2, 1));
+  for (int i = 0; i < p->P; i++) {
+    DevKern k = sg_kern(p, params, i);
+    GP_CHECK(launch_kernel_build(h, k, Z, M, Xnew, n, p->Kuf, ld, i > 0, 0.0, p->feat));
+  }
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ;
+    GP_CHECK(launch_gemm_batched(h, d2.probs + 0, 1, M, n, f)); }
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_COLSUMSQ | EPI_COLDOT;
+    GP_CHECK(launch_gemm_batched(h, d2.probs + 1, 1, M, n, f)); }
+  hipLaunchKernelGGL(predict_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, p->dot, p->s1, p->s2, rb, n,
+                     p->scal + 3, mean, var);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return check_not_pd(h);
 }
-size_t gp_sgpr_predict_source_workspace_bytes(int32_t N, int32_t n) { (void)N; (void)n; return 0; }
+
+size_t gp_sgpr_predict_source_workspace_bytes(int32_t N, int32_t n) {
+  if (N < 1 || n < 1) return 256;
+  const size_t ld = ldN64(n);
+  const int rb = gemm_rowblocks(N, 1);
+  size_t d = 0;
+  auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
+  add((size_t)N * N); add((size_t)N * N);     // K -> L, W
+  add((size_t)N * ld); add((size_t)N * ld);   // Kx, A
+  add(kernel_build_feat_ws_doubles(32, N, n > N ? n : N));
+  add((size_t)rb * n); add((size_t)rb * n); add(N); add(64);
+  return d * sizeof(double) + SG_DESC_BYTES + 4096;
+}
+
 gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                                  const double* Xnew, int32_t n, double* mean, double* var, void* workspace,
                                  size_t workspace_bytes) {
-  (void)p; (void)params; (void)X; (void)Y; (void)N; (void)Xnew; (void)n; (void)mean; (void)var; (void)workspace; (void)workspace_bytes;
-  return GP_ERR_UNSUPPORTED;
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!params || !X || !Y || !Xnew || !mean || !var || N < 1 || n < 1)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_predict_source: bad argument");
+  if (!workspace || workspace_bytes < gp_sgpr_predict_source_workspace_bytes(N, n) || (((uintptr_t)workspace) & 255))
+    return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_predict_source: workspace too small");
+  GpArena ar(workspace, workspace_bytes);
+  const int64_t ld = ldN64(n);
+  const int rb = gemm_rowblocks(N, 1);
+  char* d_desc = ar.take<char>(SG_DESC_BYTES);
+  double* L = ar.take<double>((size_t)N * N);
+  double* W = ar.take<double>((size_t)N * N);
+  double* Kx = ar.take<double>((size_t)N * ld);
+  double* A = ar.take<double>((size_t)N * ld);
+  double* feat = ar.take<double>(kernel_build_feat_ws_doubles(32, N, n > N ? n : N));
+  double* s1 = ar.take<double>((size_t)rb * n);
+  double* dot = ar.take<double>((size_t)rb * n);
+  double* V = ar.take<double>(N);
+  double* scal = ar.take<double>(64);
+  if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_predict_source: arena exhausted");
+  // K = K_sum(X) + sigma^2 I ; L = chol(K) ; W = L^-1 ; V = W y   (sgpr_ss.py:88-90)
+  for (int i = 0; i < p->P; i++)
+    GP_CHECK(launch_kernel_build(h, sg_kern(p, params, i), X, N, nullptr, N, L, N, i > 0, 0.0, feat));
+  hipLaunchKernelGGL(add_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, L, N, (int64_t)N, params, 1.0, 0.0);
+  GP_CHECK(launch_cholesky_single(h, L, N, N));
+  GP_CHECK(launch_tri_inverse_single(h, L, W, N, N));
+  std::vector<GemmProblem> probs(2);
+  memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
+  { GemmProblem& r = probs[0]; r.A = W; r.lda = N; r.M = N; r.v0 = Y; r.o0 = V; }
+  { GemmProblem& r = probs[1]; r.A = W; r.lda = N; r.B = Kx; r.ldb = ld; r.C = A; r.ldc = ld; r.M = N; r.N = n; r.K = N;
+    r.v0 = V; r.o0 = s1; r.o1 = dot; }
+  GP_HIP_CHECK(h, hipMemcpyAsync(d_desc, probs.data(), probs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // probs is a stack object
+  GemmProblem* dp = (GemmProblem*)d_desc;
+  GP_CHECK(launch_matvec_batched(h, dp + 0, 1, N, 0));
+  // kd = Kdiag of the SUM kernel (sgpr_ss.py:101), computed by the bound's finish kernel formula
+  {
+    double kd = 0.0;  // host-side: needs theta -> fetch the few scalars (predict_s is not on the training path)
+    std::vector<double> th(p->nparams);
+    GP_HIP_CHECK(h, hipMemcpyAsync(th.data(), params, p->nparams * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < p->P; i++) {
+      const double* t = th.data() + p->off_theta[i];
+      double v = t[0];
+      if (p->ktype[i] == GP_KERN_MERCER_MATERN12SM || p->ktype[i] == GP_KERN_MATERN12SM) {
+        double s = 0.0;
+        for (int q = 0; q < p->m[i]; q++) s += t[2 + q];
+        v *= s;
+      }
+      kd += v;
+    }
+    GP_HIP_CHECK(h, hipMemcpyAsync(scal, &kd, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  }
+  for (int i = 0; i < p->P; i++) {
+    // Kx = K_i(X, Xnew); A = W Kx; mean_i = A^T V; var_i = Kdiag_sum - sum A^2   (sgpr_ss.py:92-103)
+    GP_CHECK(launch_kernel_build(h, sg_kern(p, params, i), X, N, Xnew, n, Kx, ld, 0, 0.0, feat));
+    GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A;
+    f.epilogue = EPI_COLSUMSQ | EPI_COLDOT;
+    GP_CHECK(launch_gemm_batched(h, dp + 1, 1, N, n, f));
+    hipLaunchKernelGGL(predict_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, dot, s1,
+                       (const double*)nullptr, rb, n, scal, mean + (size_t)i * n, var + (size_t)i * n);
+  }
+  GP_HIP_CHECK(h, hipGetLastError());
+  return check_not_pd(h);
 }
 
 }  // extern "C"

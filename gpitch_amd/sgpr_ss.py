@@ -1,30 +1,154 @@
-"""SGPRSS — sparse GP regression for source separation (gpitch/sgpr_ss.py:10-114)."""
+"""SGPRSS — sparse Gaussian process regression for source separation (gpitch/sgpr_ss.py:10-114), on the
+HIP engine (csrc/sgpr.hip) through gp_sgpr_*.  Same constructor and method names as the reference:
+
+    m = SGPRSS(X, Y, kern, Z, reg=False)       # kern: sum of pitch kernels (np.sum(list) -> Add, .kern_list)
+    m.build_likelihood()                        # collapsed bound (sgpr_ss.py:29-71)
+    mean, var = m.predict_f(Xnew)               # GPflow SGPR.build_predict (separation.py:306)
+    smean, svar = m.predict_s(Xnew)             # per-source exact posterior (sgpr_ss.py:73-114)
+"""
+import ctypes as C
+
 import numpy as np
 
+from . import _lib
+from .kernels import Add
 from .param import DataHolder, Param, ParamList, Parameterized, transforms
 
 
-class SGPRSS(Parameterized):
-    """Same constructor as the reference (sgpr_ss.py:14): SGPRSS(X, Y, kern, Z, mean_function=None, reg=False),
-    `kern` a GPflow-style Add kernel with `.kern_list`."""
+class _Gaussian(Parameterized):
+    """gpflow.likelihoods.Gaussian: variance Param (positive), initial value 1.0"""
 
-    def __init__(self, X, Y, kern, Z, mean_function=None, reg=False):
+    def __init__(self):
+        self.variance = Param(1.0, transforms.positive)
+
+
+class SGPRSS(Parameterized):
+    def __init__(self, X, Y, kern, Z, mean_function=None, reg=False, handle=None):
         if mean_function is not None:
             raise NotImplementedError("only the zero mean function is used on the gpitch path")
+        if not isinstance(kern, Add):
+            kern = Add([kern])
         if reg:
             kern.var_vector = ParamList([k.variance for k in kern.kern_list])   # sgpr_ss.py:17-22
+        Y = np.asarray(Y, dtype=np.float64)
+        if Y.ndim != 2 or Y.shape[1] != 1:
+            raise ValueError("Y must be N x 1")
         self.X = DataHolder(np.asarray(X, dtype=np.float64).reshape(-1, 1))
-        self.Y = DataHolder(np.asarray(Y, dtype=np.float64).reshape(-1, 1))
-        self.Z = DataHolder(np.asarray(Z, dtype=np.float64).reshape(-1, 1), on_shape_change='pass')
+        self.Y = DataHolder(Y)
+        self.Z = DataHolder(np.asarray(Z, dtype=np.float64).reshape(-1, 1), on_shape_change='pass')   # :26
         self.kern = kern
         self.reg = reg
         self.likelihood = _Gaussian()
         self.num_latent = 1
+        self._handle = handle
+        self._plan = None
+        self._plan_key = None
+
+    # data can be swapped between windows (transcription.py:253-263: model.X = x; model.Y = 20*y; model.Z = z)
+    def __setattr__(self, name, value):
+        cur = self.__dict__.get(name)
+        if isinstance(cur, DataHolder) and not isinstance(value, DataHolder):
+            value = np.asarray(value, dtype=np.float64)
+            object.__setattr__(self, name, DataHolder(value.reshape(-1, 1)))
+        else:
+            Parameterized.__setattr__(self, name, value)
+
+    # ------------------------------------------------------------------------------------------
+    def _compile(self, n_pred=0):
+        h = self._handle = self._handle or _lib.default_handle()
+        kl = self.kern.kern_list
+        N, M = self.X.shape[0], self.Z.shape[0]
+        maxN = max(N, n_pred)
+        key = (maxN, M, tuple((k.type_code, int(k.num_partials)) for k in kl), bool(self.reg))
+        if self._plan is not None and self._plan_key == key:
+            return
+        self._destroy()
+        P = len(kl)
+        i32 = C.c_int32 * P
+        self._keep = (i32(*[k.type_code for k in kl]), i32(*[int(k.num_partials) for k in kl]))
+        cfg = _lib.SgprConfig(P, maxN, M, self._keep[0], self._keep[1], 1e-6, int(bool(self.reg)))
+        plan = C.c_void_p()
+        h.check(h.lib.gp_sgpr_create(h.h, C.byref(cfg), C.byref(plan)))
+        self._plan, self._plan_key = plan, key
+        self._ws = h.workspace(h.lib.gp_sgpr_workspace_bytes(plan))
+        h.check(h.lib.gp_sgpr_set_workspace(plan, self._ws.data_ptr(), self._ws.numel()))
+        self._nparams = int(h.lib.gp_sgpr_num_params(plan))
+        self._bound_dev = h.zeros(1)
+
+    def _pack(self):
+        h = self._handle
+        vec = [self.likelihood.variance.value.reshape(-1)]
+        for k in self.kern.kern_list:
+            vec.append(k.theta())
+        host = np.concatenate(vec)
+        assert host.size == self._nparams
+        self._params = h.to_device(host)
+        self._Xd = h.to_device(self.X._array.reshape(-1))
+        self._Yd = h.to_device(self.Y._array.reshape(-1))
+        self._Zd = h.to_device(self.Z._array.reshape(-1))
 
     def build_likelihood(self):
-        raise NotImplementedError("SGPRSS bound: HIP path lands next (gp_sgpr_bound)")
+        """the bound on the marginal likelihood (sgpr_ss.py:29-71)"""
+        self._compile()
+        self._pack()
+        h = self._handle
+        out = C.c_double()
+        h.check(h.lib.gp_sgpr_bound(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
+                                    self.X.shape[0], self._Zd.data_ptr(), self._bound_dev.data_ptr(), C.byref(out)))
+        return out.value
 
+    def compute_log_likelihood(self):
+        return self.build_likelihood()
 
-class _Gaussian(Parameterized):
-    def __init__(self):
-        self.variance = Param(1.0, transforms.positive)
+    def predict_f(self, Xnew):
+        """mean and variance of the mixture at Xnew (GPflow 0.5 SGPR.build_predict, full_cov=False)"""
+        Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1)
+        n = Xnew.size
+        self._compile(n_pred=n)
+        self._pack()
+        h = self._handle
+        xs = h.to_device(Xnew)
+        mean, var = h.empty(n), h.empty(n)
+        h.check(h.lib.gp_sgpr_predict_f(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
+                                        self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(), n, mean.data_ptr(),
+                                        var.data_ptr()))
+        return mean.cpu().numpy().reshape(-1, 1), var.cpu().numpy().reshape(-1, 1)
+
+    def build_predict_source(self, Xnew, full_cov=False):
+        """p(source* | Y): exact GP on the N training frames, one posterior per kernel in kern_list
+        (sgpr_ss.py:73-106; the variance uses the SUM kernel's Kdiag as the reference does)."""
+        if full_cov:
+            raise NotImplementedError("full_cov=True is never used on the gpitch path")
+        Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1)
+        n, N, P = Xnew.size, self.X.shape[0], len(self.kern.kern_list)
+        self._compile()
+        self._pack()
+        h = self._handle
+        xs = h.to_device(Xnew)
+        mean, var = h.empty(P, n), h.empty(P, n)
+        ws = h.workspace(h.lib.gp_sgpr_predict_source_workspace_bytes(N, n))
+        h.check(h.lib.gp_sgpr_predict_source(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
+                                             self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(), var.data_ptr(),
+                                             ws.data_ptr(), ws.numel()))
+        m, v = mean.cpu().numpy(), var.cpu().numpy()
+        return [m[i].reshape(-1, 1) for i in range(P)], [v[i].reshape(-1, 1) for i in range(P)]
+
+    def predict_s(self, Xnew):
+        """sgpr_ss.py:108-114"""
+        return self.build_predict_source(Xnew)
+
+    def optimize(self, *a, **kw):
+        raise NotImplementedError("SGPRSS.optimize (L-BFGS-B on the bound) needs the bound's gradient, which lands "
+                                  "after the forward path (SURVEY §8f rank 3)")
+
+    def _destroy(self):
+        if self._plan is not None and self._handle is not None and self._handle.h:
+            self._handle.sync()
+            self._handle.lib.gp_sgpr_destroy(self._plan)
+        self._plan = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass

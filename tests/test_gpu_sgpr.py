@@ -1,0 +1,89 @@
+"""GPU parity of the SGPRSS path (bound, predict_f, predict_s) against the oracle and the golden vector."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gpflow05 as orc  # noqa: E402
+
+
+def _model(X, Y, Z, kdicts, noise, handle, reg=False):
+    import gpitch_amd
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm
+    from gpitch_amd.sgpr_ss import SGPRSS
+    ks = [MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=d["variance"],
+                           lengthscales=d["lengthscales"]) for d in kdicts]
+    m = SGPRSS(X, Y, np.sum(ks), Z, reg=reg, handle=handle)
+    m.likelihood.variance = noise
+    return m
+
+
+def _problem(N, M, P, seed):
+    rng = np.random.RandomState(seed)
+    fs = 16000.
+    X = np.linspace(0, (N - 1) / fs, N).reshape(-1, 1)
+    kl = []
+    Y = np.zeros((N, 1))
+    for p in range(P):
+        f0 = 220. * 2 ** (p * 4 / 12.)
+        Y += np.sin(2 * np.pi * f0 * X) * np.exp(-((X - X.mean()) / (0.3 * np.ptp(X) + 1e-9)) ** 2)
+        kl.append({"type": "mercer_matern12sm", "variance": 1.0 + 0.1 * p, "lengthscales": 0.05 + 0.02 * p,
+                   "energy": [0.6, 0.4], "frequency": [f0, 2 * f0]})
+    Y += 0.05 * rng.randn(N, 1)
+    Z = X[:: max(N // M, 1)][:M].copy()
+    return X, Y, Z, kl
+
+
+@pytest.mark.parametrize("N,M,P", [(200, 12, 1), (2001, 64, 3), (3000, 130, 5)])
+@pytest.mark.parametrize("reg", [False, True])
+def test_sgpr_bound_matches_oracle(gp_handle, N, M, P, reg):
+    X, Y, Z, kl = _problem(N, M, P, N)
+    m = _model(X, Y, Z, kl, 0.3, gp_handle, reg=reg)
+    got = m.build_likelihood()
+    ref = orc.sgpr_bound(X, Y, Z, kl, 0.3, reg=reg)
+    assert abs(got - ref) <= 1e-9 * abs(ref), (got, ref)
+
+
+def test_sgpr_bound_matches_golden(gp_handle):
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sgpr_small.npz"))
+    kl = []
+    for i in range(int(d["P"])):
+        th = d["kern_%d_theta" % i]
+        mm = (len(th) - 2) // 2
+        kl.append({"type": "mercer_matern12sm", "variance": th[0], "lengthscales": th[1], "energy": list(th[2:2 + mm]),
+                   "frequency": list(th[2 + mm:])})
+    m = _model(d["X"], d["Y"], d["Z"], kl, float(d["noise_var"]), gp_handle)
+    got = m.build_likelihood()
+    assert abs(got - float(d["bound"])) <= 1e-9 * abs(float(d["bound"]))
+
+
+def test_sgpr_predictions_match_oracle(gp_handle):
+    X, Y, Z, kl = _problem(1500, 50, 3, 7)
+    m = _model(X, Y, Z, kl, 0.2, gp_handle)
+    Xs = X[::7] + 1e-5
+    mean, var = m.predict_f(Xs)
+    rm, rv = orc.sgpr_predict_f(Xs, X, Y, Z, kl, 0.2)
+    np.testing.assert_allclose(mean, rm, rtol=0, atol=1e-8 * np.abs(rm).max())
+    np.testing.assert_allclose(var, rv, rtol=0, atol=1e-8 * np.abs(rv).max())
+    sm, sv = m.predict_s(Xs)
+    rsm, rsv = orc.sgpr_predict_source(Xs, X, Y, kl, 0.2)
+    for i in range(3):
+        np.testing.assert_allclose(sm[i], rsm[i], rtol=0, atol=1e-8 * max(np.abs(rsm[i]).max(), 1e-3))
+        np.testing.assert_allclose(sv[i], rsv[i], rtol=0, atol=1e-8 * np.abs(rsv[i]).max())
+
+
+def test_sgpr_window_swap(gp_handle):
+    """AMT/SoSp reset the DataHolders per window (transcription.py:253-263); the plan must follow."""
+    X, Y, Z, kl = _problem(400, 20, 2, 1)
+    m = _model(X, Y, Z, kl, 0.5, gp_handle)
+    b0 = m.build_likelihood()
+    X2, Y2, Z2, _ = _problem(500, 25, 2, 2)
+    m.X = X2
+    m.Y = 20. * Y2
+    m.Z = Z2
+    m.likelihood.variance = 1.
+    b1 = m.build_likelihood()
+    ref = orc.sgpr_bound(X2, 20. * Y2, Z2, kl, 1.0)
+    assert abs(b1 - ref) <= 1e-9 * abs(ref) and b0 != b1
