@@ -131,7 +131,7 @@ def main():
                                    model._tcode.data_ptr(), model._adam_m.data_ptr(), model._adam_v.data_ptr(),
                                    model._nparams, model._adam_t, opt.learning_rate, opt.beta1, opt.beta2, opt.epsilon))
         if dist is not None:   # scalar ELBO of the whole job (north_star: all-reduce of the scalar ELBO)
-            elbo_sum.copy_(model._elbo_dev)
+            elbo_sum.copy_(model._elbo_dev[:1])
             dist.all_reduce(elbo_sum)
 
     for _ in range(args.warmup):
@@ -155,7 +155,7 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device=h.device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-    elbo_final = float(model._elbo_dev.item())
+    elbo_final = float(model._elbo_dev[0].item())
     timers = h.timers()
 
     if rank == 0:

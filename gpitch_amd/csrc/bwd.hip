@@ -378,7 +378,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
   (void)x;
   const int G = p->G;
   const size_t slot_bytes = gp_align_up(G * sizeof(GemmProblem), 256);
-  size_t base = gp_align_up(G * kl_item_bytes(), 256);
+  size_t base = pdgp_kl_region_bytes(G);
   for (int s = 0; s < S_COUNT; s++) p->off_bwd[s] = base + s * slot_bytes;
   const int64_t ldN = ldN_b(n);
   size_t slab_off = 0;

@@ -12,6 +12,10 @@ size_t kl_item_bytes();
 void kl_item_fill(void* host_item, const double* q_mu, const double* q_sqrt, int M, double* out, double* g_mu,
                   double* g_sqrt);
 gp_status launch_kl_white(gp_handle h, const void* d_items, int count);
+size_t klu_item_bytes();
+void klu_item_fill(void* host_item, const double* q_mu, const double* q_sqrt, const double* L, const double* W,
+                   const double* tr_part, int nrb, int M, double* out);
+gp_status launch_kl_unwhite(gp_handle h, const void* d_items, int count);
 gp_status launch_elbo_finish(gp_handle h, const double* lik_partials, int nblocks, const double* kl, int nkl,
                              double* elbo, double* g_noise);
 gp_status launch_mean_source(gp_handle h, const double* fmean, int P, int n, int nlin, double* out);

@@ -267,6 +267,49 @@ void kl_item_fill(void* host_item, const double* q_mu, const double* q_sqrt, int
   k->q_mu = q_mu; k->q_sqrt = q_sqrt; k->M = M; k->out = out; k->g_mu = g_mu; k->g_sqrt = g_sqrt;
 }
 
+// unwhitened KL per GP (GPflow gauss_kl with K = Kuu + jitter I, pdgp.py:126-129), given L = chol(K), W = L^-1
+// and the column sums of squares of W Lq (trace term) as row-block partials [nrb][M]:
+//   0.5*(|W mu|^2 - M - sum log Lq_ii^2 + |W Lq|_F^2 + sum log L_ii^2)
+struct KlUItem {
+  const double* q_mu; const double* q_sqrt; const double* L; const double* W; const double* tr_part;
+  int nrb; int M; double* out;
+};
+
+__global__ void __launch_bounds__(1024) kl_unwhite_kernel(const KlUItem* __restrict__ items) {
+  const KlUItem it = items[blockIdx.x];
+  const int M = it.M;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    double al = 0.0;
+    for (int k = 0; k <= i; k++) al = fma(it.W[(int64_t)i * M + k], it.q_mu[k], al);
+    const double dq = it.q_sqrt[(int64_t)i * M + i], dl = it.L[(int64_t)i * M + i];
+    acc += al * al - log(dq * dq) + log(dl * dl);
+    for (int r = 0; r < it.nrb; r++) acc += it.tr_part[(int64_t)r * M + i];
+  }
+  __shared__ double red[16];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
+    it.out[0] = 0.5 * (s - (double)M);
+  }
+}
+
+gp_status launch_kl_unwhite(gp_handle h, const void* d_items, int count) {
+  if (count <= 0) return GP_OK;
+  hipLaunchKernelGGL(kl_unwhite_kernel, dim3(count), dim3(1024), 0, h->stream, (const KlUItem*)d_items);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+size_t klu_item_bytes() { return sizeof(KlUItem); }
+void klu_item_fill(void* host_item, const double* q_mu, const double* q_sqrt, const double* L, const double* W,
+                   const double* tr_part, int nrb, int M, double* out) {
+  KlUItem* k = (KlUItem*)host_item;
+  k->q_mu = q_mu; k->q_sqrt = q_sqrt; k->L = L; k->W = W; k->tr_part = tr_part; k->nrb = nrb; k->M = M; k->out = out;
+}
+
 // elbo = sum(lik partials) - sum(kl);  grad_noise = sum(noise partials)
 __global__ void __launch_bounds__(256) elbo_finish_kernel(const double* __restrict__ lik_partials, int nblocks,
                                                           const double* __restrict__ kl, int nkl,
@@ -284,6 +327,7 @@ __global__ void __launch_bounds__(256) elbo_finish_kernel(const double* __restri
     double k = 0.0;
     for (int g = 0; g < nkl; g++) k += kl[g];
     elbo[0] = red[0][0] - k;
+    elbo[1] = k;   // sum of the KL terms (Pdgp.build_prior_kl)
     if (g_noise) g_noise[0] = red[1][0];
   }
 }

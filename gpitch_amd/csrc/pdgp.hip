@@ -87,7 +87,7 @@ gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t*
 }
 
 static size_t pdgp_misc_bytes(const gp_pdgp_plan_s* p) {
-  return gp_align_up(p->G * kl_item_bytes(), 256) + 16 * gp_align_up(p->G * sizeof(GemmProblem), 256);
+  return pdgp_kl_region_bytes(p->G) + 16 * gp_align_up(p->G * sizeof(GemmProblem), 256);
 }
 
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
@@ -98,6 +98,8 @@ size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   for (int i = 0; i < 4; i++) addd((size_t)p->G * p->maxN);
   addd(p->G);
   addd(2 * ((size_t)(p->maxN + 255) / 256) + 8);
+  if (!p->whiten)
+    for (int g = 0; g < p->G; g++) addd((size_t)gemm_rowblocks(p->gps[g].M, 0) * p->gps[g].M);
   if (p->whiten) {
     d += pdgp_bwd_doubles(p);
     int ns = gemm_nt_nsplit(p->maxM, p->maxN, p->G);
@@ -133,6 +135,9 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
     if (!cond_task_carve(ar, t, p->maxN, p->whiten != 0)) return gp_fail(p->h, GP_ERR_WORKSPACE, "workspace carve failed");
   }
   p->bw.assign(p->G, BwdBufs());
+  p->tr_part.assign(p->G, nullptr);
+  if (!p->whiten)
+    for (int g = 0; g < p->G; g++) p->tr_part[g] = ar.take<double>((size_t)gemm_rowblocks(p->gps[g].M, 0) * p->gps[g].M);
   if (p->whiten) {
     p->nsplit = gemm_nt_nsplit(p->maxM, p->maxN, p->G);
     if (p->nsplit < 2) p->nsplit = 2;
@@ -189,10 +194,22 @@ static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x
   // KL items
   p->h_misc.assign(p->misc_bytes, 0);
   p->off_kl_items = 0;
+  const size_t kl_region = pdgp_kl_region_bytes(p->G);
   for (int g = 0; g < p->G; g++) {
     const PdgpGP& q = p->gps[g];
-    kl_item_fill(p->h_misc.data() + p->off_kl_items + g * kl_item_bytes(), params + q.off_qmu, params + q.off_qsqrt, q.M,
-                 p->kl + g, grad ? grad + q.off_qmu : nullptr, grad ? grad + q.off_qsqrt : nullptr);
+    const CondTask& t = p->cb.tasks[g];
+    if (p->whiten) {
+      kl_item_fill(p->h_misc.data() + p->off_kl_items + g * kl_item_bytes(), params + q.off_qmu, params + q.off_qsqrt,
+                   q.M, p->kl + g, grad ? grad + q.off_qmu : nullptr, grad ? grad + q.off_qsqrt : nullptr);
+    } else {
+      klu_item_fill(p->h_misc.data() + p->off_kl_items + g * klu_item_bytes(), params + q.off_qmu, params + q.off_qsqrt,
+                    t.L, t.W, p->tr_part[g], gemm_rowblocks(q.M, 0), q.M, p->kl + g);
+      // trace term: column sums of squares of W Lq (first problem slot after the KL items)
+      GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + kl_region + g * sizeof(GemmProblem));
+      memset(&r, 0, sizeof(r));
+      r.A = t.W; r.lda = q.M; r.B = params + q.off_qsqrt; r.ldb = q.M; r.M = q.M; r.N = q.M; r.K = q.M; r.ldc = q.M;
+      r.o0 = p->tr_part[g];
+    }
   }
   if (grad && p->whiten) GP_CHECK(pdgp_upload_bwd(p, params, x, n, grad));
   GP_HIP_CHECK(h, hipMemcpyAsync(p->d_misc, p->h_misc.data(), p->misc_bytes, hipMemcpyHostToDevice, h->stream));
@@ -219,7 +236,12 @@ gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, co
   if (p->whiten) {
     GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl_items, p->G));
   } else {
-    return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo: whiten=0 ELBO not implemented yet");
+    // gauss_kl(q_mu, q_sqrt, K = Kuu + jitter I) (pdgp.py:123-129): L and W of the conditional are reused
+    const size_t kl_region = pdgp_kl_region_bytes(p->G);
+    GemmFlags f;
+    f.triA = TRI_LOWER; f.triB = TRI_LOWER; f.epilogue = EPI_COLSUMSQ;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(p->d_misc + kl_region), p->G, p->maxM, p->maxM, f));
+    GP_CHECK(launch_kl_unwhite(h, p->d_misc + p->off_kl_items, p->G));
   }
   GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G, elbo_dev, grad ? grad : nullptr));
   if (grad) GP_CHECK(pdgp_backward(p, params, x, n, grad));

@@ -2,6 +2,11 @@
 #pragma once
 #include "engine.h"
 
+static inline size_t pdgp_kl_region_bytes(int G) {
+  const size_t a = kl_item_bytes(), b = klu_item_bytes();
+  return gp_align_up((size_t)G * (a > b ? a : b), 256);
+}
+
 struct PdgpGP {
   int M = 0, ktype = 0, m = 0;
   int need_theta = 1, need_z = 1;   // gp_pdgp_set_grad_needs
@@ -36,6 +41,7 @@ struct gp_pdgp_plan_s {
   void* ws = nullptr; size_t ws_bytes = 0;
   CondBatch cb;
   std::vector<BwdBufs> bw;
+  std::vector<double*> tr_part;    // unwhitened KL: column-sum partials of (W Lq)^2
   double* fmean = nullptr; double* fvar = nullptr;   // [G][maxN]
   double* gFmu = nullptr; double* gFvar = nullptr;   // [G][maxN]
   double* kl = nullptr;                              // [G]

@@ -135,7 +135,7 @@ class Pdgp(Parameterized):
         self._adam_m = h.zeros(n)
         self._adam_v = h.zeros(n)
         self._tcode = t.zeros(n, dtype=t.uint8, device=h.device)
-        self._elbo_dev = h.zeros(1)
+        self._elbo_dev = h.zeros(2)     # [ELBO, sum of KL terms]
         self._ws = h.workspace(h.lib.gp_pdgp_workspace_bytes(plan))
         h.check(h.lib.gp_pdgp_set_workspace(plan, self._ws.data_ptr(), self._ws.numel()))
         self._x_dev = h.to_device(self.x._array.reshape(-1))
@@ -203,7 +203,10 @@ class Pdgp(Parameterized):
         """compute KL divergences (pdgp.py:113-131)"""
         from .conditionals import gauss_kl
         if not self.whiten:
-            raise NotImplementedError("whiten=False prior KL is not implemented in this round")
+            # K = Kuu + jitter I (pdgp.py:126-129): evaluated by the engine next to the conditionals
+            self._pack()
+            self._elbo(False)
+            return float(self._elbo_dev[1].item())
         kl = 0.
         for i in range(self.num_sources):
             kl += gauss_kl(self.q_mu_act[i].value, self.q_sqrt_act[i].value)

@@ -158,8 +158,9 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes);
 gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, int32_t need_z);
 
 /* Pdgp.build_likelihood (pdgp.py:133-170) on the batch (x, y) of n frames:
- *   elbo = (num_data / n) * sum_n varexp_n - KL.   Writes the scalar to elbo_dev[0] (device) and, when
- * elbo_host != NULL, copies it to the host (syncs).  When grad != NULL also writes d elbo / d params
+ *   elbo = (num_data / n) * sum_n varexp_n - KL.   elbo_dev points to TWO device doubles: [0] the ELBO, [1] the
+ * summed KL term (Pdgp.build_prior_kl, pdgp.py:113-131).  When
+ * elbo_host != NULL the ELBO is also copied to the host (syncs).  When grad != NULL also writes d elbo / d params
  * (constrained space, layout above) — what TF reverse-mode provides through Model.optimize. */
 gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
                        double num_data, double* elbo_dev, double* elbo_host, double* grad);

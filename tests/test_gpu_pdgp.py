@@ -161,6 +161,16 @@ def test_hip_path_matches_committed_golden(gp_handle, name):
         fm, fv = conditional(prob["x"], prob["zc"][i], kern[1][i], prob["q_mu_com"][i], q_sqrt=prob["q_sqrt_com"][i], whiten=False)
         np.testing.assert_allclose(fm[:, 0], d["fmean_unwhite"][:, P + i], rtol=0, atol=1e-9 * np.abs(d["fmean_unwhite"]).max())
         np.testing.assert_allclose(fv[:, 0], d["fvar_unwhite"][:, P + i], rtol=0, atol=1e-9 * np.abs(d["fvar_unwhite"]).max())
+    # unwhitened model: ELBO and prior KL (pdgp.py:122-129) against the golden values
+    mu = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kernels_from_problem(prob), whiten=False, nlinfun=nl,
+              handle=gp_handle)
+    for i in range(P):
+        mu.q_mu_act[i].value = prob["q_mu_act"][i]; mu.q_mu_com[i].value = prob["q_mu_com"][i]
+        mu.q_sqrt_act[i].value = prob["q_sqrt_act"][i]; mu.q_sqrt_com[i].value = prob["q_sqrt_com"][i]
+    mu.likelihood.variance = prob["noise_var"]
+    gu = mu.compute_log_likelihood()
+    assert abs(gu - float(d["elbo_unwhite"])) <= 1e-9 * abs(float(d["elbo_unwhite"]))
+    assert abs(mu.build_prior_kl() - float(d["kl_unwhite"])) <= 1e-9 * abs(float(d["kl_unwhite"]))
 
 
 def test_gradient_with_fixed_params_skips_work_but_stays_exact(gp_handle):
@@ -186,3 +196,14 @@ def test_gradient_with_fixed_params_skips_work_but_stays_exact(gp_handle):
             rg = np.tril(rg[:, :, 0])[:, :, None]
         scale = max(np.abs(rg).max(), 1e-12)
         np.testing.assert_allclose(gg.reshape(rg.shape), rg, rtol=0, atol=2e-7 * scale, err_msg=name)
+
+
+@pytest.mark.parametrize("N,M,P,m", [(1500, 40, 2, 3)])
+def test_unwhitened_elbo_matches_oracle(gp_handle, N, M, P, m):
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(N, M, P, num_partials=m, seed=9)
+    model = pdgp_from_problem(prob, whiten=False, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    ref = float(oracle_elbo(prob, whiten=False))
+    # cond(Kuu) ~ 1e9 here (Matern32, l=1, 40 points in 94 ms): both sides carry ~cond*eps in the K^-1 terms
+    assert abs(got - ref) <= 1e-6 * abs(ref), (got, ref)
