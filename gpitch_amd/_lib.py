@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "gp_pdgp_set_workspace", "gp_pdgp_set_grad_needs", "gp_pdgp_elbo", "gp_pdgp_predict",
     "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace",
-    "gp_sgpr_bound", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
+    "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
 ]
 
@@ -116,6 +116,7 @@ def load_library():
         "gp_sgpr_workspace_bytes": (sz, [vp]),
         "gp_sgpr_set_workspace": (i32, [vp, vp, sz]),
         "gp_sgpr_bound": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl)]),
+        "gp_sgpr_bound_grad": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl), vp]),
         "gp_sgpr_predict_f": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
         "gp_sgpr_predict_source_workspace_bytes": (sz, [i32, i32]),
         "gp_sgpr_predict_source": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, sz]),

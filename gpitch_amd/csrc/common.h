@@ -94,6 +94,7 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
 size_t kernel_build_feat_ws_doubles(int m, int n1, int n2);
 int sm_mpad(int m);  // spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded)
 gp_status launch_kernel_diag(gp_handle h, DevKern k, int n, double* out, int accumulate);
+gp_status launch_sm_features(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2, double* feat_ws);
 
 // chol.hip
 gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,

@@ -247,6 +247,19 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
   return GP_OK;
 }
 
+// (re)build the spectral-mixture feature tables of kernel k for (x1, x2) without building a covariance
+gp_status launch_sm_features(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2, double* feat_ws) {
+  if (k.type != GP_KERN_MERCER_MATERN12SM) return GP_OK;
+  const int mp = sm_mpad(k.m);
+  double* f1 = feat_ws;
+  double* f2 = feat_ws + gp_align_up((size_t)2 * mp * n1, 32);
+  hipLaunchKernelGGL(sm_features_kernel, dim3((n1 + 255) / 256, mp), dim3(256), 0, h->stream, k, x1, n1, f1, mp);
+  if (x2 && x2 != x1)
+    hipLaunchKernelGGL(sm_features_kernel, dim3((n2 + 255) / 256, mp), dim3(256), 0, h->stream, k, x2, n2, f2, mp);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
 gp_status launch_kernel_diag(gp_handle h, DevKern k, int n, double* out, int accumulate) {
   if (n <= 0) return GP_OK;
   hipLaunchKernelGGL(cov_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, k, n, out, accumulate);

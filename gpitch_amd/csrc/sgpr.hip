@@ -20,7 +20,10 @@ struct gp_sgpr_plan_s {
   // workspace
   double *L = nullptr, *W = nullptr, *Kuf = nullptr, *A = nullptr, *H = nullptr, *LB = nullptr, *WB = nullptr;
   double *feat = nullptr, *s1 = nullptr, *s2 = nullptr, *dot = nullptr, *u = nullptr, *c = nullptr, *slabs = nullptr;
-  double *scal = nullptr;   // [0] bound, [1] sum err^2, [2] sum colsumsq(A'), [3] kdiag total per point, [4..] scratch
+  // backward
+  double *E2 = nullptr, *T1 = nullptr, *T2 = nullptr, *Wbar = nullptr, *R = nullptr, *Binv = nullptr, *G = nullptr;
+  double *ubar = nullptr, *Lu = nullptr, *alpha = nullptr, *ones = nullptr, *hyp = nullptr, *hyp_uu = nullptr;
+  double *scal = nullptr;   // [0] bound, [1] sum err^2, [2] sum colsumsq(A'), [3] kdiag total per point, [4] dF/dkd, [5] dF/ds
   char* d_desc = nullptr; std::vector<char> h_desc[2];   // two descriptor blocks (training pass / prediction pass)
   int nsplit = 2;
 };
@@ -149,6 +152,13 @@ static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   add((size_t)rb * p->maxN); add((size_t)rb * p->maxN); add((size_t)rb * p->maxN);
   add(M); add(M); add(64);
   add((size_t)p->nsplit * M * M);
+  for (int i = 0; i < 6; i++) add(M * M);            // E2, T1, T2, Wbar, R, Binv
+  add(M * ld); add(M); add(M); add(M); add(p->maxN);
+  {
+    const size_t ns = hyper_num_sums(p->maxm);
+    add(ns * ((p->maxN + 255) / 256 + 1) * ((M + 31) / 32 + 1));
+    add(ns * ((M + 255) / 256 + 1) * ((M + 31) / 32 + 1));
+  }
   return d;
 }
 
@@ -199,6 +209,15 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   p->dot = ar.take<double>((size_t)rb * p->maxN);
   p->u = ar.take<double>(M); p->c = ar.take<double>(M); p->scal = ar.take<double>(64);
   p->slabs = ar.take<double>((size_t)p->nsplit * M * M);
+  p->E2 = ar.take<double>(M * M); p->T1 = ar.take<double>(M * M); p->T2 = ar.take<double>(M * M);
+  p->Wbar = ar.take<double>(M * M); p->R = ar.take<double>(M * M); p->Binv = ar.take<double>(M * M);
+  p->G = ar.take<double>(M * ld); p->ubar = ar.take<double>(M); p->Lu = ar.take<double>(M); p->alpha = ar.take<double>(M);
+  p->ones = ar.take<double>(p->maxN);
+  {
+    const size_t ns = hyper_num_sums(p->maxm);
+    p->hyp = ar.take<double>(ns * ((p->maxN + 255) / 256 + 1) * ((M + 31) / 32 + 1));
+    p->hyp_uu = ar.take<double>(ns * ((M + 255) / 256 + 1) * ((M + 31) / 32 + 1));
+  }
   if (!ar.ok) return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: arena exhausted");
   p->ws = workspace; p->ws_bytes = bytes;
   return GP_OK;
@@ -214,8 +233,8 @@ static DevKern sg_kern(const gp_sgpr_plan_s* p, const double* params, int i) {
 struct SgDesc { GemmProblem* probs; int* toff; int* ktype; int* km; };
 static gp_status sg_upload(gp_sgpr_plan p, const std::vector<GemmProblem>& probs, SgDesc* out, int slot) {
   const size_t nb = probs.size() * sizeof(GemmProblem);
-  const size_t off_int = gp_align_up(8 * sizeof(GemmProblem), 256);
-  if (off_int + 3 * 256 * sizeof(int) > SG_DESC_BYTES || p->P > 256 || probs.size() > 8)
+  const size_t off_int = gp_align_up(20 * sizeof(GemmProblem), 256);
+  if (off_int + 3 * 256 * sizeof(int) > SG_DESC_BYTES || p->P > 256 || probs.size() > 20)
     return gp_fail(p->h, GP_ERR_UNSUPPORTED, "sgpr: too many kernels/problems for the descriptor block");
   std::vector<char>& hd = p->h_desc[slot];
   char* dd = p->d_desc + (size_t)slot * SG_DESC_BYTES;
@@ -267,6 +286,168 @@ static gp_status sgpr_common(gp_sgpr_plan p, const double* params, const double*
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
+
+// With ubar = WB^T c = Binv u / s:  Bbar = dF/dB = -1/2 Binv - 1/2 ubar ubar^T,  dF/du = ubar / s,
+// E2 = 2 dF/dH = (2/s) Bbar + I/s = (I - Binv - ubar ubar^T) / s          (see gp_sgpr_bound_grad)
+__global__ void __launch_bounds__(256) sgpr_E2_kernel(const double* __restrict__ Binv, const double* __restrict__ ubar,
+                                                      double* __restrict__ E2, int M, const double* __restrict__ s2) {
+  const double inv = 1.0 / s2[0];
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)M * M; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx / M), j = (int)(idx % M);
+    E2[idx] = inv * ((i == j ? 1.0 : 0.0) - Binv[idx] - ubar[i] * ubar[j]);
+  }
+}
+
+// noise-variance gradient and dF/dkd (one block):
+//   dF/ds = -tr(Bbar H)/s^2 - ubar.u/s^2 - tr(H)/(2 s^2) - N/(2s) + |y|^2/(2 s^2) + N kd/(2 s^2),
+//   tr(Bbar H) = -1/2 tr(Binv H) - 1/2 ubar^T H ubar ;   dF/dkd = -N/(2s)      (ubar = Binv u / s)
+__global__ void __launch_bounds__(256) sgpr_noise_grad_kernel(const double* __restrict__ Binv, const double* __restrict__ H,
+                                                              const double* __restrict__ ubar, const double* __restrict__ u,
+                                                              int M, int N, const double* __restrict__ s2,
+                                                              double* __restrict__ scal, double* __restrict__ g_noise) {
+  __shared__ double red[3][256];
+  double t_bh = 0.0, t_uhu = 0.0, t_uu = 0.0;
+  for (int64_t idx = threadIdx.x; idx < (int64_t)M * M; idx += 256) {
+    const int i = (int)(idx / M), j = (int)(idx % M);
+    const double h = H[idx];
+    t_bh = fma(Binv[idx], h, t_bh);
+    t_uhu = fma(ubar[i] * ubar[j], h, t_uhu);
+  }
+  for (int i = threadIdx.x; i < M; i += 256) t_uu = fma(ubar[i], u[i], t_uu);
+  red[0][threadIdx.x] = t_bh; red[1][threadIdx.x] = t_uhu; red[2][threadIdx.x] = t_uu;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) for (int q = 0; q < 3; q++) red[q][threadIdx.x] += red[q][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double s = s2[0];
+    const double trBH = -0.5 * red[0][0] - 0.5 * red[1][0];
+    const double trH = scal[2];   // sum colsumsq(A') = tr(H)
+    double g = -trBH / (s * s) - red[2][0] / (s * s) - 0.5 * trH / (s * s) - 0.5 * N / s + 0.5 * scal[1] / (s * s) +
+               0.5 * N * scal[3] / (s * s);
+    g_noise[0] = g;
+    scal[4] = -0.5 * N / s;
+    scal[5] = g;
+  }
+}
+
+// d(-1000 sum |v_p|)/dv_p
+__global__ void sgpr_reg_grad_kernel(const double* __restrict__ params, double* __restrict__ grad, const int* __restrict__ toff, int P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) { const double v = params[toff[p]]; grad[toff[p]] -= 1000.0 * (v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0)); }
+}
+
+// v[i] /= s[0]
+__global__ void __launch_bounds__(256) div_scalar_kernel(double* __restrict__ v, int n, const double* __restrict__ s) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] /= s[0];
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(double* __restrict__ v, int n, double x) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = x;
+}
+
+extern "C" {
+
+/* gradient of the collapsed bound w.r.t. [noise_var | theta_0 | ... ] (what TF autodiff hands to L-BFGS-B in
+ * SGPRSS.optimize: transcription.py:283, separation.py:298).  Z is a DataHolder (sgpr_ss.py:26): no gradient. */
+gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                             const double* Z, double* bound_dev, double* bound_host, double* grad) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_bound_grad: workspace not set");
+  if (!params || !X || !Y || !Z || !grad || N < 1 || N > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound_grad: bad argument");
+  for (int i = 0; i < p->P; i++)
+    if (p->ktype[i] == GP_KERN_MATERN12SM) return gp_fail(h, GP_ERR_UNSUPPORTED, "gradient of Matern12sm is not implemented");
+  SgDesc d;
+  GP_CHECK(sgpr_common(p, params, X, Y, N, Z, &d));
+  const int M = p->M;
+  const int64_t ld = ldN64(N);
+  GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
+  enum { Q_BINV = 0, Q_UBAR, Q_EH, Q_WBAR, Q_LU, Q_RANK1, Q_R, Q_ALPHA, Q_G, Q_T2, Q_LBAR, Q_P, Q_T3, Q_S, Q_COUNT };
+  std::vector<GemmProblem> pr(Q_COUNT);
+  memset(pr.data(), 0, pr.size() * sizeof(GemmProblem));
+  auto sq = [&](int q) -> GemmProblem& { GemmProblem& r = pr[q]; r.M = M; r.N = M; r.K = M; r.lda = M; r.ldb = M; r.ldc = M; return r; };
+  { GemmProblem& r = sq(Q_BINV); r.A = p->WB; r.B = p->WB; r.C = p->Binv; }
+  { GemmProblem& r = sq(Q_UBAR); r.A = p->WB; r.v0 = p->c; r.o0 = p->ubar; }
+  { GemmProblem& r = sq(Q_EH); r.A = p->E2; r.B = p->H; r.C = p->T1; }
+  { GemmProblem& r = sq(Q_WBAR); r.A = p->T1; r.B = p->L; r.C = p->Wbar; }
+  { GemmProblem& r = sq(Q_LU); r.A = p->L; r.v0 = p->u; r.o0 = p->Lu; }
+  { GemmProblem& r = sq(Q_RANK1); r.C = p->Wbar; r.v0 = p->ubar; r.v1 = p->Lu; }
+  { GemmProblem& r = sq(Q_R); r.A = p->W; r.B = p->E2; r.C = p->R; }
+  { GemmProblem& r = sq(Q_ALPHA); r.A = p->W; r.v0 = p->ubar; r.o0 = p->alpha; }
+  { GemmProblem& r = sq(Q_G); r.A = p->R; r.B = p->A; r.ldb = ld; r.N = N; r.v1 = p->ones; r.C = p->G; r.ldc = ld; }
+  { GemmProblem& r = sq(Q_T2); r.A = p->W; r.B = p->Wbar; r.C = p->T2; }
+  { GemmProblem& r = sq(Q_LBAR); r.A = p->T2; r.B = p->W; r.C = p->T1; }
+  { GemmProblem& r = sq(Q_P); r.A = p->L; r.B = p->T1; r.C = p->T2; }
+  { GemmProblem& r = sq(Q_T3); r.A = p->W; r.B = p->T2; r.C = p->H; }     // H is free once E2 H and the noise terms are done
+  { GemmProblem& r = sq(Q_S); r.A = p->H; r.B = p->W; r.C = p->E2; }
+  SgDesc d2;
+  GP_CHECK(sg_upload(p, pr, &d2, 1));
+  GemmProblem* D = d2.probs;
+  GemmFlags f;
+  // Binv = WB^T WB ; ubar = WB^T c (= Binv u / s)
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D + Q_BINV, 1, M, M, f));
+  GP_CHECK(launch_matvec_batched(h, D + Q_UBAR, 1, M, 1));
+  hipLaunchKernelGGL(sgpr_E2_kernel, dim3(64), dim3(256), 0, h->stream, p->Binv, p->ubar, p->E2, M, params);
+  hipLaunchKernelGGL(sgpr_noise_grad_kernel, dim3(1), dim3(256), 0, h->stream, p->Binv, p->H, p->ubar, p->u, M, N, params,
+                     p->scal, grad);
+  // from here on ubar holds dF/du = ubar / s
+  hipLaunchKernelGGL(div_scalar_kernel, dim3((M + 255) / 256), dim3(256), 0, h->stream, p->ubar, M, params);
+  // Wbar = tril(E2 H L^T + ubar (L u)^T)
+  f = GemmFlags();
+  GP_CHECK(launch_gemm_batched(h, D + Q_EH, 1, M, M, f));
+  f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D + Q_WBAR, 1, M, M, f));
+  GP_CHECK(launch_matvec_batched(h, D + Q_LU, 1, M, 0));
+  GP_CHECK(launch_rank1_tril_batched(h, D + Q_RANK1, 1, M));
+  // R = W^T E2 ; alpha = W^T ubar ; Kuf_bar = R A' + alpha y^T
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
+  GP_CHECK(launch_gemm_batched(h, D + Q_R, 1, M, M, f));
+  GP_CHECK(launch_matvec_batched(h, D + Q_ALPHA, 1, M, 1));
+  hipLaunchKernelGGL(fill_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, p->ones, N, 1.0);
+  f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
+  GP_CHECK(launch_gemm_batched(h, D + Q_G, 1, M, N, f));
+  // Kuu side (same Cholesky-adjoint chain as the Pdgp backward)
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D + Q_T2, 1, M, M, f));
+  f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
+  GP_CHECK(launch_gemm_batched(h, D + Q_LBAR, 1, M, M, f));
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D + Q_P, 1, M, M, f));
+  GP_CHECK(launch_phi_batched(h, D + Q_P, 1, M));
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D + Q_T3, 1, M, M, f));
+  f = GemmFlags(); f.triB = TRI_LOWER;
+  GP_CHECK(launch_gemm_batched(h, D + Q_S, 1, M, M, f));
+  // every kernel of the sum sees the same Kuf_bar / Kuu_bar (K = sum_p K_p)
+  for (int i = 0; i < p->P; i++) {
+    DevKern k = sg_kern(p, params, i);
+    // the feature tables hold the LAST kernel built: rebuild this kernel's (Z and X) before contracting
+    if (k.type == GP_KERN_MERCER_MATERN12SM) {
+      // cheap: two feature passes; the covariance values themselves are not needed again
+      GP_CHECK(launch_sm_features(h, k, Z, M, X, N, p->feat));
+    }
+    int np_uf = 0, np_uu = 0;
+    GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, p->feat, p->hyp, &np_uf, nullptr));
+    GP_CHECK(launch_hyper_finish(h, k, p->hyp, np_uf, p->scal + 4, grad + p->off_theta[i], nullptr, 0, M, nullptr));
+    GP_CHECK(launch_hyper_contract(h, k, Z, M, Z, M, p->E2, M, nullptr, nullptr, 1, p->feat, p->hyp_uu, &np_uu, nullptr));
+    GP_CHECK(launch_hyper_finish(h, k, p->hyp_uu, np_uu, nullptr, grad + p->off_theta[i], nullptr, 0, M, nullptr));
+  }
+  if (p->reg) hipLaunchKernelGGL(sgpr_reg_grad_kernel, dim3(1), dim3(256), 0, h->stream, params, grad, d.toff, p->P);
+  GP_HIP_CHECK(h, hipGetLastError());
+  if (bound_dev) GP_HIP_CHECK(h, hipMemcpyAsync(bound_dev, p->scal, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (bound_host) {
+    GP_HIP_CHECK(h, hipMemcpyAsync(bound_host, p->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return check_not_pd(h);
+  }
+  return GP_OK;
+}
+
+}  // extern "C"
 
 extern "C" {
 

@@ -137,9 +137,46 @@ class SGPRSS(Parameterized):
         """sgpr_ss.py:108-114"""
         return self.build_predict_source(Xnew)
 
-    def optimize(self, *a, **kw):
-        raise NotImplementedError("SGPRSS.optimize (L-BFGS-B on the bound) needs the bound's gradient, which lands "
-                                  "after the forward path (SURVEY §8f rank 3)")
+    # ---- training: GPflow Model.optimize -> scipy L-BFGS-B on the free state (transcription.py:283) ----
+    def _param_list(self):
+        ps = [self.likelihood.variance]
+        for k in self.kern.kern_list:
+            ps.extend(k.theta_params())
+        return ps
+
+    def _objective(self, x_free):
+        """(-(bound), -d bound / d free-state) — GPflow Model._objective"""
+        h = self._handle
+        ps = self._param_list()
+        free_idx = [i for i, p in enumerate(ps) if not p.fixed]
+        vals = np.array([p.value[0] for p in ps])
+        for j, i in enumerate(free_idx):
+            vals[i] = ps[i].transform.forward(np.array([x_free[j]]))[0]
+        self._params = h.to_device(vals)
+        grad = h.zeros(self._nparams)
+        out = C.c_double()
+        h.check(h.lib.gp_sgpr_bound_grad(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
+                                         self.X.shape[0], self._Zd.data_ptr(), self._bound_dev.data_ptr(), C.byref(out),
+                                         grad.data_ptr()))
+        g = grad.cpu().numpy()
+        gf = np.empty(len(free_idx))
+        for j, i in enumerate(free_idx):
+            dydx = 1. / (1. + np.exp(-x_free[j])) if ps[i].transform.code == 1 else 1.
+            gf[j] = g[i] * dydx
+        return -out.value, -gf
+
+    def optimize(self, method='L-BFGS-B', tol=None, callback=None, maxiter=1000, disp=False, **kw):
+        from scipy.optimize import minimize
+        self._compile()
+        self._pack()
+        ps = self._param_list()
+        free_idx = [i for i, p in enumerate(ps) if not p.fixed]
+        x0 = np.array([ps[i].transform.backward(ps[i].value)[0] for i in free_idx])
+        res = minimize(self._objective, x0, jac=True, method=method, tol=tol, callback=callback,
+                       options=dict(maxiter=maxiter, disp=disp))
+        for j, i in enumerate(free_idx):
+            ps[i].value = ps[i].transform.forward(np.array([res.x[j]]))
+        return res
 
     def _destroy(self):
         if self._plan is not None and self._handle is not None and self._handle.h:

@@ -203,6 +203,10 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes);
 /* SGPRSS.build_likelihood (sgpr_ss.py:29-71), D = 1 output column.  bound_host may be NULL. */
 gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                         const double* Z, double* bound_dev, double* bound_host);
+/* The bound and its gradient w.r.t. the parameter vector (what TF autodiff gives L-BFGS-B in SGPRSS.optimize:
+ * transcription.py:283, separation.py:298).  grad has gp_sgpr_num_params entries. */
+gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                             const double* Z, double* bound_dev, double* bound_host, double* grad);
 /* GPflow SGPR.build_predict (predict_f; separation.py:306) at Xnew: mean, var (n values each) */
 gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                             const double* Z, const double* Xnew, int32_t n, double* mean, double* var);

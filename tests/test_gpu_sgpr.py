@@ -87,3 +87,48 @@ def test_sgpr_window_swap(gp_handle):
     b1 = m.build_likelihood()
     ref = orc.sgpr_bound(X2, 20. * Y2, Z2, kl, 1.0)
     assert abs(b1 - ref) <= 1e-9 * abs(ref) and b0 != b1
+
+
+def _torch_bound_and_grads(X, Y, Z, kl, noise, reg=False):
+    import torch
+    from oracle.backend import TorchBackend
+    tb = TorchBackend()
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=True)
+    nv = T(noise)
+    leaves = [nv]
+    tk = []
+    for d in kl:
+        o = dict(d)
+        o["variance"] = T(d["variance"]); o["lengthscales"] = T(d["lengthscales"])
+        o["energy"] = [T(e) for e in d["energy"]]; o["frequency"] = [T(f) for f in d["frequency"]]
+        leaves += [o["variance"], o["lengthscales"]] + o["energy"] + o["frequency"]
+        tk.append(o)
+    b = orc.sgpr_bound(torch.tensor(X), torch.tensor(Y), torch.tensor(Z), tk, nv, reg=reg, xp=tb)
+    b.backward()
+    return float(b.detach()), np.array([float(l.grad) for l in leaves])
+
+
+@pytest.mark.parametrize("N,M,P,reg", [(300, 16, 1, False), (1200, 48, 3, True)])
+def test_sgpr_gradient_matches_autograd(gp_handle, N, M, P, reg):
+    X, Y, Z, kl = _problem(N, M, P, N + 1)
+    m = _model(X, Y, Z, kl, 0.3, gp_handle, reg=reg)
+    m._compile(); m._pack()
+    ps = m._param_list()
+    x0 = np.array([p.transform.backward(p.value)[0] for p in ps])
+    f, gfree = m._objective(x0)
+    ref_b, ref_g = _torch_bound_and_grads(X, Y, Z, kl, 0.3, reg=reg)
+    assert abs(-f - ref_b) <= 1e-9 * abs(ref_b)
+    got = -gfree * (1. + np.exp(-x0))        # undo the positive-transform chain rule: d/d constrained
+    np.testing.assert_allclose(got, ref_g, rtol=0, atol=2e-7 * np.abs(ref_g).max())
+
+
+def test_sgpr_optimize_increases_bound(gp_handle):
+    X, Y, Z, kl = _problem(800, 32, 2, 11)
+    m = _model(X, Y, Z, kl, 1.0, gp_handle)
+    for k in m.kern.kern_list:            # as the reference's component kernels: lengthscale fixed, rest free
+        k.lengthscales.fixed = True
+    b0 = m.build_likelihood()
+    res = m.optimize(maxiter=15)
+    b1 = m.build_likelihood()
+    assert b1 > b0 and np.isfinite(res.fun) and abs(-res.fun - b1) <= 1e-8 * abs(b1)
+    assert m.kern.kern_list[0].lengthscales.value[0] == kl[0]["lengthscales"]
