@@ -12,4 +12,5 @@ from .methods import (logistic, ilogistic, softplus, isoftplus, gaussfun, logist
                       gaussfun_tf, midi2freq, freq2midi, norm)
 from . import param, kernels, matern12_spectral_mixture, likelihoods, conditionals, pdgp, sgpr_ss, synth, train  # noqa: E402,F401
 from .init_models import init_liv, init_iv  # noqa: E402,F401
+from .window_overlap import segmented, windowed, merged_mean, merged_variance  # noqa: E402,F401
 from .init_kernels import init_kern_act, init_kern_com, init_kern  # noqa: E402,F401

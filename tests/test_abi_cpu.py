@@ -101,3 +101,25 @@ def test_nonlinearity_tokens():
     np.testing.assert_allclose(gpitch_amd.logistic_tf(np.array([np.pi])), [0.5])
     with pytest.raises(TypeError):
         gpitch_amd.methods.nlin_code(np.tanh)
+
+
+def test_windowing_and_overlap_add():
+    import gpitch_amd
+    from gpitch_amd import window_overlap as wo
+    n, ws = 10001, 2001
+    x = np.linspace(0, 1, n).reshape(-1, 1)
+    y = np.sin(40 * x)
+    xw, yw = wo.windowed(x, y, ws)
+    l = (ws - 1) // 2
+    assert len(xw) == (n - ws) // l + 1 and all(w.shape == (ws, 1) for w in xw)
+    assert np.array_equal(xw[1][:l + 1], xw[0][l:])                       # 50 % overlap
+    # Hann windows at 50 % overlap sum to one: overlap-add of the windows themselves returns the signal
+    merged = wo.merged_mean(yw, ws, n)
+    np.testing.assert_allclose(merged, y, atol=1e-12)
+    np.testing.assert_allclose(wo.merged_x(xw, ws), x, atol=1e-12)
+    v = wo.merged_variance([np.ones((ws, 1)) for _ in yw], ws, n)
+    assert v.min() >= 0.5 - 1e-12 and v.max() <= 1 + 1e-12
+    xs, ys = gpitch_amd.segmented(x, y, window_size=3000)
+    assert len(xs) == 3 and ys[2].shape == (3000, 1)
+    xa, ya = wo.segmented(x, y, window_size=3000, aug=True)
+    assert ya[0].shape == (3000 + 3200, 1) and ya[0][:1600].max() == 0
