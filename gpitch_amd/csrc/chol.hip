@@ -5,11 +5,12 @@
 //
 // One workgroup (8 wavefronts, two per SIMD) per matrix, many matrices per launch (one per latent GP).
 // Right-looking blocked factorisation, panel width 32:
-//   * the 32 x 32 diagonal block is factorised by ONE wavefront entirely in registers — lane i holds
-//     row i, pivots/columns are broadcast with v_readlane (no LDS round trips, no barriers);
-//   * the panel below is solved one row per lane against the factor held in LDS (broadcast reads);
-//   * the trailing SYRK update runs on the matrix cores (v_mfma_f64_16x16x4_f64), 16 x 16 tiles
-//     dealt round-robin to the 8 wavefronts, lower triangle only.
+//   * the 32 x 32 diagonal block is factorised (and inverted) by ONE wavefront entirely in registers — lane i
+//     holds row i, pivots/columns are broadcast with v_readlane (no LDS round trips, no barriers);
+//   * the panel below is X = A_panel L_kk^-T on the matrix cores against the inverse held in LDS;
+//   * the trailing SYRK update runs on the matrix cores (v_mfma_f64_16x16x4_f64) in 32 x 32 macro tiles (four
+//     independent accumulators) drawn from an LDS work counter; the wavefront that draws the next diagonal
+//     block factorises it immediately (look-ahead), hiding the serial factorisation behind the update.
 // The inverse W = L^-1 inverts the diagonal blocks in registers the same way, then each wavefront
 // walks one block column with MFMA products; a 16x16 f64 accumulator register r is exactly the
 // B-fragment of k-step r, so the chained product -W_ii * (sum_k L_ik W_kj) needs no data movement.
@@ -28,123 +29,168 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Factor the 32 x 32 diagonal block at (k0, k0) entirely in the registers of ONE wavefront (lane i holds row i;
+// pivots / columns are broadcast with v_readlane), write L_kk to global and its inverse to Dinv (LDS).
+__device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t ld, int M, int k0, int lane,
+                                                double (*Dinv)[CH_NB + 1], int* __restrict__ status, int b) {
+  const int nb = min(CH_NB, M - k0);
+  double row[CH_NB];
+  const int i = lane & 31;
+#pragma unroll
+  for (int c = 0; c < CH_NB; c++)
+    row[c] = (i < nb && c <= i) ? A[(int64_t)(k0 + i) * ld + k0 + c] : (i == c ? 1.0 : 0.0);
+#pragma unroll
+  for (int j = 0; j < CH_NB; j++) {
+    double djj = lane_bcast(row[j], j);
+    if (!(djj > 0.0)) {  // non-positive or NaN pivot: report the first one, keep going finite
+      if (lane == 0 && j < nb) {
+        if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = k0 + j; status[2] = b; }
+      }
+      djj = 1.0;
+    }
+    double s = __dsqrt_rn(djj);
+    double lij = (i > j) ? row[j] / s : (i == j ? s : 0.0);
+    row[j] = lij;
+#pragma unroll
+    for (int c = j + 1; c < CH_NB; c++) {
+      double lcj = lane_bcast(lij, c);
+      row[c] = fma(-lij, lcj, row[c]);  // meaningful for i >= c only
+    }
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++)
+      if (i < nb && c <= i) A[(int64_t)(k0 + i) * ld + k0 + c] = row[c];
+  }
+  // inverse of the diagonal factor, column c in lane c: x[r] = (L_kk^-1)[r][c]
+  double x[CH_NB];
+#pragma unroll
+  for (int r = 0; r < CH_NB; r++) {
+    double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < r; t++) acc = fma(-lane_bcast(row[t], r), x[t], acc);
+    x[r] = acc / lane_bcast(row[r], r);
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int r = 0; r < CH_NB; r++) Dinv[r][i] = x[r];
+  }
+}
+
 __global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,
                                                           const int* __restrict__ lds_, int* __restrict__ status,
-                                                          double* single_mat, int single_M, int single_ld) {
+                                                          double* single_mat, int single_M, int single_ld, int panel_rows_cap) {
   const int b = blockIdx.x;
   double* A = mats ? mats[b] : single_mat;
   const int M = mats ? Ms[b] : single_M;
   const int64_t ld = mats ? lds_[b] : single_ld;
-  __shared__ double D[CH_NB][CH_NB + 1];
+  extern __shared__ __attribute__((aligned(16))) double chol_smem[];
+  // [ D: 2 x 32 x 33 (inverse of the current / next diagonal factor) | P: panel X, (M-32) x 33 when it fits ]
+  double (*D)[CH_NB][CH_NB + 1] = reinterpret_cast<double (*)[CH_NB][CH_NB + 1]>(chol_smem);
+  double* P = chol_smem + 2 * CH_NB * (CH_NB + 1);
+  __shared__ int tile_counter;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kq = lane >> 4, lc = lane & 15;
+  const bool p_lds = (panel_rows_cap >= M - CH_NB);   // operands of the trailing update come from LDS
 
-  for (int k0 = 0; k0 < M; k0 += CH_NB) {
+  if (wave == 0) chol_diag_block(A, ld, M, 0, lane, D[0], status, b);
+  __syncthreads();
+
+  int pb = 0;
+  for (int k0 = 0; k0 < M; k0 += CH_NB, pb ^= 1) {
     const int nb = min(CH_NB, M - k0);
-    // ---- diagonal block: one wavefront, rows in registers --------------------------------------
-    if (wave == 0) {
-      double row[CH_NB];
-      const int i = lane & 31;
-#pragma unroll
-      for (int c = 0; c < CH_NB; c++)
-        row[c] = (i < nb && c <= i) ? A[(int64_t)(k0 + i) * ld + k0 + c] : (i == c ? 1.0 : 0.0);
-#pragma unroll
-      for (int j = 0; j < CH_NB; j++) {
-        double djj = lane_bcast(row[j], j);
-        if (!(djj > 0.0)) {  // non-positive or NaN pivot: report the first one, keep going finite
-          if (lane == 0 && j < nb) {
-            if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = k0 + j; status[2] = b; }
-          }
-          djj = 1.0;
-        }
-        double s = __dsqrt_rn(djj);
-        double lij = (i > j) ? row[j] / s : (i == j ? s : 0.0);
-        row[j] = lij;
-#pragma unroll
-        for (int c = j + 1; c < CH_NB; c++) {
-          double lcj = lane_bcast(lij, c);
-          row[c] = fma(-lij, lcj, row[c]);  // meaningful for i >= c only
-        }
-      }
-      if (lane < 32) {
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++)
-          if (i < nb && c <= i) A[(int64_t)(k0 + i) * ld + k0 + c] = row[c];
-      }
-      // inverse of the diagonal factor, column c in lane c: x[r] = (L_kk^-1)[r][c]
-      double x[CH_NB];
-#pragma unroll
-      for (int r = 0; r < CH_NB; r++) {
-        double acc = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-        for (int t = 0; t < r; t++) acc = fma(-lane_bcast(row[t], r), x[t], acc);
-        x[r] = acc / lane_bcast(row[r], r);
-      }
-      if (lane < 32) {
-#pragma unroll
-        for (int r = 0; r < CH_NB; r++) D[r][i] = x[r];
-      }
-    }
-    __syncthreads();
     const int r0 = k0 + nb;  // first trailing row
     const int R = M - r0;
     if (R <= 0) break;
     // ---- panel: X = A_panel * L_kk^-T on the matrix cores, 16 rows per wavefront step ----------
-    {
-      const int kq = lane >> 4, lc = lane & 15;
-      for (int rg = wave; rg * 16 < R; rg += CH_WAVES) {
-        const int ra = r0 + rg * 16 + lc;
-        double af[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
-          const int kc = kk * 4 + kq;
-          af[kk] = (ra < M && kc < nb) ? A[(int64_t)ra * ld + k0 + kc] : 0.0;
-        }
-        d4 o[2];
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-          o[tj] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int kk = 0; kk < 8; kk++)  // B[k][j] = (L_kk^-1)[j][k]
-            o[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], D[tj * 16 + lc][kk * 4 + kq], o[tj], 0, 0, 0);
-        }
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int rw = r0 + rg * 16 + kq + 4 * r, cw = tj * 16 + lc;
-            if (rw < M && cw < nb) A[(int64_t)rw * ld + k0 + cw] = o[tj][r];
-          }
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // ---- trailing update (lower triangle): A22 -= X X^T on the matrix cores --------------------
-    const int nt = (R + 15) >> 4;
-    const int ntiles = nt * (nt + 1) / 2;
-    for (int t = wave; t < ntiles; t += CH_WAVES) {
-      // linear index -> (ti >= tj)
-      int ti = (int)((__dsqrt_rn(8.0 * t + 1.0) - 1.0) * 0.5);
-      while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-      while (ti * (ti + 1) / 2 > t) ti--;
-      const int tj = t - ti * (ti + 1) / 2;
-      const int ra = r0 + ti * 16 + (lane & 15);
-      const int rb = r0 + tj * 16 + (lane & 15);
-      const int kq = lane >> 4;
-      double af[8], bf[8];
+    for (int rg = wave; rg * 16 < R; rg += CH_WAVES) {
+      const int ra = r0 + rg * 16 + lc;
+      double af[8];
 #pragma unroll
       for (int kk = 0; kk < 8; kk++) {
         const int kc = kk * 4 + kq;
         af[kk] = (ra < M && kc < nb) ? A[(int64_t)ra * ld + k0 + kc] : 0.0;
-        bf[kk] = (rb < M && kc < nb) ? A[(int64_t)rb * ld + k0 + kc] : 0.0;
       }
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      d4 o[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-      for (int kk = 0; kk < 8; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], acc, 0, 0, 0);
-      const int cc = r0 + tj * 16 + (lane & 15);
+      for (int kk = 0; kk < 8; kk++) {  // B[k][j] = (L_kk^-1)[j][k]; two independent accumulators
+        o[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], D[pb][lc][kk * 4 + kq], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], D[pb][16 + lc][kk * 4 + kq], o[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int rw = r0 + rg * 16 + kq + 4 * r, cw = tj * 16 + lc;
+          if (rw < M && cw < nb) A[(int64_t)rw * ld + k0 + cw] = o[tj][r];
+          if (p_lds && rw < M) P[(rw - r0) * (CH_NB + 1) + cw] = (cw < nb) ? o[tj][r] : 0.0;
+        }
+    }
+    if (tid == 0) tile_counter = 0;
+    __threadfence_block();
+    __syncthreads();
+    // ---- trailing update A22 -= X X^T (lower triangle), 32 x 32 macro tiles handed out dynamically.  Macro tile
+    //      0 is the NEXT diagonal block: the wavefront that draws it factorises that block straight away
+    //      (look-ahead), overlapping the serial 32-column factorisation with the other waves' updates.
+    const int nmt = (R + 31) >> 5;
+    const int total = nmt * (nmt + 1) / 2;
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&tile_counter, 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= total) break;
+      int mi = (int)((__dsqrt_rn(8.0 * t + 1.0) - 1.0) * 0.5);
+      while ((mi + 1) * (mi + 2) / 2 <= t) mi++;
+      while (mi * (mi + 1) / 2 > t) mi--;
+      const int mj = t - mi * (mi + 1) / 2;
+      const int rbase = r0 + mi * 32, cbase = r0 + mj * 32;
+      double af0[8], af1[8], bf0[8], bf1[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        const int kc = kk * 4 + kq;
+        const bool kin = kc < nb;
+        const int ra0 = rbase + lc, ra1 = rbase + 16 + lc, rb0 = cbase + lc, rb1 = cbase + 16 + lc;
+        if (p_lds) {   // rows >= M were never written: guard; columns >= nb hold zeros
+          af0[kk] = (ra0 < M) ? P[(ra0 - r0) * (CH_NB + 1) + kc] : 0.0;
+          af1[kk] = (ra1 < M) ? P[(ra1 - r0) * (CH_NB + 1) + kc] : 0.0;
+          bf0[kk] = (rb0 < M) ? P[(rb0 - r0) * (CH_NB + 1) + kc] : 0.0;
+          bf1[kk] = (rb1 < M) ? P[(rb1 - r0) * (CH_NB + 1) + kc] : 0.0;
+        } else {
+          af0[kk] = (kin && ra0 < M) ? A[(int64_t)ra0 * ld + k0 + kc] : 0.0;
+          af1[kk] = (kin && ra1 < M) ? A[(int64_t)ra1 * ld + k0 + kc] : 0.0;
+          bf0[kk] = (kin && rb0 < M) ? A[(int64_t)rb0 * ld + k0 + kc] : 0.0;
+          bf1[kk] = (kin && rb1 < M) ? A[(int64_t)rb1 * ld + k0 + kc] : 0.0;
+        }
+      }
+      // C tile: issue the loads now, consume them after the MFMAs
+      double cold[4][4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int rw = r0 + ti * 16 + (lane >> 4) + 4 * r;
-        if (rw < M && cc < M && cc <= rw) A[(int64_t)rw * ld + cc] -= acc[r];
+        const int rw0 = rbase + kq + 4 * r, rw1 = rw0 + 16, cw0 = cbase + lc, cw1 = cw0 + 16;
+        cold[0][r] = (rw0 < M && cw0 <= rw0) ? A[(int64_t)rw0 * ld + cw0] : 0.0;
+        cold[1][r] = (rw0 < M && cw1 <= rw0) ? A[(int64_t)rw0 * ld + cw1] : 0.0;
+        cold[2][r] = (rw1 < M && cw0 <= rw1) ? A[(int64_t)rw1 * ld + cw0] : 0.0;
+        cold[3][r] = (rw1 < M && cw1 <= rw1) ? A[(int64_t)rw1 * ld + cw1] : 0.0;
+      }
+      d4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf0[kk], c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf1[kk], c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf0[kk], c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf1[kk], c11, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rw0 = rbase + kq + 4 * r, rw1 = rw0 + 16, cw0 = cbase + lc, cw1 = cw0 + 16;
+        if (rw0 < M && cw0 <= rw0) A[(int64_t)rw0 * ld + cw0] = cold[0][r] - c00[r];
+        if (rw0 < M && cw1 <= rw0) A[(int64_t)rw0 * ld + cw1] = cold[1][r] - c01[r];
+        if (rw1 < M && cw0 <= rw1) A[(int64_t)rw1 * ld + cw0] = cold[2][r] - c10[r];
+        if (rw1 < M && cw1 <= rw1) A[(int64_t)rw1 * ld + cw1] = cold[3][r] - c11[r];
+      }
+      if (t == 0) {
+        __threadfence_block();  // this wave's own updates of the block it is about to read back
+        chol_diag_block(A, ld, M, r0, lane, D[pb ^ 1], status, b);
       }
     }
     __threadfence_block();
@@ -269,13 +315,35 @@ __global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* c
   }
 }
 
+// dynamic LDS: the two 32 x 33 inverse blocks plus, when it fits in 150 KiB, the whole panel below the first
+// diagonal block ((maxM - 32) rows x 33 doubles).  *cap = rows the panel buffer can hold (0 = operands from global).
+static size_t chol_smem_bytes(int maxM, int* cap) {
+  const size_t dbytes = (size_t)2 * CH_NB * (CH_NB + 1) * sizeof(double);
+  const int rows = maxM > CH_NB ? maxM - CH_NB : 0;
+  const size_t pbytes = (size_t)rows * (CH_NB + 1) * sizeof(double);
+  if (dbytes + pbytes <= 150 * 1024) { *cap = rows; return dbytes + pbytes; }
+  *cap = 0;
+  return dbytes;
+}
+static gp_status chol_set_attr(gp_handle h) {
+  static bool done = false;
+  if (!done) {
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    done = true;
+  }
+  return GP_OK;
+}
+
 gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
                                   int maxM) {
   (void)maxM;
   if (batch <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_CHOL);
-  hipLaunchKernelGGL(chol_kernel, dim3(batch), dim3(CH_THREADS), 0, h->stream, d_mats, d_M, d_ld, h->d_status,
-                     (double*)nullptr, 0, 0);
+  int cap = 0;
+  size_t sh = chol_smem_bytes(maxM, &cap);
+  GP_CHECK(chol_set_attr(h));
+  hipLaunchKernelGGL(chol_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_M, d_ld, h->d_status,
+                     (double*)nullptr, 0, 0, cap);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -283,8 +351,11 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
 gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld) {
   if (M <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_CHOL);
-  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(CH_THREADS), 0, h->stream, (double* const*)nullptr,
-                     (const int*)nullptr, (const int*)nullptr, h->d_status, A, M, (int)ld);
+  int cap = 0;
+  size_t sh = chol_smem_bytes(M, &cap);
+  GP_CHECK(chol_set_attr(h));
+  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(CH_THREADS), sh, h->stream, (double* const*)nullptr,
+                     (const int*)nullptr, (const int*)nullptr, h->d_status, A, M, (int)ld, cap);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
