@@ -169,8 +169,14 @@ def main():
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         sym = {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
                "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"}
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (tools/make_traffic_json.py); null if absent
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["kernels"]
+            traffic = tj[sym[dom].replace(" ", "")]["hbm_bytes"] if (N, M, args.P) == (32768, 512, 12) else None
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None, "kernel": sym[dom],
+                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "kernel": sym[dom],
                 "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": alg[dom]}
         kuf = {}
         for name, mm in (("kuf_build", 0), ("kuf_build_sm", args.partials)):
