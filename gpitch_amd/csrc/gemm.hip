@@ -85,11 +85,15 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
   int bid = blockIdx.x;
   int tm, tn, ksl = 0;
   if (f.ksplit > 1) {
-    // split-K: consecutive workgroups take consecutive K-slices of one output tile; with a symmetric
-    // (lower) output only the tilesM(tilesM+1)/2 tiles on or below the diagonal are enumerated, so every
-    // launched workgroup has work (no statically idle XCD / shader engine).
-    ksl = bid % f.ksplit;
-    const int t = bid / f.ksplit;
+    // split-K.  With a symmetric (lower) output only the tilesM(tilesM+1)/2 tiles on or below the diagonal are
+    // enumerated, so every launched workgroup has work.  Order: XCD-contiguous ranges, and inside a range the
+    // OUTPUT TILE varies fastest, so the workgroups resident together on one XCD work on the same K-slice of
+    // different tiles and share its operand strips in that XCD's L2 (each strip is used by tilesM+1 tiles).
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ntl = (f.triC == TRI_LOWER) ? f.tilesM * (f.tilesM + 1) / 2 : f.tilesM * f.tilesN;
+    ksl = bid / ntl;
+    const int t = bid % ntl;
     if (f.triC == TRI_LOWER) {
       tm = (int)((__dsqrt_rn(8.0 * t + 1.0) - 1.0) * 0.5);
       while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
@@ -130,6 +134,18 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WAVES_N, wc = wave % WAVES_N;
   const int lc = lane & 15, kq = lane >> 4;
+  // Column tiles (16 wide) owned by this wave.  The symmetric split-K product (TAG 4) pairs tile wc with tile
+  // 7 - wc: on a diagonal output tile only the MFMA tiles with row-tile >= column-tile are needed, and this
+  // pairing gives every wave the same number of them (9 of 16), so the skip costs no barrier imbalance.
+  constexpr bool PERM = (TAG == 4 && TN == 2 && WAVES_N == 4);
+  int ctile[TN];
+#pragma unroll
+  for (int b = 0; b < TN; b++) ctile[b] = PERM ? (b == 0 ? wc : 2 * WAVES_N - 1 - wc) : (wc * TN + b);
+  const bool diag_sym = PERM && (f.triC == TRI_LOWER) && (tm == tn);
+  // first row-tile each of this wave's column tiles needs (wave-uniform scalars; 0 = everything)
+  int cmin[TN];
+#pragma unroll
+  for (int b = 0; b < TN; b++) cmin[b] = diag_sym ? __builtin_amdgcn_readfirstlane(ctile[b]) : 0;
 
   // ---- global -> register staging ---------------------------------------------------------------
   // Row-contiguous tiles (op(A) transposed / op(B) plain) are dealt to threads in 16-byte pairs so that
@@ -282,7 +298,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
           double af[TM], bf[TN];
 #pragma unroll
           for (int b = 0; b < TN; b++) {
-            const int n = wc * WN + b * 16 + lc;
+            const int n = ctile[b] * 16 + lc;
             bf[b] = TB ? Bs[n * S::SB + k] : Bs[k * S::SB + n];
           }
 #pragma unroll
@@ -294,7 +310,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
           for (int a = 0; a < TM; a++)
 #pragma unroll
             for (int b = 0; b < TN; b++)
-              acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+              if (!PERM || a >= cmin[b])   // symmetric diagonal tile: upper MFMA tiles are never read
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -308,7 +325,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
           double af[TM], bf[TN];
 #pragma unroll
           for (int b = 0; b < TN; b++) {
-            const int n = wc * WN + b * 16 + lc;
+            const int n = ctile[b] * 16 + lc;
             bf[b] = TB ? Bs[n * S::SB + k] : Bs[k * S::SB + n];
           }
 #pragma unroll
@@ -341,7 +358,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       for (int b = 0; b < TN; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
+          const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + ctile[b] * 16 + lc;
           if (i < p.M && j < p.N) slab[(int64_t)i * p.N + j] = acc[a][b][r];
         }
     return;
@@ -353,7 +370,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       for (int b = 0; b < TN; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + wc * WN + b * 16 + lc;
+          const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + ctile[b] * 16 + lc;
           if (i < p.M && j < p.N) {
             double v = f.alpha * acc[a][b][r];
             gptr c = gC + (int64_t)i * p.ldc + j;
@@ -381,7 +398,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
         }
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
-      const int n = wc * WN + b * 16 + lc;
+      const int n = ctile[b] * 16 + lc;
       if (WAVES_M == 1) {
         const int j = j0 + n;
         if (kq == 0 && j < p.N) {
