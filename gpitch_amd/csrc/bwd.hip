@@ -409,7 +409,9 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
       return r;
     };
     { GemmProblem& r = P(S_H); r.A = t.A; r.lda = ldN; r.B = t.A; r.ldb = ldN; r.K = n; r.v1 = gv; r.C = b.H;
-      r.o2 = p->slabs + slab_off; slab_off += gp_align_up((size_t)p->nsplit * M * M * sizeof(double), 256) / sizeof(double); }
+      r.o2 = p->slabs + slab_off; slab_off += gp_align_up((size_t)p->nsplit * M * M * sizeof(double), 256) / sizeof(double);
+      // fused u = A gm: partials per K-slice in o1, result in o0 and accumulated into grad q_mu (xa)
+      r.v2 = gm; r.o1 = b.upart; r.o0 = b.u; r.xa = grad + q.off_qmu; }
     { GemmProblem& r = P(S_U); r.A = t.A; r.lda = ldN; r.N = n; r.v0 = gm; r.o0 = b.u; r.o1 = grad + q.off_qmu; }
     { GemmProblem& r = P(S_HLQ); r.A = b.H; r.B = q_sqrt; r.C = grad + q.off_qsqrt; }
     { GemmProblem& r = P(S_E); r.A = q_sqrt; r.B = q_sqrt; r.C = b.E; }
@@ -437,8 +439,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   auto D = [&](int slot) { return (const GemmProblem*)(p->d_misc + p->off_bwd[slot]); };
   // H = A diag(2 gv) A^T  (symmetric, split-K over the frames)
   GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
-  // u = A gm ; grad q_mu += u
-  GP_CHECK(launch_rowdot_batched(h, D(S_U), G, maxM));
+  // (u = A gm and grad q_mu += u are fused into the split-K product above)
   // sum_n gv  (kdiag term)
   hipLaunchKernelGGL(batched_sum_kernel, dim3(G), dim3(256), 0, h->stream, p->gFvar, (int64_t)n, n, p->bw[0].gvsum);
   GP_HIP_CHECK(h, hipGetLastError());

@@ -152,6 +152,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
   // consecutive lanes hold consecutive pairs: coalesced 256-B row segments per load and conflict-free
   // ds_write_b128.  k-contiguous tiles give each thread EA (EB) consecutive k of one row.
   double ra[EA], rb[EB], rs[EB];
+  // split-K product only: the tiles of the first tile-column also form u = X v2 (row dot products with a
+  // frame vector) from the A tiles they stage anyway — one pass over X instead of two (bwd: u = A gm).
+  const bool rowdot = (TAG == 4) && !TA && (p.v2 != nullptr) && (tn == 0);
+  const gcptr gv2 = (gcptr)p.v2;
+  double udot = 0.0, rg[EA];
   int a_i, a_k;
   constexpr int TPR_A = TA ? (BM / EA) : (GEMM_BK / EA);
   if (TA) { a_k = tid / TPR_A; a_i = (tid % TPR_A) * 2; }   // pairs at a_i + e/2 * (2*TPR_A)
@@ -194,6 +199,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
       } else {
 #pragma unroll
         for (int e = 0; e < EA; e++) ra[e] = (i < p.M && k + e < kend) ? src[e] : 0.0;
+      }
+      if (TAG == 4 && rowdot) {
+#pragma unroll
+        for (int e = 0; e < EA; e++) rg[e] = (k + e < kend) ? gv2[k + e] : 0.0;
       }
     }
     if (TB) {
@@ -250,6 +259,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
     if (scale_mode != 0) {
 #pragma unroll
       for (int e = 0; e < EB; e++) rb[e] *= rs[e];
+    }
+    if (TAG == 4 && rowdot) {
+#pragma unroll
+      for (int e = 0; e < EA; e++) udot = fma(ra[e], rg[e], udot);
     }
     if (TA) {
 #pragma unroll
@@ -361,6 +374,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
           const int i = rowbase + a * 16 + kq + 4 * r, j = j0 + ctile[b] * 16 + lc;
           if (i < p.M && j < p.N) slab[(int64_t)i * p.N + j] = acc[a][b][r];
         }
+    if (TAG == 4 && rowdot) {
+      // the GEMM_BK / EA threads that share a row hold disjoint k-ranges: combine, then one partial per K-slice
+      constexpr int TPR = GEMM_BK / EA;
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1) udot += __shfl_xor(udot, o, 64);
+      if ((tid % TPR) == 0 && i0 + a_i < p.M) go1[(int64_t)ksl * p.M + i0 + a_i] = udot;
+    }
     return;
   }
   if (f.epi & 1) {
@@ -437,6 +457,14 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const GemmProblem* __r
     s *= alpha;
     p.C[(int64_t)i * p.ldc + j] = s;
     if (sym && j < i) p.C[(int64_t)j * p.ldc + i] = s;
+  }
+  if (p.v2 && p.o1 && blockIdx.x == 0) {   // u = sum over K-slices of the fused row-dot partials; o0 = u, v0 += u
+    for (int i = threadIdx.x; i < p.M; i += blockDim.x) {
+      double s = 0.0;
+      for (int k = 0; k < nsplit; k++) s += p.o1[(int64_t)k * p.M + i];
+      p.o0[i] = s;
+      if (p.xa) const_cast<double*>(p.xa)[i] += s;
+    }
   }
 }
 

@@ -13,7 +13,7 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
     const size_t M = p->gps[g].M;
     for (int i = 0; i < 6; i++) add(M * M);
     add(M * (size_t)ldN_of64(p->maxN));
-    add(M); add(M); add(M);
+    add(M); add(M); add(M); add((size_t)65 * M);
     const size_t ns = hyper_num_sums(p->gps[g].m);
     const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
     add(ns * colblocks * rowblocks);
@@ -148,6 +148,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       b.T2 = ar.take<double>(M * M); b.Wbar = ar.take<double>(M * M); b.R = ar.take<double>(M * M);
       b.G = ar.take<double>(M * (size_t)ldN_of64(p->maxN));
       b.u = ar.take<double>(M); b.Lu = ar.take<double>(M); b.alpha = ar.take<double>(M);
+      b.upart = ar.take<double>((size_t)p->nsplit * M);
       const size_t ns = hyper_num_sums(p->gps[g].m);
       const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
       b.hyp_part = ar.take<double>(ns * colblocks * rowblocks);

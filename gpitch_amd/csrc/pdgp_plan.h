@@ -22,6 +22,7 @@ struct BwdBufs {  // per-GP backward workspace (device)
   double* R = nullptr;      // M x M   W^T E
   double* G = nullptr;      // M x N   K̄uf (dense part R (A D))
   double* u = nullptr;      // M       A gm
+  double* upart = nullptr;  // nsplit x M   fused row-dot partials
   double* Lu = nullptr;     // M       L u
   double* alpha = nullptr;  // M       W^T q_mu
   double* hyp_part = nullptr;   // hyper-gradient partial sums (Kuf side)
