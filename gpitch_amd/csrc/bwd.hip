@@ -150,6 +150,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   const int i0 = blockIdx.y * HY_ROWS;
   const int iend = min(i0 + HY_ROWS, n1);
   double* fzs = smem;
+  __shared__ double row_a[HY_ROWS];   // x1[i] / lengthscale, once per row
+  if (threadIdx.x < HY_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / ls : 0.0;
   double* omega = smem + (SM ? HY_ROWS * 2 * MPAD : 0);
   double* red = omega + (SM ? MPAD : 0);  // [4 waves][max(2+2m, HY_ROWS)]
   if (SM) {
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   }
   double acc_v = 0.0, acc_l = 0.0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double inv_ls2 = 1.0 / (ls * ls);
+  const double inv_ls = 1.0 / ls, inv_ls2 = inv_ls * inv_ls;   // hoisted: f64 division is ~25 instructions
 
   for (int i = i0; i < iend; i++) {
     const double xa = x1[i];
@@ -185,14 +187,14 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
       if (symmetric) w = 0.5 * (w + G[(int64_t)j * ldg + i]);
       if (alpha) w = fma(alpha[i], gmj, w);
     }
-    const double a = xa / ls, aa = __dmul_rn(a, a);
+    const double a = row_a[i - i0], aa = __dmul_rn(a, a);
     const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b), aa), bb);
     const double d = xa - xb;
     double dz = 0.0;  // w * dK/dx1
     if (!SM && k.type == GP_KERN_RBF) {
       const double e = exp(-0.5 * r2);
       acc_v = fma(w, e, acc_v);
-      acc_l = fma(w, var * e * r2 / ls, acc_l);
+      acc_l = fma(w, var * e * r2 * inv_ls, acc_l);
       if (GZ) dz = -w * var * e * d * inv_ls2;
     } else {
       const double r = __dsqrt_rn(__dadd_rn(r2, 1e-12));
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
         }
         const double rinv = 1.0 / r;
         acc_v = fma(w * E, S, acc_v);
-        acc_l = fma(wvE * S, r2 * rinv / ls, acc_l);
+        acc_l = fma(wvE * S, r2 * rinv * inv_ls, acc_l);
         if (GZ) dz = wvE * (-S * d * inv_ls2 * rinv - Ssin);
       } else {
         double phi, dphi;  // K = var * phi(r), dphi = phi'(r)
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
         }
         const double rinv = 1.0 / r;
         acc_v = fma(w, phi, acc_v);
-        acc_l = fma(w * var * dphi, -r2 * rinv / ls, acc_l);
+        acc_l = fma(w * var * dphi, -r2 * rinv * inv_ls, acc_l);
         if (GZ) dz = w * var * dphi * d * inv_ls2 * rinv;
       }
     }

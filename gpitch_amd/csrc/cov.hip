@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
                                                                 const double* __restrict__ f1,
                                                                 const double* __restrict__ f2, int vec_ok) {
   extern __shared__ double smem[];  // MODE 1: z-features for this block's rows [COV_ROWS][2m]
+  __shared__ double row_a[COV_ROWS];  // x1[i] / lengthscale (the exact quotient, computed once per row, not per entry)
   const double* th = k.theta;
   const double var = th[0];
   const double ls = th[1];
@@ -71,6 +72,8 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   const int i0 = blockIdx.y * COV_ROWS;
   const int iend = min(i0 + COV_ROWS, n1);
 
+  if (threadIdx.x < COV_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / th[1] : 0.0;
+  if (MODE != 1) __syncthreads();
   if (MODE == 1) {
     // stage this block's row features: smem[(i - i0) * 2*MPAD + q] = f1[q][i]
     for (int t = threadIdx.x; t < COV_ROWS * 2 * MPAD; t += COV_THREADS) {
@@ -102,8 +105,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
       }
     }
     for (int i = i0; i < iend; i++) {
-      double xa = x1[i];
-      double a = xa / ls, aa = __dmul_rn(a, a);
+      double a = row_a[i - i0], aa = __dmul_rn(a, a);
       const double* fz = &smem[(i - i0) * 2 * MPAD];
       double acc[CPT];
 #pragma unroll
@@ -139,7 +141,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
     double xa = x1[i];
     double res[CPT];
     if (MODE == 0) {
-      double a = xa / ls, aa = __dmul_rn(a, a);
+      double a = row_a[i - i0], aa = __dmul_rn(a, a);
 #pragma unroll
       for (int c = 0; c < CPT; c++) res[c] = stat_profile(k.type, r2_expand(a, aa, b[c], bb[c]), var);
     } else {
