@@ -91,13 +91,6 @@ __global__ void __launch_bounds__(256) batched_sum_kernel(const double* __restri
   if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out[i] = in[i] / theta[1]   (inputs scaled by the lengthscale, the exact quotient used in r2)
-__global__ void __launch_bounds__(256) div_ls_kernel(const double* __restrict__ in, int n, const double* __restrict__ theta,
-                                                     double* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = in[i] / theta[1];
-}
-
 static int ew_grid(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 512 ? 512 : (b < 1 ? 1 : b)); }
 
 gp_status launch_rowdot_batched(gp_handle h, const GemmProblem* d, int batch, int maxM) {
@@ -430,13 +423,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     { GemmProblem& r = P(S_RANK1); r.C = b.Wbar; r.v0 = q_mu; r.v1 = b.Lu; }
     { GemmProblem& r = P(S_R); r.A = t.W; r.B = b.E; r.C = b.R; }
     { GemmProblem& r = P(S_ALPHA); r.A = t.W; r.v0 = q_mu; r.o0 = b.alpha; }
-    {
-      GemmProblem& r = P(S_G); r.A = b.R; r.B = t.A; r.ldb = ldN; r.N = n; r.v1 = gv; r.C = b.G; r.ldc = ldN;
-      // stationary kernels without an inducing-input gradient: contract Kuf_bar in the GEMM epilogue
-      const bool fuse = kneed && (q.m == 0) && !q.need_z;
-      p->bw[g].fused = fuse;
-      if (fuse) { r.kern = t.kern; r.v0 = b.alpha; r.v2 = gm; r.xa = b.za; r.xb = b.xl; r.o0 = b.hyp_fused; }
-    }
+    { GemmProblem& r = P(S_G); r.A = b.R; r.B = t.A; r.ldb = ldN; r.N = n; r.v1 = gv; r.C = b.G; r.ldc = ldN; }
     { GemmProblem& r = P(S_T2); r.A = t.W; r.B = b.Wbar; r.C = b.T2; }
     { GemmProblem& r = P(S_LBAR); r.A = b.T2; r.B = t.W; r.C = b.T1; }
     { GemmProblem& r = P(S_P); r.A = t.L; r.B = b.T1; r.C = b.T2; }
@@ -481,15 +468,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     GP_CHECK(launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f));
     GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), nK, maxM, 1));
     // Kuf_bar (dense part) = R (A diag(2 gv))
-    for (int g : p->kgps) {
-      if (!p->bw[g].fused) continue;
-      const PdgpGP& q = p->gps[g];
-      const DevKern k = p->cb.tasks[g].kern;
-      hipLaunchKernelGGL(div_ls_kernel, dim3((q.M + 255) / 256), dim3(256), 0, h->stream, params + q.off_z, q.M, k.theta, p->bw[g].za);
-      hipLaunchKernelGGL(div_ls_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, x, n, k.theta, p->bw[g].xl);
-    }
     f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
-    f.epilogue = EPI_STORE | EPI_HYPER_STAT;
     GP_CHECK(launch_gemm_batched(h, D(S_G), nK, maxM, n, f));
     // Kuu side: Lbar = -tril(W^T Wbar W^T); P = Phi(L^T Lbar); S = W^T P W
     f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
@@ -515,14 +494,9 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS, cb_uu = (q.M + HY_THREADS - 1) / HY_THREADS;
     double* gz_uf = q.need_z ? b.gz_part : nullptr;
     double* gz_uu = q.need_z ? b.gz_part + (size_t)cb_uf * q.M : nullptr;
-    if (b.fused) {
-      const int ntiles = ((q.M + 127) / 128) * ((n + 127) / 128);
-      GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_fused, ntiles, b.gvsum, grad + q.off_theta, nullptr, 0, q.M, nullptr));
-    } else {
-      GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, x, n, b.G, ldN, b.alpha, gm, 0, t.feat, b.hyp_part, &np_uf, gz_uf));
-      GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part, np_uf, b.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
-                                   grad + q.off_z));
-    }
+    GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, x, n, b.G, ldN, b.alpha, gm, 0, t.feat, b.hyp_part, &np_uf, gz_uf));
+    GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part, np_uf, b.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
+                                 grad + q.off_z));
     GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, z, q.M, b.E, q.M, nullptr, nullptr, 1, t.feat, b.hyp_part_uu,
                                    &np_uu, gz_uu));
     GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part_uu, np_uu, nullptr, grad + q.off_theta, gz_uu, cb_uu, q.M,

@@ -130,9 +130,7 @@ struct GemmFlags {
 enum GemmEpi {
   EPI_STORE = 1,     // C = alpha*acc + beta*C
   EPI_COLSUMSQ = 2,  // o0[rowblk*N + n] = sum over the tile's rows of (alpha*acc)^2
-  EPI_COLDOT = 4,    // o1[rowblk*N + n] = sum over the tile's rows of alpha*acc * v0[row]
-  EPI_HYPER_STAT = 8 // kuf_bar role: stationary-kernel problems contract the tile with dK/dtheta in the epilogue
-                     // (o0[2*tile + {0,1}]; v0 = alpha (M), v2 = gm (N), xa = z/l (M), xb = x/l (N)) instead of storing it
+  EPI_COLDOT = 4     // o1[rowblk*N + n] = sum over the tile's rows of alpha*acc * v0[row]
 };
 // Batched: d_probs is a device array of `batch` problems; maxM/maxN bound the grid.
 gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN,

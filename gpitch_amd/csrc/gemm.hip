@@ -424,67 +424,6 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
     }
     return;
   }
-  if (TAG == 3 && (f.epi & 8)) {
-    // Kuf_bar tile never leaves the chip for stationary kernels: contract it here with dK/d(variance) and
-    // dK/d(lengthscale) (what hyper_contract_kernel<1,..> would do after a 2 x M x N round trip through HBM).
-    //   w = alpha*acc + v0[i]*v2[j] ;  K = var*phi(r), r = sqrt(r2 + 1e-12), r2 from xa[i] = z_i/l, xb[j] = x_j/l
-    // Spectral-mixture problems of the same launch take the store path below (p.kern.m > 0).
-    const DevKern kk = p.kern;
-    if (kk.theta != nullptr && kk.m == 0) {
-      const double var = kk.theta[0], ils = 1.0 / kk.theta[1];
-      const gcptr za = (gcptr)p.xa, xbv = (gcptr)p.xb;
-      double hv = 0.0, hl = 0.0;
-      double bj[TN], bbj[TN], gmj[TN];
-      bool jin[TN];
-#pragma unroll
-      for (int b = 0; b < TN; b++) {
-        const int j = j0 + ctile[b] * 16 + lc;
-        jin[b] = j < p.N;
-        bj[b] = jin[b] ? xbv[j] : 0.0; bbj[b] = __dmul_rn(bj[b], bj[b]); gmj[b] = jin[b] ? gv2[j] : 0.0;
-      }
-#pragma unroll
-      for (int a = 0; a < TM; a++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = rowbase + a * 16 + kq + 4 * r;
-          const bool iin = i < p.M;
-          const double ai = iin ? za[i] : 0.0, aai = __dmul_rn(ai, ai), al = iin ? gv0[i] : 0.0;
-#pragma unroll
-          for (int b = 0; b < TN; b++) {
-            const double w = (iin && jin[b]) ? fma(al, gmj[b], f.alpha * acc[a][b][r]) : 0.0;
-            const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(ai, bj[b]), aai), bbj[b]);
-            if (kk.type == GP_KERN_RBF) {
-              const double e = exp(-0.5 * r2);
-              hv = fma(w, e, hv);
-              hl = fma(w, var * e * r2 * ils, hl);
-            } else {
-              const double rr = __dsqrt_rn(__dadd_rn(r2, 1e-12));
-              double phi, dphi;
-              if (kk.type == GP_KERN_MATERN12) { phi = exp(-rr); dphi = -phi; }
-              else if (kk.type == GP_KERN_MATERN32) {
-                const double s3 = 1.7320508075688772, e = exp(-s3 * rr);
-                phi = (1.0 + s3 * rr) * e; dphi = -3.0 * rr * e;
-              } else {
-                const double s5 = 2.23606797749979, e = exp(-s5 * rr);
-                phi = (1.0 + s5 * rr + (5.0 / 3.0) * rr * rr) * e; dphi = -(5.0 / 3.0) * rr * (1.0 + s5 * rr) * e;
-              }
-              hv = fma(w, phi, hv);
-              hl = fma(w * var * dphi, -r2 * ils / rr, hl);
-            }
-          }
-        }
-      __syncthreads();   // staging LDS is free now
-      for (int o = 32; o > 0; o >>= 1) { hv += __shfl_down(hv, o, 64); hl += __shfl_down(hl, o, 64); }
-      if (lane == 0) { smem[wave * 2] = hv; smem[wave * 2 + 1] = hl; }
-      __syncthreads();
-      if (tid == 0) {
-        const int64_t part = (int64_t)tn * ((p.M + BM - 1) / BM) + tm;   // dense over this problem's own tiles
-        go0[part * 2 + 0] = (smem[0] + smem[2]) + (smem[4] + smem[6]);
-        go0[part * 2 + 1] = (smem[1] + smem[3]) + (smem[5] + smem[7]);
-      }
-      return;
-    }
-  }
   if (f.epi & 1) {
 #pragma unroll
     for (int a = 0; a < TM; a++)

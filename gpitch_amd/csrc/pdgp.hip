@@ -14,7 +14,6 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
     for (int i = 0; i < 6; i++) add(M * M);
     add(M * (size_t)ldN_of64(p->maxN));
     add(M); add(M); add(M); add((size_t)65 * M);
-    add(M); add(p->maxN); add(2 * (size_t)((M + 127) / 128) * ((p->maxN + 127) / 128) + 8);
     const size_t ns = hyper_num_sums(p->gps[g].m);
     const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
     add(ns * colblocks * rowblocks);
@@ -150,8 +149,6 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       b.G = ar.take<double>(M * (size_t)ldN_of64(p->maxN));
       b.u = ar.take<double>(M); b.Lu = ar.take<double>(M); b.alpha = ar.take<double>(M);
       b.upart = ar.take<double>((size_t)p->nsplit * M);
-      b.za = ar.take<double>(M); b.xl = ar.take<double>(p->maxN);
-      b.hyp_fused = ar.take<double>(2 * (size_t)((M + 127) / 128) * ((p->maxN + 127) / 128) + 8);
       const size_t ns = hyper_num_sums(p->gps[g].m);
       const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
       b.hyp_part = ar.take<double>(ns * colblocks * rowblocks);

@@ -23,10 +23,6 @@ struct BwdBufs {  // per-GP backward workspace (device)
   double* G = nullptr;      // M x N   K̄uf (dense part R (A D))
   double* u = nullptr;      // M       A gm
   double* upart = nullptr;  // nsplit x M   fused row-dot partials
-  double* za = nullptr;     // M       z / lengthscale   (stationary kernels: fused hyper epilogue)
-  double* xl = nullptr;     // N       x / lengthscale
-  double* hyp_fused = nullptr;  // 2 x tiles  partial sums written by the kuf_bar epilogue
-  bool fused = false;       // this GP's Kuf-side hyper contraction runs inside the kuf_bar GEMM
   double* Lu = nullptr;     // M       L u
   double* alpha = nullptr;  // M       W^T q_mu
   double* hyp_part = nullptr;   // hyper-gradient partial sums (Kuf side)

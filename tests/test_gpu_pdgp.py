@@ -207,3 +207,40 @@ def test_unwhitened_elbo_matches_oracle(gp_handle, N, M, P, m):
     ref = float(oracle_elbo(prob, whiten=False))
     # cond(Kuu) ~ 1e9 here (Matern32, l=1, 40 points in 94 ms): both sides carry ~cond*eps in the K^-1 terms
     assert abs(got - ref) <= 1e-6 * abs(ref), (got, ref)
+
+
+def test_minibatch_elbo_scaling_and_pairing(gp_handle):
+    """minibatch_size < N: GPflow's MinibatchData draws WITH replacement when mb/N < 0.5 (x and y generators are
+    seeded identically, pdgp.py:76-77) and the ELBO is rescaled by N/mb (pdgp.py:168-169)."""
+    from gpitch_amd.synth import make_problem
+    from oracle import gpflow05 as orc
+    prob = make_problem(3000, 30, 2, num_partials=3, seed=6)
+    mb = 100
+    model = pdgp_from_problem(prob, minibatch_size=mb, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    idx = orc.minibatch_indices(np.random.RandomState(0), 3000, mb)      # first draw of the same seeded generator
+    ref = orc.pdgp_elbo(prob["x"][idx], prob["y"][idx], prob["za"], prob["zc"], prob["kern_act"], prob["kern_com"],
+                        prob["q_mu_act"], prob["q_sqrt_act"], prob["q_mu_com"], prob["q_sqrt_com"], prob["noise_var"],
+                        num_data=3000)
+    assert abs(got - float(ref)) <= ELBO_RTOL * abs(float(ref))
+    got2 = model.compute_log_likelihood()                                  # a fresh minibatch every call
+    assert got2 != got
+
+
+def test_ragged_inducing_counts_and_single_frame(gp_handle):
+    """M differs per source and per role (pdgp.py:93-94); N = 1 frame; M = 1 inducing point."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(257, 20, 2, num_partials=2, seed=8)
+    prob["za"][1] = prob["za"][1][:7].copy(); prob["q_mu_act"][1] = prob["q_mu_act"][1][:7].copy()
+    prob["q_sqrt_act"][1] = prob["q_sqrt_act"][1][:7, :7].copy()
+    prob["zc"][0] = prob["zc"][0][:1].copy(); prob["q_mu_com"][0] = prob["q_mu_com"][0][:1].copy()
+    prob["q_sqrt_com"][0] = prob["q_sqrt_com"][0][:1, :1].copy()
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    ref = float(oracle_elbo(prob))
+    assert abs(got - ref) <= ELBO_RTOL * abs(ref)
+    one = dict(prob); one["x"] = prob["x"][:1].copy(); one["y"] = prob["y"][:1].copy(); one["N"] = 1
+    m1 = pdgp_from_problem(one, handle=gp_handle)
+    g1 = m1.compute_log_likelihood()
+    r1 = float(oracle_elbo(one))
+    assert abs(g1 - r1) <= ELBO_RTOL * abs(r1)
