@@ -104,17 +104,24 @@ def main():
     ap.add_argument("--lr", type=float, default=0.0025)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; a rehearsal with more ranks than GPUs (gloo) wraps around
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    os.environ["LOCAL_RANK"] = str(dev_index)      # gpitch_amd's default handle binds to this device
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
 
     import gpitch_amd
     from gpitch_amd import _lib
