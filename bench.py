@@ -21,7 +21,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor sheet); bare MFMA loop measures ~48
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor sheet); a bare VGPR-accumulator MFMA loop measures 70-76
 PEAK_HBM_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -31,8 +31,14 @@ def build_model(args, rank):
     from gpitch_amd.synth import make_problem
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import pdgp_from_problem
-    prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=rank)
-    model = pdgp_from_problem(prob)
+    if args.shard == "pitch":
+        # ONE model over all ranks: same problem everywhere, rank r holds pitches p = r (mod world)
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=0)
+        model = pdgp_from_problem(prob, shard=(rank, world) if world > 1 else None)
+    else:
+        prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=rank)
+        model = pdgp_from_problem(prob)
     model.za.fixed = True      # as demos/scripts/demo-modgp.py:40-41
     model.zc.fixed = True
     return prob, model
@@ -104,6 +110,10 @@ def main():
     ap.add_argument("--lr", type=float, default=0.0025)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--shard", choices=["window", "pitch"], default="window",
+                    help="window: one independent P-pitch window per GPU (weak scaling, scalar all-reduce only); "
+                         "pitch: ONE P-pitch model spread over the GPUs, one all-reduce of 3N+1 doubles per step "
+                         "(strong scaling, ceiling P / ceil(P / gpus))")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
@@ -137,9 +147,10 @@ def main():
         h.check(h.lib.gp_adam_step(h.h, model._free.data_ptr(), model._params.data_ptr(), model._grad.data_ptr(),
                                    model._tcode.data_ptr(), model._adam_m.data_ptr(), model._adam_v.data_ptr(),
                                    model._nparams, model._adam_t, opt.learning_rate, opt.beta1, opt.beta2, opt.epsilon))
-        if dist is not None:   # scalar ELBO of the whole job (north_star: all-reduce of the scalar ELBO)
+        if dist is not None and args.shard == "window":
+            # scalar ELBO of the whole job (north_star: all-reduce of the scalar ELBO)
             elbo_sum.copy_(model._elbo_dev[:1])
-            dist.all_reduce(elbo_sum)
+            gpitch_amd.dist.allreduce_sum_(elbo_sum)
 
     for _ in range(args.warmup):
         step()
@@ -166,7 +177,8 @@ def main():
     timers = h.timers()
 
     if rank == 0:
-        G, M, N, T = 2 * args.P, args.M, args.N, 8
+        pitch = args.shard == "pitch" and world > 1
+        G, M, N, T = 2 * len(model._local), args.M, args.N, 8      # latent GPs in this rank's launches
         m2n = float(M) * M * N
         # algorithmic flops per launch (one launch = all 2P latent GPs); SURVEY §8d / DESIGN.md
         alg = {"cond_A": G * m2n, "cond_LTA": G * m2n, "nt_gemm": G * m2n, "kuf_bar": G * 2.0 * m2n}
@@ -179,7 +191,7 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (tools/make_traffic_json.py); null if absent
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["kernels"]
-            traffic = tj[sym[dom].replace(" ", "")]["hbm_bytes"] if (N, M, args.P) == (32768, 512, 12) else None
+            traffic = tj[sym[dom].replace(" ", "")]["hbm_bytes"] if (N, M, G) == (32768, 512, 24) else None
         except Exception:
             traffic = None
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -194,14 +206,17 @@ def main():
                 kuf[name] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
                              "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": byts}
         out = {
-            "metric": "ELBO-steps/sec", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+            "metric": "ELBO-steps/sec", "value": (1 if pitch else world) * args.steps / elapsed, "unit": "steps/s",
+            "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if pitch else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "pdgp ELBO step (fwd + grad + Adam), N=%d frames x M=%d inducing x P=%d pitches "
-                                   "(2P=%d latent GPs), m=%d partials, float64, full batch; one independent window per GPU"
-                                   % (N, M, args.P, G, args.partials),
+                                   "(2P=%d latent GPs), m=%d partials, float64, full batch; %s"
+                                   % (N, M, args.P, 2 * args.P, args.partials,
+                                      "one model pitch-sharded over the GPUs (all-reduce of 3N+1 doubles per step)"
+                                      if pitch else "one independent window per GPU"),
                        "N": N, "M": M, "P": args.P, "partials": args.partials, "whiten": True,
-                       "parallelism": "window-per-gpu x%d" % world},
+                       "parallelism": ("pitch-sharded x%d" if pitch else "window-per-gpu x%d") % world},
             "roofline": roof,
             "roofline_kuf_build": kuf,
             "kernel_ms_per_step": {k: ms / args.steps for k, (ms, n) in timers.items()},

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "gp_kernel_build", "gp_kernel_diag", "gp_chol_workspace_bytes", "gp_kuu_cholesky", "gp_cholesky_inplace",
     "gp_conditional_workspace_bytes", "gp_conditional_diag", "gp_gauss_kl", "gp_mpd_varexp",
     "gp_pdgp_create", "gp_pdgp_destroy", "gp_pdgp_num_params", "gp_pdgp_layout", "gp_pdgp_workspace_bytes",
-    "gp_pdgp_set_workspace", "gp_pdgp_set_grad_needs", "gp_pdgp_elbo", "gp_pdgp_predict",
+    "gp_pdgp_set_workspace", "gp_pdgp_set_grad_needs", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_predict",
     "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace",
     "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
@@ -106,6 +106,8 @@ def load_library():
         "gp_pdgp_set_workspace": (i32, [vp, vp, sz]),
         "gp_pdgp_set_grad_needs": (i32, [vp, i32, i32, i32]),
         "gp_pdgp_elbo": (i32, [vp, vp, vp, vp, i32, dbl, vp, C.POINTER(dbl), vp]),
+        "gp_pdgp_elbo_begin": (i32, [vp, vp, vp, vp, i32, vp, vp]),
+        "gp_pdgp_elbo_end": (i32, [vp, vp, vp, vp, i32, dbl, vp, vp, C.POINTER(dbl), vp]),
         "gp_pdgp_predict": (i32, [vp, vp, vp, i32, vp, vp, vp]),
         "gp_transform_forward": (i32, [vp, vp, vp, i64, vp]),
         "gp_transform_backward": (i32, [vp, vp, vp, i64, vp]),

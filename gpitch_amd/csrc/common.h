@@ -150,7 +150,7 @@ int gemm_rowblocks(int M, int big_tiles);
 gp_status launch_mpd_lik(gp_handle h, const double* Fmu, const double* Fvar, int64_t f_rs, int64_t f_cs,
                          const double* y, int N, int P, int nlin, const double* noise_var, double scale,
                          double* per_frame, double* partial_sums, int* num_partials_out,
-                         double* gFmu, double* gFvar);
+                         double* gFmu, double* gFvar, double* psum = nullptr, const double* gsum = nullptr);
 gp_status launch_finish_sum(gp_handle h, const double* partials, int count, int stride, int nsums, double* out,
                             double mul, int accumulate);
 

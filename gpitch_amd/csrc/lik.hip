@@ -76,30 +76,46 @@ __global__ void __launch_bounds__(LIK_THREADS) mpd_lik_kernel(const double* __re
                                                               int P, int nlin, const double* __restrict__ noise_var,
                                                               double scale, double* __restrict__ per_frame,
                                                               double* __restrict__ partial, double* __restrict__ gFmu,
-                                                              double* __restrict__ gFvar) {
+                                                              double* __restrict__ gFvar, double* __restrict__ psum,
+                                                              const double* __restrict__ gsum) {
+  // Pitch-sharded operation (the P sources here are one rank's share of a larger model):
+  //   psum != NULL : write this rank's per-frame partial sums  A = sum a_i, B = sum E2_i(v_f+m_f^2), D = sum a_i^2
+  //                  to psum[0..N), psum[N..2N), psum[2N..3N) and stop;
+  //   gsum != NULL : the same three vectors summed over all ranks; the cross term becomes C = A^2 - D
+  //                  (likelihoods.py:56-65 builds the same quantity as an explicit pair sum).
   const int n = blockIdx.x * LIK_THREADS + threadIdx.x;
   const double s2 = noise_var[0];
   double ve = 0.0, dnoise = 0.0;
   if (n < N) {
     const double Y = y[n];
     // pass 1: A, B, C (C as the reference's pair sum 2*sum_{i<j} a_i a_j, accumulated with a running prefix)
-    double A = 0.0, B = 0.0, Cpair = 0.0;
-    for (int i = 0; i < P; i++) {
-      const double mg = Fmu[n * rs + i * cs], vg = Fvar[n * rs + i * cs];
-      const double mf = Fmu[n * rs + (i + P) * cs], vf = Fvar[n * rs + (i + P) * cs];
-      Quad q = gh_quad(nlin, mg, vg, false);
-      const double a = q.E1 * mf;
-      Cpair = fma(a, A, Cpair);  // a_i * sum_{j<i} a_j
-      A += a;
-      B = fma(q.E2, vf + mf * mf, B);
+    double A = 0.0, B = 0.0, Cpair = 0.0, D = 0.0;
+    if (!gsum || psum) {
+      for (int i = 0; i < P; i++) {
+        const double mg = Fmu[n * rs + i * cs], vg = Fvar[n * rs + i * cs];
+        const double mf = Fmu[n * rs + (i + P) * cs], vf = Fvar[n * rs + (i + P) * cs];
+        Quad q = gh_quad(nlin, mg, vg, false);
+        const double a = q.E1 * mf;
+        Cpair = fma(a, A, Cpair);  // a_i * sum_{j<i} a_j
+        D = fma(a, a, D);
+        A += a;
+        B = fma(q.E2, vf + mf * mf, B);
+      }
     }
-    const double C = 2.0 * Cpair;
+    double C = 2.0 * Cpair;
+    if (psum) {
+      psum[n] = A; psum[(int64_t)N + n] = B; psum[2 * (int64_t)N + n] = D;
+    }
+    if (gsum) {
+      A = gsum[n]; B = gsum[(int64_t)N + n];
+      C = A * A - gsum[2 * (int64_t)N + n];
+    }
     const double resid = Y * Y - 2.0 * Y * A + B + C;
     const double LOG2PI = 1.8378770664093453;
     const double v = -0.5 * ((1.0 / s2) * resid + LOG2PI + log(s2));
     if (per_frame) per_frame[n] = v;
     ve = v * scale;
-    if (gFmu) {
+    if (gFmu && !psum) {
       dnoise = scale * (0.5 * resid / (s2 * s2) - 0.5 / s2);
       const double qf = -0.5 * scale / s2;
       for (int i = 0; i < P; i++) {
@@ -135,12 +151,12 @@ __global__ void __launch_bounds__(LIK_THREADS) mpd_lik_kernel(const double* __re
 gp_status launch_mpd_lik(gp_handle h, const double* Fmu, const double* Fvar, int64_t f_rs, int64_t f_cs,
                          const double* y, int N, int P, int nlin, const double* noise_var, double scale,
                          double* per_frame, double* partial_sums, int* num_partials_out, double* gFmu,
-                         double* gFvar) {
+                         double* gFvar, double* psum, const double* gsum) {
   if (N <= 0) { if (num_partials_out) *num_partials_out = 0; return GP_OK; }
   GpTimerScope ts(h, GP_TIMER_LIK);
   int blocks = (N + LIK_THREADS - 1) / LIK_THREADS;
   hipLaunchKernelGGL(mpd_lik_kernel, dim3(blocks), dim3(LIK_THREADS), 0, h->stream, Fmu, Fvar, f_rs, f_cs, y, N, P,
-                     nlin, noise_var, scale, per_frame, partial_sums, gFmu, gFvar);
+                     nlin, noise_var, scale, per_frame, partial_sums, gFmu, gFvar, psum, gsum);
   GP_HIP_CHECK(h, hipGetLastError());
   if (num_partials_out) *num_partials_out = blocks;
   return GP_OK;

@@ -177,7 +177,9 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
 static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad,
                            double* fmean, double* fvar) {
   gp_handle h = p->h;
-  const bool same = (p->last_params == params && p->last_x == x && p->last_n == n && p->last_grad == grad &&
+  // (the batch pointers x / y are not part of any descriptor: a fresh minibatch tensor every step must not
+  //  force a re-upload)
+  const bool same = (p->last_params == params && p->last_n == n && p->last_grad == grad &&
                      p->cb.tasks[0].fmean == fmean);
   if (same && p->cb.uploaded) return GP_OK;
   for (int g = 0; g < p->G; g++) {
@@ -220,20 +222,19 @@ static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x
 
 extern "C" {
 
-gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
-                       double num_data, double* elbo_dev, double* elbo_host, double* grad) {
-  if (!p) return GP_ERR_BAD_ARG;
+// Shared body of gp_pdgp_elbo (xchg == NULL, one call) and of the two-stage pitch-sharded form:
+//   stage 1 (begin): conditionals, per-frame partial sums [A | B | D] and sum of the local KL terms -> xchg[0..3n]
+//   stage 2 (end)  : likelihood + gradients from the rank-summed xchg, local backward pass.
+static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double* x, const double* y, int n,
+                              double* grad, double* xchg) {
   gp_handle h = p->h;
-  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo: workspace not set");
-  if (!params || !x || !y || !elbo_dev || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo: bad argument");
-  if (grad && !p->whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo: gradient needs whiten=1");
   GP_CHECK(pdgp_bind(p, params, x, n, grad, p->fmean, p->fvar));
   if (grad) GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
   GP_CHECK(cond_batch_run(h, p->cb, x, n, p->whiten != 0, p->jitter));
-  int nb = 0;
-  const double scale = num_data / (double)n;
-  GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
-                          grad ? p->gFmu : nullptr, grad ? p->gFvar : nullptr));
+  if (xchg) {
+    GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, 1.0, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, xchg, nullptr));
+  }
   if (p->whiten) {
     GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl_items, p->G));
   } else {
@@ -244,13 +245,60 @@ gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, co
     GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(p->d_misc + kl_region), p->G, p->maxM, p->maxM, f));
     GP_CHECK(launch_kl_unwhite(h, p->d_misc + p->off_kl_items, p->G));
   }
-  GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G, elbo_dev, grad ? grad : nullptr));
+  if (xchg) GP_CHECK(launch_finish_sum(h, p->kl, p->G, 1, 1, xchg + 3 * (size_t)n, 1.0, 0));
+  return GP_OK;
+}
+
+static gp_status pdgp_finish(gp_pdgp_plan p, const double* params, const double* x, const double* y, int n,
+                             double num_data, const double* xchg, double* elbo_dev, double* elbo_host, double* grad) {
+  gp_handle h = p->h;
+  int nb = 0;
+  const double scale = num_data / (double)n;
+  GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
+                          grad ? p->gFmu : nullptr, grad ? p->gFvar : nullptr, nullptr, xchg));
+  if (xchg) GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, xchg + 3 * (size_t)n, 1, elbo_dev, grad ? grad : nullptr));
+  else GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G, elbo_dev, grad ? grad : nullptr));
   if (grad) GP_CHECK(pdgp_backward(p, params, x, n, grad));
   if (elbo_host) {
     GP_HIP_CHECK(h, hipMemcpyAsync(elbo_host, elbo_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GP_CHECK(check_not_pd(h));
   }
   return GP_OK;
+}
+
+gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                       double num_data, double* elbo_dev, double* elbo_host, double* grad) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo: workspace not set");
+  if (!params || !x || !y || !elbo_dev || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo: bad argument");
+  if (grad && !p->whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo: gradient needs whiten=1");
+  GP_CHECK(pdgp_forward(p, params, x, y, n, grad, nullptr));
+  return pdgp_finish(p, params, x, y, n, num_data, nullptr, elbo_dev, elbo_host, grad);
+}
+
+gp_status gp_pdgp_elbo_begin(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                             double* grad, double* exchange) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo_begin: workspace not set");
+  if (!params || !x || !y || !exchange || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo_begin: bad argument");
+  if (grad && !p->whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo_begin: gradient needs whiten=1");
+  p->staged_n = 0;
+  GP_CHECK(pdgp_forward(p, params, x, y, n, grad, exchange));
+  p->staged_n = n; p->staged_grad = grad; p->staged_params = params;
+  return GP_OK;
+}
+
+gp_status gp_pdgp_elbo_end(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                           double num_data, const double* exchange, double* elbo_dev, double* elbo_host, double* grad) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!params || !x || !y || !exchange || !elbo_dev) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo_end: bad argument");
+  if (p->staged_n != n || p->staged_grad != grad || p->staged_params != params)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo_end: no matching gp_pdgp_elbo_begin (same params, n and grad required)");
+  p->staged_n = 0;
+  return pdgp_finish(p, params, x, y, n, num_data, exchange, elbo_dev, elbo_host, grad);
 }
 
 gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n, double* fmean,

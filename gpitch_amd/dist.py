@@ -37,7 +37,13 @@ def allreduce_sum_(t):
     """in-place sum over ranks of a (device or host) tensor; no-op single-process"""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t)
+        if t.is_cuda and dist.get_backend() == "gloo":
+            # CPU rehearsal backend: stage through the host (RCCL reduces device memory directly)
+            host = t.cpu()
+            dist.all_reduce(host)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t)
     return t
 
 

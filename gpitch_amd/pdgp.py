@@ -48,11 +48,21 @@ def predict_windowed(model, xnew, ws=1600):
     return m_a_l, v_a_l, m_c_l, v_c_l, m_s_l
 
 
+def pitch_assignment(num_sources, world_size, rank):
+    """pitches held by `rank` when one model is spread over `world_size` GPUs (pitch p -> rank p mod world)"""
+    return list(range(rank, num_sources, world_size))
+
+
 class Pdgp(Parameterized):
     def __init__(self, x, y, z, kern, whiten=True, minibatch_size=None, nlinfun=logistic_tf, handle=None,
-                 max_predict_batch=None):
+                 max_predict_batch=None, shard=None):
         """Pitch detection using Gaussian process (pdgp.py:49-111).
-        x, y: (N,1) arrays; z = [[za_0..], [zc_0..]]; kern = [[kern_act...], [kern_com...]]."""
+        x, y: (N,1) arrays; z = [[za_0..], [zc_0..]]; kern = [[kern_act...], [kern_com...]].
+
+        shard=(rank, world) spreads ONE model over `world` GPUs (one process each): this rank's engine plan holds
+        the pitches {p : p mod world == rank} (both GPs of a pitch), the likelihood noise is replicated, and each
+        ELBO evaluation exchanges one all-reduce of 3n+1 doubles (include/gpitch_abi.h: gp_pdgp_elbo_begin/_end).
+        Every rank constructs the model with the same arguments."""
         x = np.asarray(x, dtype=np.float64).reshape(-1, 1)
         y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
         if minibatch_size is None:
@@ -60,6 +70,15 @@ class Pdgp(Parameterized):
         self.minibatch_size = int(minibatch_size)
         self.num_data = x.shape[0]
         self.num_sources = len(kern[0])
+        if shard is None:
+            self._shard = None
+            self._local = list(range(self.num_sources))
+        else:
+            rank, world = int(shard[0]), int(shard[1])
+            if not (0 <= rank < world) or world > self.num_sources:
+                raise ValueError("shard=(rank, world) needs 0 <= rank < world <= number of sources")
+            self._shard = (rank, world)
+            self._local = pitch_assignment(self.num_sources, world, rank)
         self.whiten = whiten
         self.nlinfun = nlinfun
         self.likelihood = MpdLik(nlinfun=self.nlinfun, num_sources=self.num_sources)
@@ -94,12 +113,11 @@ class Pdgp(Parameterized):
     # ------------------------------------------------------------------------------------------
     # engine plumbing
     def _gps(self):
-        """GP order of the engine: act_0..act_{P-1}, com_0..com_{P-1}"""
-        P = self.num_sources
+        """GP order of the engine: act then com of the pitches this rank holds (all of them when unsharded)"""
         out = []
-        for i in range(P):
+        for i in self._local:
             out.append((self.kern_act[i], self.za[i], self.q_mu_act[i], self.q_sqrt_act[i]))
-        for i in range(P):
+        for i in self._local:
             out.append((self.kern_com[i], self.zc[i], self.q_mu_com[i], self.q_sqrt_com[i]))
         return out
 
@@ -107,14 +125,15 @@ class Pdgp(Parameterized):
         if self._plan is not None:
             return
         h = self._handle = self._handle or _lib.default_handle()
-        P = self.num_sources
+        loc = self._local
+        P = len(loc)
         i32 = C.c_int32 * P
-        gps = self._gps()
         self._cfg_keep = dict(
-            M_act=i32(*self.num_inducing_a), M_com=i32(*self.num_inducing_c),
-            kt_act=i32(*[k.type_code for k in self.kern_act]), kt_com=i32(*[k.type_code for k in self.kern_com]),
-            np_act=i32(*[int(k.num_partials) for k in self.kern_act]),
-            np_com=i32(*[int(k.num_partials) for k in self.kern_com]))
+            M_act=i32(*[self.num_inducing_a[i] for i in loc]), M_com=i32(*[self.num_inducing_c[i] for i in loc]),
+            kt_act=i32(*[self.kern_act[i].type_code for i in loc]),
+            kt_com=i32(*[self.kern_com[i].type_code for i in loc]),
+            np_act=i32(*[int(self.kern_act[i].num_partials) for i in loc]),
+            np_com=i32(*[int(self.kern_com[i].num_partials) for i in loc]))
         k = self._cfg_keep
         self._max_batch = max(self.minibatch_size, self._max_predict_batch or min(self.num_data, 32768))
         cfg = _lib.PdgpConfig(P, int(bool(self.whiten)), nlin_code(self.nlinfun), self._max_batch,
@@ -140,6 +159,7 @@ class Pdgp(Parameterized):
         h.check(h.lib.gp_pdgp_set_workspace(plan, self._ws.data_ptr(), self._ws.numel()))
         self._x_dev = h.to_device(self.x._array.reshape(-1))
         self._y_dev = h.to_device(self.y._array.reshape(-1))
+        self._xchg = h.zeros(3 * self._max_batch + 1) if self._shard else None
 
     def _segments(self):
         """[(offset, Param)] of every Param in the flat vector"""
@@ -189,6 +209,11 @@ class Pdgp(Parameterized):
 
     def _elbo(self, want_grad, sync=True):
         h = self._handle
+        if self._shard:
+            xchg = self._elbo_begin(want_grad)
+            from .dist import allreduce_sum_
+            allreduce_sum_(xchg)
+            return self._elbo_end(want_grad, sync)
         xb, yb, n = self._batch()
         self._last_batch = (xb, yb)   # keep alive while the stream uses them
         out = C.c_double()
@@ -197,12 +222,33 @@ class Pdgp(Parameterized):
                                    self._grad.data_ptr() if want_grad else None))
         return out.value if sync else None
 
+    def _elbo_begin(self, want_grad):
+        """pitch-sharded stage 1: returns the exchange tensor [A | B | D | sum KL] (3n+1) to be summed over ranks"""
+        h = self._handle
+        xb, yb, n = self._batch()
+        self._last_batch = (xb, yb)
+        xchg = self._xchg[:3 * n + 1]
+        h.check(h.lib.gp_pdgp_elbo_begin(self._plan, self._params.data_ptr(), xb.data_ptr(), yb.data_ptr(), n,
+                                         self._grad.data_ptr() if want_grad else None, xchg.data_ptr()))
+        return xchg
+
+    def _elbo_end(self, want_grad, sync=True):
+        """pitch-sharded stage 2 on the rank-summed exchange tensor"""
+        h = self._handle
+        xb, yb = self._last_batch
+        n = xb.numel()
+        out = C.c_double()
+        h.check(h.lib.gp_pdgp_elbo_end(self._plan, self._params.data_ptr(), xb.data_ptr(), yb.data_ptr(), n,
+                                       float(self.num_data), self._xchg.data_ptr(), self._elbo_dev.data_ptr(),
+                                       C.byref(out) if sync else None, self._grad.data_ptr() if want_grad else None))
+        return out.value if sync else None
+
     # ------------------------------------------------------------------------------------------
     # reference API
     def build_prior_kl(self):
         """compute KL divergences (pdgp.py:113-131)"""
         from .conditionals import gauss_kl
-        if not self.whiten:
+        if not self.whiten or self._shard:
             # K = Kuu + jitter I (pdgp.py:126-129): evaluated by the engine next to the conditionals
             self._pack()
             self._elbo(False)
@@ -258,8 +304,14 @@ class Pdgp(Parameterized):
             x_final = self._free.cpu().numpy()
             f, g = self._objective(x_final)
             self._unpack()
+            if self._shard:
+                self.sync_params()
             return OptimizeResult(fun=f, jac=g, x=x_final, message='Finished iterations.', status='Finished iterations.',
                                   success=True)
+        if self._shard:
+            # each rank owns a different slice of the free state: only element-wise update rules (Adam) stay
+            # consistent across ranks without exchanging it
+            raise NotImplementedError("a pitch-sharded Pdgp is trained with AdamOptimizer")
         from scipy.optimize import minimize
         x0 = self._free.cpu().numpy()
         res = minimize(self._objective, x0, jac=True, method=method, tol=tol, callback=callback,
@@ -274,22 +326,54 @@ class Pdgp(Parameterized):
         self._pack()
         h = self._handle
         xnew = np.asarray(xnew, dtype=np.float64).reshape(-1)
-        P, G, n = self.num_sources, 2 * self.num_sources, xnew.size
-        fmean = np.empty((G, n))
-        fvar = np.empty((G, n))
-        src = np.empty((P, n))
+        P, n = self.num_sources, xnew.size
+        loc = self._local
+        Pl, Gl = len(loc), 2 * len(loc)
+        fmean = np.zeros((2 * P, n))
+        fvar = np.zeros((2 * P, n))
+        src = np.zeros((P, n))
+        rows = np.array(loc + [P + i for i in loc])      # engine row -> model row [g_0..g_{P-1}, f_0..f_{P-1}]
         step = self._max_batch
         for s in range(0, n, step):
             xs = h.to_device(xnew[s:s + step])
             c = xs.numel()
-            fm, fv, ms = h.empty(G, c), h.empty(G, c), h.empty(P, c)
+            fm, fv, ms = h.empty(Gl, c), h.empty(Gl, c), h.empty(Pl, c)
             h.check(h.lib.gp_pdgp_predict(self._plan, self._params.data_ptr(), xs.data_ptr(), c, fm.data_ptr(),
                                           fv.data_ptr(), ms.data_ptr() if want_source else None))
-            fmean[:, s:s + c] = fm.cpu().numpy()
-            fvar[:, s:s + c] = fv.cpu().numpy()
+            fmean[rows, s:s + c] = fm.cpu().numpy()
+            fvar[rows, s:s + c] = fv.cpu().numpy()
             if want_source:
-                src[:, s:s + c] = ms.cpu().numpy()
+                src[loc, s:s + c] = ms.cpu().numpy()
+        if self._shard:
+            # rows of other ranks are zero here: a sum over ranks assembles the full prediction
+            from .dist import allreduce_sum_
+            t = h.torch
+            for a in (fmean, fvar, src):
+                a[...] = allreduce_sum_(t.as_tensor(a)).numpy()
         return fmean, fvar, src
+
+    def sync_params(self):
+        """pitch-sharded model: after training, give every rank the Param values of every pitch"""
+        import torch.distributed as dist
+        if not (self._shard and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        mine = {}
+        for i in self._local:
+            for name, lst in (("kern_act", self.kern_act), ("kern_com", self.kern_com)):
+                mine[(name, i)] = [q.value.copy() for q in lst[i].theta_params()]
+            for name in ("za", "zc", "q_mu_act", "q_mu_com", "q_sqrt_act", "q_sqrt_com"):
+                mine[(name, i)] = getattr(self, name)[i].value.copy()
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        for part in everyone:
+            for (name, i), val in part.items():
+                if i in self._local:
+                    continue
+                if name.startswith("kern"):
+                    for q, v in zip(getattr(self, name)[i].theta_params(), val):
+                        q.value = v
+                else:
+                    getattr(self, name)[i].value = val
 
     def predict_act(self, xnew):
         """pdgp.py:172-179"""

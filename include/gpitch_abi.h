@@ -165,6 +165,23 @@ gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, 
 gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
                        double num_data, double* elbo_dev, double* elbo_host, double* grad);
 
+/* Pitch-sharded evaluation of ONE Pdgp model over several GPUs (one process per GPU).  Each rank builds a plan
+ * over its own subset of the P sources (both GPs of a pitch on the same rank; the noise variance params[0] is
+ * replicated).  The likelihood (likelihoods.py:47-68) couples sources only through three per-frame sums
+ *   A = sum_i E1_i m_f,i ,  B = sum_i E2_i (v_f,i + m_f,i^2) ,  D = sum_i (E1_i m_f,i)^2     (C = A^2 - D),
+ * so the exchange step is ONE sum-all-reduce of 3n+1 doubles (the last slot carries the KL terms):
+ *   gp_pdgp_elbo_begin  : conditionals of the local GPs; writes the local [A | B | D | sum KL] to exchange[0..3n]
+ *   -- caller: ncclAllReduce(exchange, 3n+1, ncclSum) ordered after begin / before end on the handle's stream --
+ *   gp_pdgp_elbo_end    : likelihood + noise gradient from the reduced sums (identical on every rank), local
+ *                         backward pass; elbo_dev / elbo_host / grad as in gp_pdgp_elbo (the ELBO is the whole
+ *                         model's; grad covers this rank's parameters, and grad[0] is the full noise gradient).
+ * No collective is needed in the backward pass.  begin and end must be called with the same params, n and grad. */
+gp_status gp_pdgp_elbo_begin(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                             double* grad, double* exchange);
+gp_status gp_pdgp_elbo_end(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                           double num_data, const double* exchange, double* elbo_dev, double* elbo_host,
+                           double* grad);
+
 /* Pdgp.predict_act / predict_com / predict_act_n_com (pdgp.py:172-208): conditionals at xnew for all 2P
  * GPs.  fmean/fvar: 2P x n row-major (row g as in gp_pdgp_layout).  mean_source (P x n, may be NULL)
  * = nlinfun(mean_act_i) * mean_com_i (pdgp.py:207). */

@@ -20,12 +20,12 @@ def kernels_from_problem(prob):
     return [[mk(d) for d in prob["kern_act"]], [mk(d) for d in prob["kern_com"]]]
 
 
-def pdgp_from_problem(prob, whiten=True, minibatch_size=None, nlinfun=None, handle=None):
+def pdgp_from_problem(prob, whiten=True, minibatch_size=None, nlinfun=None, handle=None, shard=None):
     import gpitch_amd
     from gpitch_amd.pdgp import Pdgp
     kern = kernels_from_problem(prob)
     m = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kern, whiten=whiten, minibatch_size=minibatch_size,
-             nlinfun=nlinfun or gpitch_amd.logistic_tf, handle=handle)
+             nlinfun=nlinfun or gpitch_amd.logistic_tf, handle=handle, shard=shard)
     for i in range(prob["P"]):
         m.q_mu_act[i].value = prob["q_mu_act"][i]
         m.q_mu_com[i].value = prob["q_mu_com"][i]
@@ -80,11 +80,12 @@ def oracle_elbo_and_grads(prob, nlin_code=0):
 def model_grad_dict(m):
     """the engine's gradient vector split by parameter name (same keys as oracle_elbo_and_grads)"""
     g = m._grad.cpu().numpy()
-    P = m.num_sources
+    loc = m._local                 # pitches held by this model (all of them unless pitch-sharded)
+    P = len(loc)
     out = {"noise": g[0:1].copy()}
     for gi in range(2 * P):
         act = gi < P
-        i = gi if act else gi - P
+        i = loc[gi if act else gi - P]
         name = ("act%d" if act else "com%d") % i
         kern = (m.kern_act if act else m.kern_com)[i]
         o_th, o_z, o_mu, o_sq = m._layout[gi]

@@ -244,3 +244,59 @@ def test_ragged_inducing_counts_and_single_frame(gp_handle):
     g1 = m1.compute_log_likelihood()
     r1 = float(oracle_elbo(one))
     assert abs(g1 - r1) <= ELBO_RTOL * abs(r1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,world,whiten", [(3, 2, True), (5, 3, True), (2, 2, False)])
+def test_pitch_sharded_two_stage_matches_unsharded(gp_handle, P, world, whiten):
+    """One model spread over `world` ranks (gp_pdgp_elbo_begin -> sum of the 3n+1 exchange vectors ->
+    gp_pdgp_elbo_end), the ranks emulated in this process: every rank must report the whole model's ELBO and
+    its slice of the unsharded gradient (the pair sum C of likelihoods.py:56-65 becomes A^2 - D)."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(900, 24, P, num_partials=3, seed=11)
+    full = pdgp_from_problem(prob, whiten=whiten, handle=gp_handle)
+    full._pack()
+    e_full = full._elbo(whiten)
+    g_full = model_grad_dict(full) if whiten else None
+    kl_full = float(full._elbo_dev[1].item())
+    shards = [pdgp_from_problem(prob, whiten=whiten, handle=gp_handle, shard=(r, world)) for r in range(world)]
+    for s in shards:
+        s._pack()
+    parts = [s._elbo_begin(whiten).clone() for s in shards]
+    total = sum(parts)
+    seen = set()
+    for s in shards:
+        s._xchg[:total.numel()].copy_(total)
+        e = s._elbo_end(whiten)
+        assert abs(e - e_full) <= 1e-10 * abs(e_full)
+        assert abs(float(s._elbo_dev[1].item()) - kl_full) <= 1e-10 * max(1.0, abs(kl_full))
+        if whiten:
+            gs = model_grad_dict(s)
+            for k, v in gs.items():
+                ref = g_full[k]
+                assert np.allclose(v, ref, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref).max())), k
+                seen.add(k)
+    if whiten:
+        assert seen == set(g_full.keys())
+    # predictions: each rank fills its own rows (the sum over ranks assembles the list)
+    xs = prob["x"][::7]
+    ref = full.predict_act_n_com(xs)
+    got = [s._predict(xs, True) for s in shards]
+    fm = sum(g[0] for g in got)
+    src = sum(g[2] for g in got)
+    for i in range(P):
+        assert np.allclose(fm[i].reshape(-1, 1), ref[0][i], rtol=1e-10, atol=1e-12)
+        assert np.allclose(fm[P + i].reshape(-1, 1), ref[2][i], rtol=1e-10, atol=1e-12)
+        assert np.allclose(src[i].reshape(-1, 1), ref[4][i], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_pitch_sharded_end_requires_matching_begin(gp_handle):
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(200, 8, 2, num_partials=2, seed=3)
+    s = pdgp_from_problem(prob, handle=gp_handle, shard=(0, 2))
+    s._pack()
+    s._batch_keep = s._batch()
+    s._last_batch = s._batch_keep[:2]
+    with pytest.raises(Exception):
+        s._elbo_end(True)
