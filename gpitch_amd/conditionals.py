@@ -43,9 +43,8 @@ def conditional(Xnew, X, kern, f, full_cov=False, q_sqrt=None, whiten=False):
 
 
 def gauss_kl(q_mu, q_sqrt, K=None):
-    """KL[q(u) || p(u)], whitened when K is None (pdgp.py:120-121)."""
-    if K is not None:
-        raise NotImplementedError("gauss_kl with an explicit K matrix: use Pdgp(whiten=False).build_prior_kl()")
+    """KL[q(u) || p(u)]: whitened (p = N(0, I)) when K is None (pdgp.py:120-121); p = N(0, K) for an explicit
+    M x M matrix K (pdgp.py:126-129 passes kern.K(z) + jitter I)."""
     h = _lib.default_handle()
     q_mu = np.asarray(q_mu, dtype=np.float64)
     q = np.asarray(q_sqrt, dtype=np.float64)
@@ -53,8 +52,13 @@ def gauss_kl(q_mu, q_sqrt, K=None):
         q = q[:, :, 0]
     M = q_mu.shape[0]
     out = C.c_double()
-    ws = h.workspace(8192)
+    ws = h.workspace(h.lib.gp_gauss_kl_workspace_bytes(M, int(K is not None)))
     dmu, dq = h.to_device(q_mu), h.to_device(q)   # named so they outlive the call
-    h.check(h.lib.gp_gauss_kl(h.h, dmu.data_ptr(), dq.data_ptr(), M, None, None, 1e-6,
-                              C.byref(out), ws.data_ptr(), ws.numel()))
+    if K is None:
+        h.check(h.lib.gp_gauss_kl(h.h, dmu.data_ptr(), dq.data_ptr(), M, None, None, 1e-6,
+                                  C.byref(out), ws.data_ptr(), ws.numel()))
+    else:
+        dK = h.to_device(np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(M, M)))
+        h.check(h.lib.gp_gauss_kl_matrix(h.h, dmu.data_ptr(), dq.data_ptr(), M, dK.data_ptr(),
+                                         C.byref(out), ws.data_ptr(), ws.numel()))
     return out.value

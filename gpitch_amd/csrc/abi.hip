@@ -210,25 +210,73 @@ gp_status gp_mpd_varexp(gp_handle h, const double* Fmu, const double* Fvar, cons
   return s;
 }
 
+size_t gp_gauss_kl_workspace_bytes(int32_t M, int32_t with_kernel) {
+  if (M <= 0 || !with_kernel) return 4096;
+  const size_t mm = gp_align_up((size_t)M * M * sizeof(double), 256);
+  return 4096 + 2 * mm + gp_align_up((size_t)gemm_rowblocks(M, 0) * M * sizeof(double), 256) + gp_chol_workspace_bytes(M);
+}
+
+// shared body: kern != NULL builds K = kern.K(z) + jitter I; Kmat != NULL takes the caller's K (M x M, ld = M)
+static gp_status gauss_kl_impl(gp_handle h, const double* q_mu, const double* q_sqrt, int32_t M,
+                               const gp_kernel_desc* kern, const double* z, double jitter, const double* Kmat,
+                               double* out_host, void* workspace, size_t workspace_bytes, const char* who) {
+  GpArena ar(workspace, workspace_bytes);
+  const size_t item_bytes = kl_item_bytes() > klu_item_bytes() ? kl_item_bytes() : klu_item_bytes();
+  char* d_item = ar.take<char>(item_bytes);
+  GemmProblem* d_prob = ar.take<GemmProblem>(1);
+  double* d_out = ar.take<double>(4);
+  if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, who);
+  std::vector<char> item(item_bytes);
+  GemmProblem r;
+  if (kern || Kmat) {
+    // L = chol(K), W = L^-1, trace term from the column sums of (W Lq)^2
+    double* L = ar.take<double>((size_t)M * M);
+    double* W = ar.take<double>((size_t)M * M);
+    const int nrb = gemm_rowblocks(M, 0);
+    double* tr = ar.take<double>((size_t)nrb * M);
+    void* cw = ar.take<char>(gp_chol_workspace_bytes(M));
+    if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, who);
+    if (kern) {
+      GP_CHECK(gp_kuu_cholesky(h, kern, z, M, jitter, L, W, cw, gp_chol_workspace_bytes(M)));
+    } else {
+      GP_HIP_CHECK(h, hipMemcpyAsync(L, Kmat, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      GP_CHECK(launch_cholesky_single(h, L, M, M));
+      GP_CHECK(launch_tri_inverse_single(h, L, W, M, M));
+    }
+    memset(&r, 0, sizeof(r));
+    r.A = W; r.lda = M; r.B = q_sqrt; r.ldb = M; r.M = M; r.N = M; r.K = M; r.ldc = M; r.o0 = tr;
+    GP_HIP_CHECK(h, hipMemcpyAsync(d_prob, &r, sizeof(r), hipMemcpyHostToDevice, h->stream));
+    GemmFlags f;
+    f.triA = TRI_LOWER; f.triB = TRI_LOWER; f.epilogue = EPI_COLSUMSQ;
+    GP_CHECK(launch_gemm_batched(h, d_prob, 1, M, M, f));
+    klu_item_fill(item.data(), q_mu, q_sqrt, L, W, tr, nrb, M, d_out);
+    GP_HIP_CHECK(h, hipMemcpyAsync(d_item, item.data(), item.size(), hipMemcpyHostToDevice, h->stream));
+    GP_CHECK(launch_kl_unwhite(h, d_item, 1));
+  } else {
+    kl_item_fill(item.data(), q_mu, q_sqrt, M, d_out, nullptr, nullptr);
+    GP_HIP_CHECK(h, hipMemcpyAsync(d_item, item.data(), item.size(), hipMemcpyHostToDevice, h->stream));
+    GP_CHECK(launch_kl_white(h, d_item, 1));
+  }
+  GP_HIP_CHECK(h, hipMemcpyAsync(out_host, d_out, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // also keeps the host-side `r` / `item` alive long enough
+  return check_not_pd(h);
+}
+
 gp_status gp_gauss_kl(gp_handle h, const double* q_mu, const double* q_sqrt, int32_t M, const gp_kernel_desc* kern,
                       const double* z, double jitter, double* out_host, void* workspace, size_t workspace_bytes) {
   if (!h) return GP_ERR_BAD_ARG;
-  if (!q_mu || !q_sqrt || M < 1 || !out_host) return gp_fail(h, GP_ERR_BAD_ARG, "gp_gauss_kl: bad argument");
-  GpArena ar(workspace, workspace_bytes);
-  char* d_item = ar.take<char>(kl_item_bytes());
-  double* d_out = ar.take<double>(4);
-  if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, "gp_gauss_kl: workspace too small (need >= 4 KiB)");
-  if (kern) {
-    (void)z; (void)jitter;
-    return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_gauss_kl: K != None (unwhitened) not implemented yet");
-  }
-  std::vector<char> item(kl_item_bytes());
-  kl_item_fill(item.data(), q_mu, q_sqrt, M, d_out, nullptr, nullptr);
-  GP_HIP_CHECK(h, hipMemcpyAsync(d_item, item.data(), item.size(), hipMemcpyHostToDevice, h->stream));
-  GP_CHECK(launch_kl_white(h, d_item, 1));
-  GP_HIP_CHECK(h, hipMemcpyAsync(out_host, d_out, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-  return GP_OK;
+  if (!q_mu || !q_sqrt || M < 1 || !out_host || (kern && (!kern_ok(kern) || !z)))
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_gauss_kl: bad argument");
+  return gauss_kl_impl(h, q_mu, q_sqrt, M, kern, z, jitter, nullptr, out_host, workspace, workspace_bytes,
+                       "gp_gauss_kl: workspace too small (gp_gauss_kl_workspace_bytes)");
+}
+
+gp_status gp_gauss_kl_matrix(gp_handle h, const double* q_mu, const double* q_sqrt, int32_t M, const double* K,
+                             double* out_host, void* workspace, size_t workspace_bytes) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!q_mu || !q_sqrt || M < 1 || !out_host || !K) return gp_fail(h, GP_ERR_BAD_ARG, "gp_gauss_kl_matrix: bad argument");
+  return gauss_kl_impl(h, q_mu, q_sqrt, M, nullptr, nullptr, 0.0, K, out_host, workspace, workspace_bytes,
+                       "gp_gauss_kl_matrix: workspace too small (gp_gauss_kl_workspace_bytes)");
 }
 
 gp_status gp_transform_forward(gp_handle h, const double* fs, const uint8_t* tcode, int64_t n, double* params) {

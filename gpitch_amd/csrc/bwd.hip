@@ -272,6 +272,112 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   }
 }
 
+
+// Legacy broadcast-form kernel Matern12sm (matern12_spectral_mixture.py:38-56):
+//   d = x1_i - x2_j + 1e-12,  r = |d|,  K = var * exp(-r / ls) * sum_q e_q cos(2 pi f_q r).
+// Same grid and partial layout as hyper_contract_kernel; m cosines per entry, as the reference.
+template <bool GZ>
+__global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, const double* __restrict__ x1, int n1,
+                                                                 const double* __restrict__ x2, int n2,
+                                                                 const double* __restrict__ G, int64_t ldg,
+                                                                 const double* __restrict__ alpha,
+                                                                 const double* __restrict__ gm, int symmetric,
+                                                                 double* __restrict__ partials,
+                                                                 double* __restrict__ gz_part) {
+  extern __shared__ double smem[];   // e[m] | omega[m] | reduction scratch [4][max(2+2m, HY_ROWS)]
+  const double* th = k.theta;
+  const double var = th[0], ls = th[1];
+  const int m = k.m;
+  double* en = smem;
+  double* omega = smem + m;
+  double* red = smem + 2 * m;
+  if ((int)threadIdx.x < m) {
+    en[threadIdx.x] = th[2 + threadIdx.x];
+    omega[threadIdx.x] = __dmul_rn(6.283185307179586, th[2 + m + threadIdx.x]);
+  }
+  __syncthreads();
+  const int j = blockIdx.x * HY_THREADS + threadIdx.x;
+  const int i0 = blockIdx.y * HY_ROWS;
+  const int iend = min(i0 + HY_ROWS, n1);
+  const bool live = (j < n2);
+  const int jc = live ? j : n2 - 1;
+  const double xb = x2[jc];
+  const double gmj = (gm && live) ? gm[jc] : 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ns = 2 + 2 * m;
+  double acc_v = 0.0, acc_l = 0.0;
+  double acc_e[32], acc_f[32];
+#pragma unroll
+  for (int q = 0; q < 32; q++) { acc_e[q] = 0.0; acc_f[q] = 0.0; }
+  for (int i = i0; i < iend; i++) {
+    double w = 0.0;
+    if (live) {
+      w = G[(int64_t)i * ldg + j];
+      if (symmetric) w = 0.5 * (w + G[(int64_t)j * ldg + i]);
+      if (alpha) w = fma(alpha[i], gmj, w);
+    }
+    const double d = __dadd_rn(__dadd_rn(x1[i], -xb), 1e-12);
+    const double r = __dsqrt_rn(__dmul_rn(d, d));
+    // dr/dx1 = sign(d).  On the Kuu side z_i enters K_ij as x1 and K_ji as x2: the two contributions are
+    // sign(d_ij) and -sign(d_ji); they cancel on the diagonal (d_ii = +1e-12 both ways), where the generic
+    // "twice the x1 derivative" shortcut of the symmetric mode would be wrong for this kinked kernel.
+    double sg = d < 0.0 ? -1.0 : 1.0;
+    if (symmetric) {
+      const double dji = __dadd_rn(__dadd_rn(xb, -x1[i]), 1e-12);
+      sg = 0.5 * (sg - (dji < 0.0 ? -1.0 : 1.0));
+    }
+    const double E = exp(-(r / ls));
+    const double wvE = w * var * E;
+    double S = 0.0, Sf = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      if (q < m) {
+        double sn, cs;
+        sincos(__dmul_rn(omega[q], r), &sn, &cs);
+        S = fma(en[q], cs, S);
+        Sf = fma(en[q] * omega[q], sn, Sf);
+        acc_e[q] = fma(wvE, cs, acc_e[q]);
+        acc_f[q] = fma(wvE * en[q] * r, sn, acc_f[q]);
+      }
+    }
+    acc_v = fma(w * E, S, acc_v);
+    acc_l = fma(wvE * S, r / (ls * ls), acc_l);
+    if (GZ) {
+      double dz = sg * wvE * (-S / ls - Sf);
+      for (int o = 32; o > 0; o >>= 1) dz += __shfl_down(dz, o, 64);
+      if (lane == 0) red[wave * HY_ROWS + (i - i0)] = dz;
+    }
+  }
+  if (GZ) {
+    __syncthreads();
+    if (threadIdx.x < HY_ROWS && i0 + (int)threadIdx.x < n1) {
+      const int t = threadIdx.x;
+      double s = (red[0 * HY_ROWS + t] + red[1 * HY_ROWS + t]) + (red[2 * HY_ROWS + t] + red[3 * HY_ROWS + t]);
+      gz_part[(int64_t)blockIdx.x * n1 + i0 + t] = symmetric ? 2.0 * s : s;
+    }
+    __syncthreads();
+  }
+  auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+  double rv = wred(acc_v), rl = wred(acc_l);
+  if (lane == 0) { red[wave * ns + 0] = rv; red[wave * ns + 1] = rl; }
+#pragma unroll
+  for (int q = 0; q < 32; q++) {
+    if (q < m) {
+      double re = wred(acc_e[q]), rf = wred(acc_f[q]);
+      if (lane == 0) {
+        red[wave * ns + 2 + q] = re;
+        red[wave * ns + 2 + m + q] = -6.283185307179586 * rf;
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ns) {
+    const int t = threadIdx.x;
+    const double s = (red[0 * ns + t] + red[1 * ns + t]) + (red[2 * ns + t] + red[3 * ns + t]);
+    partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ns + t] = s;
+  }
+}
+
 template <int MPAD, bool SM>
 static void launch_hyper_t(gp_handle h, dim3 grid, size_t sh, DevKern k, const double* x1, int n1, const double* x2,
                            int n2, const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
@@ -287,8 +393,22 @@ static void launch_hyper_t(gp_handle h, dim3 grid, size_t sh, DevKern k, const d
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
                                 const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
                                 const double* feat, double* partials, int* nparts, double* gz_partials) {
-  if (k.type == GP_KERN_MATERN12SM) return gp_fail(h, GP_ERR_UNSUPPORTED, "gradient of Matern12sm is not implemented");
   GpTimerScope ts(h, GP_TIMER_HYPER);
+  if (k.type == GP_KERN_MATERN12SM) {
+    dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + HY_ROWS - 1) / HY_ROWS);
+    const int ns = 2 + 2 * k.m;
+    const int redw = ns > HY_ROWS ? ns : HY_ROWS;
+    const size_t sh = (2 * (size_t)k.m + 4 * (size_t)redw) * sizeof(double);
+    if (gz_partials)
+      hipLaunchKernelGGL((hyper_m12sm_kernel<true>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
+                         alpha, gm, symmetric, partials, gz_partials);
+    else
+      hipLaunchKernelGGL((hyper_m12sm_kernel<false>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
+                         alpha, gm, symmetric, partials, gz_partials);
+    GP_HIP_CHECK(h, hipGetLastError());
+    if (nparts) *nparts = grid.x * grid.y;
+    return GP_OK;
+  }
   const bool sm = (k.type == GP_KERN_MERCER_MATERN12SM);
   const int mp = sm ? sm_mpad(k.m) : 0;
   const double* f1 = feat;
@@ -371,8 +491,12 @@ gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, in
 
 // ---------------------------------------------------------------------------------------------
 // orchestration
-enum BwdSlot { S_H = 0, S_U, S_HLQ, S_E, S_EH, S_WBAR, S_LU, S_RANK1, S_R, S_ALPHA, S_G, S_T2, S_LBAR, S_P, S_T3, S_S,
+// slots below S_E are batched over all latent GPs, slots from S_E on over the GPs whose kernel gradients are needed.
+// S_QW_* / S_GQ_* / S_WB_*: unwhitened model only (see pdgp_backward).
+enum BwdSlot { S_H = 0, S_U, S_HLQ, S_QW_MU, S_QW_L, S_GQ_MU, S_GQ_L,
+               S_E, S_EH, S_WBAR, S_LU, S_RANK1, S_R, S_ALPHA, S_G, S_T2, S_LBAR, S_P, S_T3, S_S, S_WB_R1, S_WB_L,
                S_COUNT };
+static_assert(S_COUNT <= 24, "gp_pdgp_plan_s::off_bwd");
 
 static inline int64_t ldN_b(int N) { return (N + 1) & ~1; }
 
@@ -382,6 +506,8 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
   const size_t slot_bytes = gp_align_up(G * sizeof(GemmProblem), 256);
   size_t base = pdgp_kl_region_bytes(G);
   for (int s = 0; s < S_COUNT; s++) p->off_bwd[s] = base + s * slot_bytes;
+  p->off_kl2 = base + 24 * slot_bytes;
+  const bool white = p->whiten != 0;
   const int64_t ldN = ldN_b(n);
   size_t slab_off = 0;
   p->kgps.clear();
@@ -394,8 +520,12 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     const CondTask& t = p->cb.tasks[g];
     const BwdBufs& b = p->bw[g];
     const int M = q.M;
-    const double* q_mu = params + q.off_qmu;
-    const double* q_sqrt = params + q.off_qsqrt;
+    // unwhitened model: the chain runs on the equivalent whitened state q' = (W q_mu, W Lq) and its gradient
+    // buffers; pdgp_backward maps the result back (see there)
+    const double* q_mu = white ? params + q.off_qmu : b.qmu_w;
+    const double* q_sqrt = white ? params + q.off_qsqrt : b.Lq_w;
+    double* g_mu = white ? grad + q.off_qmu : b.g_qmu_w;
+    double* g_sqrt = white ? grad + q.off_qsqrt : b.g_Lq_w;
     const double* gm = p->gFmu + (size_t)g * n;
     const double* gv = p->gFvar + (size_t)g * n;
     const bool kneed = (q.need_theta || q.need_z);
@@ -413,9 +543,21 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     { GemmProblem& r = P(S_H); r.A = t.A; r.lda = ldN; r.B = t.A; r.ldb = ldN; r.K = n; r.v1 = gv; r.C = b.H;
       r.o2 = p->slabs + slab_off; slab_off += gp_align_up((size_t)p->nsplit * M * M * sizeof(double), 256) / sizeof(double);
       // fused u = A gm: partials per K-slice in o1, result in o0 and accumulated into grad q_mu (xa)
-      r.v2 = gm; r.o1 = b.upart; r.o0 = b.u; r.xa = grad + q.off_qmu; }
-    { GemmProblem& r = P(S_U); r.A = t.A; r.lda = ldN; r.N = n; r.v0 = gm; r.o0 = b.u; r.o1 = grad + q.off_qmu; }
-    { GemmProblem& r = P(S_HLQ); r.A = b.H; r.B = q_sqrt; r.C = grad + q.off_qsqrt; }
+      r.v2 = gm; r.o1 = b.upart; r.o0 = b.u; r.xa = g_mu; }
+    { GemmProblem& r = P(S_U); r.A = t.A; r.lda = ldN; r.N = n; r.v0 = gm; r.o0 = b.u; r.o1 = g_mu; }
+    { GemmProblem& r = P(S_HLQ); r.A = b.H; r.B = q_sqrt; r.C = g_sqrt; }
+    if (!white) {
+      const double* qm = params + q.off_qmu;
+      const double* qs = params + q.off_qsqrt;
+      { GemmProblem& r = P(S_QW_MU); r.A = t.W; r.v0 = qm; r.o0 = b.qmu_w; }
+      { GemmProblem& r = P(S_QW_L); r.A = t.W; r.B = qs; r.C = b.Lq_w; }
+      { GemmProblem& r = P(S_GQ_MU); r.A = t.W; r.v0 = b.g_qmu_w; r.o0 = grad + q.off_qmu; }
+      { GemmProblem& r = P(S_GQ_L); r.A = t.W; r.B = b.g_Lq_w; r.C = grad + q.off_qsqrt; }
+      { GemmProblem& r = P(S_WB_R1); r.C = b.Wbar; r.v0 = b.g_qmu_w; r.v1 = qm; }
+      { GemmProblem& r = P(S_WB_L); r.A = b.g_Lq_w; r.B = qs; r.C = b.Wbar; }
+      kl_item_fill(p->h_misc.data() + p->off_kl2 + g * kl_item_bytes(), b.qmu_w, b.Lq_w, M, p->kl_dummy + g, b.g_qmu_w,
+                   b.g_Lq_w);
+    }
     { GemmProblem& r = P(S_E); r.A = q_sqrt; r.B = q_sqrt; r.C = b.E; }
     { GemmProblem& r = P(S_EH); r.A = b.E; r.B = b.H; r.C = b.T1; }
     { GemmProblem& r = P(S_WBAR); r.A = b.T1; r.B = t.L; r.C = b.Wbar; }
@@ -439,13 +581,25 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   const int G = p->G, maxM = p->maxM;
   const int64_t ldN = ldN_b(n);
   auto D = [&](int slot) { return (const GemmProblem*)(p->d_misc + p->off_bwd[slot]); };
+  GemmFlags f;
+  const bool white = p->whiten != 0;
+  if (!white) {
+    // conditional(whiten=False) + gauss_kl(q_mu, q_sqrt, K) (pdgp.py:123-129, 147-155) is the whitened model at
+    //   q_mu' = W q_mu,  Lq' = W Lq      (W = chol(Kuu + jitter I)^-1),
+    // so the whitened chain below runs on (q_mu', Lq') with gradient buffers (g', G'), and afterwards
+    //   grad q_mu = W^T g',  grad q_sqrt = tril(W^T G'),  Wbar += tril(g' q_mu^T + G' Lq^T).
+    GP_HIP_CHECK(h, hipMemsetAsync(p->qw_block, 0, p->qw_doubles * sizeof(double), h->stream));
+    GP_CHECK(launch_matvec_batched(h, D(S_QW_MU), G, maxM, 0));
+    f = GemmFlags(); f.triA = TRI_LOWER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D(S_QW_L), G, maxM, maxM, f));
+    GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl2, G));   // accumulates -dKL/dq' into (g', G')
+  }
   // H = A diag(2 gv) A^T  (symmetric, split-K over the frames)
   GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
   // (u = A gm and grad q_mu += u are fused into the split-K product above)
   // sum_n gv  (kdiag term)
   hipLaunchKernelGGL(batched_sum_kernel, dim3(G), dim3(256), 0, h->stream, p->gFvar, (int64_t)n, n, p->bw[0].gvsum);
   GP_HIP_CHECK(h, hipGetLastError());
-  GemmFlags f;
   // grad q_sqrt += tril(H Lq)
   f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
   GP_CHECK(launch_gemm_batched(h, D(S_HLQ), G, maxM, maxM, f));
@@ -463,6 +617,11 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     GP_CHECK(launch_gemm_batched(h, D(S_WBAR), nK, maxM, maxM, f));
     GP_CHECK(launch_matvec_batched(h, D(S_LU), nK, maxM, 0));
     GP_CHECK(launch_rank1_tril_batched(h, D(S_RANK1), nK, maxM));
+    if (!white) {
+      GP_CHECK(launch_rank1_tril_batched(h, D(S_WB_R1), nK, maxM));
+      f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.beta = 1.0;
+      GP_CHECK(launch_gemm_batched(h, D(S_WB_L), nK, maxM, maxM, f));
+    }
     // R = W^T E ; alpha = W^T mu
     f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
     GP_CHECK(launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f));
@@ -482,6 +641,11 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     GP_CHECK(launch_gemm_batched(h, D(S_T3), nK, maxM, maxM, f));
     f = GemmFlags(); f.triB = TRI_LOWER;
     GP_CHECK(launch_gemm_batched(h, D(S_S), nK, maxM, maxM, f));
+  }
+  if (!white) {
+    GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D(S_GQ_L), G, maxM, maxM, f));
   }
   // hyper-parameter and inducing-input gradients
   for (int g : p->kgps) {

@@ -21,6 +21,10 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
     add(colblocks * M + ((M + 255) / 256 + 1) * M);
   }
   add(p->G + 8);
+  if (!p->whiten) {
+    for (int g = 0; g < p->G; g++) { const size_t M = p->gps[g].M; add(2 * (M + M * M) + 8); }
+    add(p->G + 8);
+  }
   return d;
 }
 
@@ -87,7 +91,7 @@ gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t*
 }
 
 static size_t pdgp_misc_bytes(const gp_pdgp_plan_s* p) {
-  return pdgp_kl_region_bytes(p->G) + 16 * gp_align_up(p->G * sizeof(GemmProblem), 256);
+  return 2 * pdgp_kl_region_bytes(p->G) + 24 * gp_align_up(p->G * sizeof(GemmProblem), 256);
 }
 
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
@@ -100,7 +104,7 @@ size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   addd(2 * ((size_t)(p->maxN + 255) / 256) + 8);
   if (!p->whiten)
     for (int g = 0; g < p->G; g++) addd((size_t)gemm_rowblocks(p->gps[g].M, 0) * p->gps[g].M);
-  if (p->whiten) {
+  {
     d += pdgp_bwd_doubles(p);
     int ns = gemm_nt_nsplit(p->maxM, p->maxN, p->G);
     if (ns < 2) ns = 2;
@@ -138,7 +142,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
   p->tr_part.assign(p->G, nullptr);
   if (!p->whiten)
     for (int g = 0; g < p->G; g++) p->tr_part[g] = ar.take<double>((size_t)gemm_rowblocks(p->gps[g].M, 0) * p->gps[g].M);
-  if (p->whiten) {
+  {
     p->nsplit = gemm_nt_nsplit(p->maxM, p->maxN, p->G);
     if (p->nsplit < 2) p->nsplit = 2;
     for (int g = 0; g < p->G; g++) {
@@ -162,6 +166,19 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
     size_t slab_total = 0;
     for (int g = 0; g < p->G; g++) slab_total += gp_align_up((size_t)p->nsplit * p->gps[g].M * p->gps[g].M * sizeof(double), 256) / sizeof(double);
     p->slabs = ar.take<double>(slab_total);
+    if (!p->whiten) {
+      auto ev = [](size_t c) { return (c + 1) & ~(size_t)1; };   // keep every piece 16-byte aligned
+      size_t tot = 0;
+      for (int g = 0; g < p->G; g++) { const size_t M = p->gps[g].M; tot += 2 * (ev(M) + ev(M * M)); }
+      p->qw_block = ar.take<double>(tot); p->qw_doubles = tot;
+      double* c = p->qw_block;
+      for (int g = 0; g < p->G && c; g++) {
+        const size_t M = p->gps[g].M;
+        BwdBufs& b = p->bw[g];
+        b.qmu_w = c; c += ev(M); b.Lq_w = c; c += ev(M * M); b.g_qmu_w = c; c += ev(M); b.g_Lq_w = c; c += ev(M * M);
+      }
+      p->kl_dummy = ar.take<double>(p->G + 8);
+    }
   }
   if (!ar.ok) return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_pdgp_set_workspace: arena exhausted");
   p->last_params = nullptr; p->last_n = -1;
@@ -197,7 +214,6 @@ static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x
   // KL items
   p->h_misc.assign(p->misc_bytes, 0);
   p->off_kl_items = 0;
-  const size_t kl_region = pdgp_kl_region_bytes(p->G);
   for (int g = 0; g < p->G; g++) {
     const PdgpGP& q = p->gps[g];
     const CondTask& t = p->cb.tasks[g];
@@ -207,14 +223,14 @@ static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x
     } else {
       klu_item_fill(p->h_misc.data() + p->off_kl_items + g * klu_item_bytes(), params + q.off_qmu, params + q.off_qsqrt,
                     t.L, t.W, p->tr_part[g], gemm_rowblocks(q.M, 0), q.M, p->kl + g);
-      // trace term: column sums of squares of W Lq (first problem slot after the KL items)
-      GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + kl_region + g * sizeof(GemmProblem));
+      // trace term: column sums of squares of W Lq (its own descriptor slot, after the backward ones)
+      GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + pdgp_kltr_offset(p->G) + g * sizeof(GemmProblem));
       memset(&r, 0, sizeof(r));
       r.A = t.W; r.lda = q.M; r.B = params + q.off_qsqrt; r.ldb = q.M; r.M = q.M; r.N = q.M; r.K = q.M; r.ldc = q.M;
       r.o0 = p->tr_part[g];
     }
   }
-  if (grad && p->whiten) GP_CHECK(pdgp_upload_bwd(p, params, x, n, grad));
+  if (grad) GP_CHECK(pdgp_upload_bwd(p, params, x, n, grad));
   GP_HIP_CHECK(h, hipMemcpyAsync(p->d_misc, p->h_misc.data(), p->misc_bytes, hipMemcpyHostToDevice, h->stream));
   p->last_params = params; p->last_x = x; p->last_n = n; p->last_grad = grad;
   return GP_OK;
@@ -239,10 +255,9 @@ static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double
     GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl_items, p->G));
   } else {
     // gauss_kl(q_mu, q_sqrt, K = Kuu + jitter I) (pdgp.py:123-129): L and W of the conditional are reused
-    const size_t kl_region = pdgp_kl_region_bytes(p->G);
     GemmFlags f;
     f.triA = TRI_LOWER; f.triB = TRI_LOWER; f.epilogue = EPI_COLSUMSQ;
-    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(p->d_misc + kl_region), p->G, p->maxM, p->maxM, f));
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(p->d_misc + pdgp_kltr_offset(p->G)), p->G, p->maxM, p->maxM, f));
     GP_CHECK(launch_kl_unwhite(h, p->d_misc + p->off_kl_items, p->G));
   }
   if (xchg) GP_CHECK(launch_finish_sum(h, p->kl, p->G, 1, 1, xchg + 3 * (size_t)n, 1.0, 0));
@@ -272,7 +287,6 @@ gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, co
   gp_handle h = p->h;
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo: workspace not set");
   if (!params || !x || !y || !elbo_dev || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo: bad argument");
-  if (grad && !p->whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo: gradient needs whiten=1");
   GP_CHECK(pdgp_forward(p, params, x, y, n, grad, nullptr));
   return pdgp_finish(p, params, x, y, n, num_data, nullptr, elbo_dev, elbo_host, grad);
 }
@@ -283,7 +297,6 @@ gp_status gp_pdgp_elbo_begin(gp_pdgp_plan p, const double* params, const double*
   gp_handle h = p->h;
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo_begin: workspace not set");
   if (!params || !x || !y || !exchange || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo_begin: bad argument");
-  if (grad && !p->whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_pdgp_elbo_begin: gradient needs whiten=1");
   p->staged_n = 0;
   GP_CHECK(pdgp_forward(p, params, x, y, n, grad, exchange));
   p->staged_n = n; p->staged_grad = grad; p->staged_params = params;

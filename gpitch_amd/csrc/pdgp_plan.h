@@ -7,6 +7,11 @@ static inline size_t pdgp_kl_region_bytes(int G) {
   return gp_align_up((size_t)G * (a > b ? a : b), 256);
 }
 
+// descriptor slot (of 24) holding the trace-term problems of the unwhitened KL
+static inline size_t pdgp_kltr_offset(int G) {
+  return pdgp_kl_region_bytes(G) + 23 * gp_align_up((size_t)G * sizeof(GemmProblem), 256);
+}
+
 struct PdgpGP {
   int M = 0, ktype = 0, m = 0;
   int need_theta = 1, need_z = 1;   // gp_pdgp_set_grad_needs
@@ -29,6 +34,9 @@ struct BwdBufs {  // per-GP backward workspace (device)
   double* hyp_part_uu = nullptr;
   double* gz_part = nullptr;    // z-gradient partials
   double* gvsum = nullptr;      // sum_n gv
+  // unwhitened model only: the equivalent whitened variational state q' = (W q_mu, W Lq) and its gradient
+  double* qmu_w = nullptr; double* Lq_w = nullptr;       // M, M x M
+  double* g_qmu_w = nullptr; double* g_Lq_w = nullptr;   // M, M x M
 };
 
 struct gp_pdgp_plan_s {
@@ -51,7 +59,10 @@ struct gp_pdgp_plan_s {
   char* d_misc = nullptr; size_t misc_bytes = 0;     // KL items + backward problem arrays
   std::vector<char> h_misc;
   size_t off_kl_items = 0;
-  size_t off_bwd[16] = {0};
+  size_t off_bwd[24] = {0};
+  size_t off_kl2 = 0;         // unwhitened backward: KL items of the equivalent whitened state
+  double* qw_block = nullptr; size_t qw_doubles = 0;   // [q' | grad q'] of all GPs, contiguous (one memset)
+  double* kl_dummy = nullptr;
   int nsplit = 1;
   int nK = 0;                 // number of GPs whose kernel gradients are needed (compacted batch)
   std::vector<int> kgps;      // their indices

@@ -110,10 +110,16 @@ gp_status gp_conditional_diag(gp_handle h, const gp_kernel_desc* kern, const dou
                               void* workspace, size_t workspace_bytes);
 
 /* gpflow.kullback_leiblers.gauss_kl(q_mu, q_sqrt, K=None) (pdgp.py:120-121 whitened; :126-129 with
- * K = kern.K(z) + jitter I built internally when kern != NULL).  Result to *out_host (syncs). */
+ * K = kern.K(z) + jitter I built internally when kern != NULL).  Result to *out_host (syncs).
+ * workspace: gp_gauss_kl_workspace_bytes(M, kern != NULL). */
+size_t gp_gauss_kl_workspace_bytes(int32_t M, int32_t with_kernel);
 gp_status gp_gauss_kl(gp_handle h, const double* q_mu, const double* q_sqrt, int32_t M,
                       const gp_kernel_desc* kern_or_null, const double* z, double jitter,
                       double* out_host, void* workspace, size_t workspace_bytes);
+/* the same with the caller's own prior covariance: gauss_kl(q_mu, q_sqrt, K) for a device matrix K (M x M,
+ * row-major, ld = M, symmetric positive definite; not modified).  GP_ERR_NOT_PD when its Cholesky fails. */
+gp_status gp_gauss_kl_matrix(gp_handle h, const double* q_mu, const double* q_sqrt, int32_t M, const double* K,
+                             double* out_host, void* workspace, size_t workspace_bytes);
 
 /* MpdLik.variational_expectations(Fmu, Fvar, Y) (likelihoods.py:422-447 + hermgauss1d :33-45 +
  * log_lik_exp :47-68).  Fmu/Fvar are N x 2P row-major with columns [g_0..g_{P-1}, f_0..f_{P-1}]
@@ -129,7 +135,7 @@ gp_status gp_mpd_varexp(gp_handle h, const double* Fmu, const double* Fvar, cons
  * The same layout is used for the gradient vector, the free-state vector and the Adam moments. */
 typedef struct {
   int32_t num_sources;            /* P */
-  int32_t whiten;                 /* pdgp.py:49 (only whiten=1 has a backward pass) */
+  int32_t whiten;                 /* pdgp.py:49  */
   int32_t nlin;                   /* GP_NLIN_* (pdgp.py:49 nlinfun) */
   int32_t max_batch;              /* largest minibatch N the plan will see */
   const int32_t* M_act;           /* host, P entries (pdgp.py:93) */

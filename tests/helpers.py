@@ -44,7 +44,7 @@ def oracle_elbo(prob, whiten=True, nlin_code=0, xp=None):
                          prob["noise_var"], whiten=whiten, nlin_code=nlin_code, xp=xp)
 
 
-def oracle_elbo_and_grads(prob, nlin_code=0):
+def oracle_elbo_and_grads(prob, nlin_code=0, whiten=True):
     """ELBO and its gradient w.r.t. every constrained parameter by torch-CPU autograd through the
     oracle's restatement (mirrors TF reverse-mode)."""
     import torch
@@ -71,7 +71,7 @@ def oracle_elbo_and_grads(prob, nlin_code=0):
     qsa = [leaves.setdefault("q_sqrt_act%d" % i, T(prob["q_sqrt_act"][i])) for i in range(P)]
     qsc = [leaves.setdefault("q_sqrt_com%d" % i, T(prob["q_sqrt_com"][i])) for i in range(P)]
     x = torch.tensor(prob["x"]); y = torch.tensor(prob["y"])
-    elbo = orc.pdgp_elbo(x, y, za, zc, ka, kc, qma, qsa, qmc, qsc, leaves["noise"], whiten=True,
+    elbo = orc.pdgp_elbo(x, y, za, zc, ka, kc, qma, qsa, qmc, qsc, leaves["noise"], whiten=whiten,
                          nlin_code=nlin_code, xp=tb)
     elbo.backward()
     return float(elbo.detach()), {k: (v.grad.numpy().copy() if v.grad is not None else None) for k, v in leaves.items()}

@@ -139,6 +139,45 @@ def test_mpd_varexp_matches_oracle(gp_handle, nlin, P):
     assert abs(s.value - ref.sum()) <= 1e-11 * abs(ref.sum())
 
 
+@pytest.mark.parametrize("ktype", ["matern32", "mercer_matern12sm"])
+def test_gauss_kl_with_prior_covariance(gp_handle, ktype):
+    """gauss_kl(q_mu, q_sqrt, K) with K = kern.K(z) + jitter I (pdgp.py:126-129): through the kernel descriptor
+    (gp_gauss_kl), through an explicit matrix (gp_gauss_kl_matrix) and through the Python mirror."""
+    from gpitch_amd.conditionals import gauss_kl
+    h = gp_handle
+    M = 45
+    rng = np.random.RandomState(5)
+    z = (np.linspace(0, 0.05, M) + 2e-4 * rng.rand(M)).reshape(-1, 1)
+    q_mu = rng.randn(M, 1)
+    q_sqrt = (np.eye(M) + 0.1 * rng.randn(M, M))[:, :, None]
+    if ktype == "matern32":
+        kd = {"type": "matern32", "variance": 1.3, "lengthscales": 0.02, "energy": [], "frequency": []}
+    else:
+        kd = {"type": "mercer_matern12sm", "variance": 0.9, "lengthscales": 0.05, "energy": [0.5, 0.3, 0.2],
+              "frequency": [110.0, 220.0, 330.0]}
+    K = orc.K(kd, z) + 1e-6 * np.eye(M)
+    ref = float(orc.gauss_kl(q_mu, q_sqrt, K))
+    desc, keep = _desc(h, kd)
+    out = C.c_double()
+    ws = h.workspace(h.lib.gp_gauss_kl_workspace_bytes(M, 1))
+    dmu, dsq, dz = h.to_device(q_mu), h.to_device(q_sqrt[:, :, 0]), h.to_device(z)
+    h.check(h.lib.gp_gauss_kl(h.h, dmu.data_ptr(), dsq.data_ptr(), M, C.byref(desc), dz.data_ptr(), 1e-6,
+                              C.byref(out), ws.data_ptr(), ws.numel()))
+    assert abs(out.value - ref) <= 1e-8 * abs(ref), (out.value, ref)
+    dK = h.to_device(K)
+    out2 = C.c_double()
+    h.check(h.lib.gp_gauss_kl_matrix(h.h, dmu.data_ptr(), dsq.data_ptr(), M, dK.data_ptr(), C.byref(out2),
+                                     ws.data_ptr(), ws.numel()))
+    assert abs(out2.value - ref) <= 1e-8 * abs(ref)
+    assert abs(gauss_kl(q_mu, q_sqrt, K) - ref) <= 1e-8 * abs(ref)
+    # not positive definite -> status, not a wrong number
+    bad = K.copy(); bad[3, 3] = -1.0
+    dB = h.to_device(bad)
+    with pytest.raises(Exception):
+        h.check(h.lib.gp_gauss_kl_matrix(h.h, dmu.data_ptr(), dsq.data_ptr(), M, dB.data_ptr(), C.byref(out2),
+                                         ws.data_ptr(), ws.numel()))
+
+
 def test_gauss_kl_whitened(gp_handle):
     h = gp_handle
     M = 77
