@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "gp_pdgp_set_workspace", "gp_pdgp_set_grad_needs", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_predict",
     "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace",
-    "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
+    "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
 ]
 
@@ -121,6 +121,8 @@ def load_library():
         "gp_sgpr_set_workspace": (i32, [vp, vp, sz]),
         "gp_sgpr_bound": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl)]),
         "gp_sgpr_bound_grad": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl), vp]),
+        "gp_sgpr_set_graphs": (i32, [vp, i32]),
+        "gp_sgpr_eval_counts": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
         "gp_sgpr_predict_f": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
         "gp_sgpr_predict_source_workspace_bytes": (sz, [i32, i32]),
         "gp_sgpr_predict_source": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, sz]),
@@ -147,7 +149,9 @@ class Handle(object):
     """One (process, GPU) library handle — replaces gpitch.init_settings / the global TF session
     (gpitch/methods.py:155-180)."""
 
-    def __init__(self, device_id=0, use_torch_stream=True):
+    def __init__(self, device_id=0, use_torch_stream=True, stream=None):
+        """stream: a torch.cuda.Stream the library launches on (the caller keeps torch's current stream on it, e.g.
+        `with torch.cuda.stream(s):`, so that copies and kernels stay ordered); default: torch's current stream."""
         import torch
         self.lib = load_library()
         if not torch.cuda.is_available():
@@ -156,7 +160,11 @@ class Handle(object):
         self.torch = torch
         self.device = torch.device("cuda", device_id)
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
+        self.stream = stream
+        if stream is not None:
+            stream = stream.cuda_stream
+        else:
+            stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
         h = C.c_void_p()
         st = self.lib.gp_create(device_id, C.c_void_p(stream) if stream else None, C.byref(h))
         if st != GP_OK:

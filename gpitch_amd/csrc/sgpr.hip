@@ -26,9 +26,29 @@ struct gp_sgpr_plan_s {
   double *scal = nullptr;   // [0] bound, [1] sum err^2, [2] sum colsumsq(A'), [3] kdiag total per point, [4] dF/dkd, [5] dF/ds
   char* d_desc = nullptr; std::vector<char> h_desc[2];   // two descriptor blocks (training pass / prediction pass)
   int nsplit = 2;
+  // bound+gradient evaluations are launch-bound at window sizes (N ~ 2001): once the device descriptors match
+  // the argument pointers the whole kernel sequence is captured into a hipGraph and replayed (L-BFGS-B calls it
+  // dozens of times per window with the same buffers)
+  struct EvalKey {
+    const double *params = nullptr, *X = nullptr, *Y = nullptr, *Z = nullptr; double *grad = nullptr; int N = -1;
+    bool operator==(const EvalKey& o) const {
+      return params == o.params && X == o.X && Y == o.Y && Z == o.Z && grad == o.grad && N == o.N;
+    }
+  };
+  EvalKey desc_key; bool desc_valid = false;   // what descriptor slots 0/1 on the device currently describe
+  EvalKey graph_key; hipGraphExec_t gexec = nullptr;
+  bool skip_upload = false;                    // set while re-enqueueing with valid device descriptors
+  int graphs = 1;                              // gp_sgpr_set_graphs
+  int64_t n_eager = 0, n_captured = 0, n_replayed = 0;
+  ~gp_sgpr_plan_s() { if (gexec) (void)hipGraphExecDestroy(gexec); }
 };
 
 static inline int64_t ldN64(int N) { return (N + 1) & ~1; }
+// any other entry point rewrites the device descriptor blocks the recorded graph reads
+static inline void sg_invalidate(gp_sgpr_plan_s* p) {
+  p->desc_valid = false;
+  if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+}
 static const size_t SG_DESC_BYTES = 16 * 1024;
 
 // ---- small kernels ----------------------------------------------------------------------------------
@@ -195,6 +215,7 @@ size_t gp_sgpr_workspace_bytes(gp_sgpr_plan p) { return p ? sgpr_ws_doubles(p) *
 
 gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   if (!p) return GP_ERR_BAD_ARG;
+  sg_invalidate(p);
   if (!workspace || bytes < gp_sgpr_workspace_bytes(p) || (((uintptr_t)workspace) & 255))
     return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: workspace too small or not 256-byte aligned");
   GpArena ar(workspace, bytes);
@@ -242,7 +263,8 @@ static gp_status sg_upload(gp_sgpr_plan p, const std::vector<GemmProblem>& probs
   memcpy(hd.data(), probs.data(), nb);
   int* hi = (int*)(hd.data() + off_int);
   for (int i = 0; i < p->P; i++) { hi[i] = (int)p->off_theta[i]; hi[256 + i] = p->ktype[i]; hi[512 + i] = p->m[i]; }
-  GP_HIP_CHECK(p->h, hipMemcpyAsync(dd, hd.data(), SG_DESC_BYTES, hipMemcpyHostToDevice, p->h->stream));
+  if (!p->skip_upload)
+    GP_HIP_CHECK(p->h, hipMemcpyAsync(dd, hd.data(), SG_DESC_BYTES, hipMemcpyHostToDevice, p->h->stream));
   out->probs = (GemmProblem*)dd;
   out->toff = (int*)(dd + off_int); out->ktype = out->toff + 256; out->km = out->toff + 512;
   return GP_OK;
@@ -353,14 +375,12 @@ extern "C" {
 
 /* gradient of the collapsed bound w.r.t. [noise_var | theta_0 | ... ] (what TF autodiff hands to L-BFGS-B in
  * SGPRSS.optimize: transcription.py:283, separation.py:298).  Z is a DataHolder (sgpr_ss.py:26): no gradient. */
-gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
-                             const double* Z, double* bound_dev, double* bound_host, double* grad) {
-  if (!p) return GP_ERR_BAD_ARG;
+}  // extern "C"
+
+// every launch of one bound + gradient evaluation, in stream order (no host synchronisation inside)
+static gp_status sgpr_enqueue_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N,
+                                         const double* Z, double* grad) {
   gp_handle h = p->h;
-  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_bound_grad: workspace not set");
-  if (!params || !X || !Y || !Z || !grad || N < 1 || N > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound_grad: bad argument");
-  for (int i = 0; i < p->P; i++)
-    if (p->ktype[i] == GP_KERN_MATERN12SM) return gp_fail(h, GP_ERR_UNSUPPORTED, "gradient of Matern12sm is not implemented");
   SgDesc d;
   GP_CHECK(sgpr_common(p, params, X, Y, N, Z, &d));
   const int M = p->M;
@@ -439,6 +459,70 @@ gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double*
   }
   if (p->reg) hipLaunchKernelGGL(sgpr_reg_grad_kernel, dim3(1), dim3(256), 0, h->stream, params, grad, d.toff, p->P);
   GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+extern "C" {
+
+gp_status gp_sgpr_set_graphs(gp_sgpr_plan p, int32_t enable) {
+  if (!p) return GP_ERR_BAD_ARG;
+  p->graphs = enable ? 1 : 0;
+  if (!enable && p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+  return GP_OK;
+}
+
+gp_status gp_sgpr_eval_counts(gp_sgpr_plan p, int64_t* eager, int64_t* captured, int64_t* replayed) {
+  if (!p) return GP_ERR_BAD_ARG;
+  if (eager) *eager = p->n_eager;
+  if (captured) *captured = p->n_captured;
+  if (replayed) *replayed = p->n_replayed;
+  return GP_OK;
+}
+
+gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                             const double* Z, double* bound_dev, double* bound_host, double* grad) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_bound_grad: workspace not set");
+  if (!params || !X || !Y || !Z || !grad || N < 1 || N > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound_grad: bad argument");
+  gp_sgpr_plan_s::EvalKey key;
+  key.params = params; key.X = X; key.Y = Y; key.Z = Z; key.grad = grad; key.N = N;
+  // capture needs a real stream (not the legacy null stream) and no event timers inside the sequence
+  const bool can_graph = p->graphs && h->stream != nullptr && !h->timers_on;
+  if (can_graph && p->gexec && key == p->graph_key) {
+    GP_HIP_CHECK(h, hipGraphLaunch(p->gexec, h->stream));
+    p->n_replayed++;
+  } else if (can_graph && p->desc_valid && key == p->desc_key) {
+    // second evaluation with the same buffers: the descriptors are on the device already, record the launches
+    if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+    hipGraph_t graph = nullptr;
+    GP_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    p->skip_upload = true;
+    gp_status st = sgpr_enqueue_bound_grad(p, params, X, Y, N, Z, grad);
+    p->skip_upload = false;
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (st != GP_OK || e != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      p->graphs = 0;                       // fall back to eager launches for the rest of this plan's life
+      p->desc_valid = false;
+      GP_CHECK(sgpr_enqueue_bound_grad(p, params, X, Y, N, Z, grad));
+      p->desc_key = key; p->desc_valid = true;
+      p->n_eager++;
+    } else {
+      e = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) { p->gexec = nullptr; return gp_fail(h, GP_ERR_HIP, "hipGraphInstantiate failed"); }
+      p->graph_key = key;
+      GP_HIP_CHECK(h, hipGraphLaunch(p->gexec, h->stream));
+      p->n_captured++;
+    }
+  } else {
+    p->desc_valid = false;
+    GP_CHECK(sgpr_enqueue_bound_grad(p, params, X, Y, N, Z, grad));
+    p->desc_key = key; p->desc_valid = true;
+    p->n_eager++;
+  }
   if (bound_dev) GP_HIP_CHECK(h, hipMemcpyAsync(bound_dev, p->scal, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (bound_host) {
     GP_HIP_CHECK(h, hipMemcpyAsync(bound_host, p->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -455,6 +539,7 @@ gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, c
                         const double* Z, double* bound_dev, double* bound_host) {
   if (!p) return GP_ERR_BAD_ARG;
   gp_handle h = p->h;
+  sg_invalidate(p);
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_bound: workspace not set");
   if (!params || !X || !Y || !Z || N < 1 || N > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound: bad argument");
   SgDesc d;
@@ -471,6 +556,7 @@ gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* 
                             const double* Z, const double* Xnew, int32_t n, double* mean, double* var) {
   if (!p) return GP_ERR_BAD_ARG;
   gp_handle h = p->h;
+  sg_invalidate(p);
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_predict_f: workspace not set");
   if (!params || !X || !Y || !Z || !Xnew || !mean || !var || N < 1 || N > p->maxN || n < 1 || n > p->maxN)
     return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_predict_f: bad argument");
@@ -518,6 +604,7 @@ gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const dou
                                  size_t workspace_bytes) {
   if (!p) return GP_ERR_BAD_ARG;
   gp_handle h = p->h;
+  sg_invalidate(p);
   if (!params || !X || !Y || !Xnew || !mean || !var || N < 1 || n < 1)
     return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_predict_source: bad argument");
   if (!workspace || workspace_bytes < gp_sgpr_predict_source_workspace_bytes(N, n) || (((uintptr_t)workspace) & 255))

@@ -75,17 +75,28 @@ class SGPRSS(Parameterized):
         self._nparams = int(h.lib.gp_sgpr_num_params(plan))
         self._bound_dev = h.zeros(1)
 
-    def _pack(self):
+    def _dev(self, name, host):
+        """device copy of `host` in a buffer that is reused while the size stays the same: stable pointers let the
+        engine keep its descriptors and replay the recorded evaluation graph across evaluations and windows"""
         h = self._handle
+        host = np.ascontiguousarray(np.asarray(host, dtype=np.float64).reshape(-1))
+        cur = self.__dict__.get(name)
+        if cur is None or cur.numel() != host.size or cur.device != h.device:
+            cur = h.empty(host.size)
+            object.__setattr__(self, name, cur)
+        cur.copy_(h.torch.as_tensor(host))
+        return cur
+
+    def _pack(self):
         vec = [self.likelihood.variance.value.reshape(-1)]
         for k in self.kern.kern_list:
             vec.append(k.theta())
         host = np.concatenate(vec)
         assert host.size == self._nparams
-        self._params = h.to_device(host)
-        self._Xd = h.to_device(self.X._array.reshape(-1))
-        self._Yd = h.to_device(self.Y._array.reshape(-1))
-        self._Zd = h.to_device(self.Z._array.reshape(-1))
+        self._dev("_params", host)
+        self._dev("_Xd", self.X._array)
+        self._dev("_Yd", self.Y._array)
+        self._dev("_Zd", self.Z._array)
 
     def build_likelihood(self):
         """the bound on the marginal likelihood (sgpr_ss.py:29-71)"""
@@ -152,8 +163,11 @@ class SGPRSS(Parameterized):
         vals = np.array([p.value[0] for p in ps])
         for j, i in enumerate(free_idx):
             vals[i] = ps[i].transform.forward(np.array([x_free[j]]))[0]
-        self._params = h.to_device(vals)
-        grad = h.zeros(self._nparams)
+        self._dev("_params", vals)
+        grad = self.__dict__.get("_grad_dev")
+        if grad is None or grad.numel() != self._nparams:
+            grad = h.empty(self._nparams)
+            object.__setattr__(self, "_grad_dev", grad)
         out = C.c_double()
         h.check(h.lib.gp_sgpr_bound_grad(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
                                          self.X.shape[0], self._Zd.data_ptr(), self._bound_dev.data_ptr(), C.byref(out),

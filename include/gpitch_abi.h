@@ -230,6 +230,14 @@ gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, c
  * transcription.py:283, separation.py:298).  grad has gp_sgpr_num_params entries. */
 gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                              const double* Z, double* bound_dev, double* bound_host, double* grad);
+
+/* gp_sgpr_bound_grad is launch-bound at window sizes (N ~ 2001, ~50 small kernels), and L-BFGS-B calls it dozens
+ * of times per window with the same buffers: from the second call with identical pointer arguments the launch
+ * sequence is recorded into a hipGraph and replayed.  Needs a handle created on a real stream (the legacy null
+ * stream cannot be captured) and timers off; otherwise the launches stay eager.  enable = 0 turns it off.
+ * gp_sgpr_eval_counts reports how many evaluations ran eagerly / were captured / were replayed. */
+gp_status gp_sgpr_set_graphs(gp_sgpr_plan p, int32_t enable);
+gp_status gp_sgpr_eval_counts(gp_sgpr_plan p, int64_t* eager, int64_t* captured, int64_t* replayed);
 /* GPflow SGPR.build_predict (predict_f; separation.py:306) at Xnew: mean, var (n values each) */
 gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                             const double* Z, const double* Xnew, int32_t n, double* mean, double* var);

@@ -132,3 +132,76 @@ def test_sgpr_optimize_increases_bound(gp_handle):
     b1 = m.build_likelihood()
     assert b1 > b0 and np.isfinite(res.fun) and abs(-res.fun - b1) <= 1e-8 * abs(b1)
     assert m.kern.kern_list[0].lengthscales.value[0] == kl[0]["lengthscales"]
+
+
+def test_fit_windows_streams_match_sequential_loop(gp_handle):
+    """gpitch_amd.windows.fit_windows (the AMT / SoSp window loop, transcription.py:265-288) on several HIP
+    streams: every window's result equals a plain sequential loop over the same windows, whatever the number of
+    streams, and overlap-added per-window predictions can be produced from the worker."""
+    from gpitch_amd.windows import fit_windows, default_reset
+    nwin, N, M, P = 6, 400, 20, 2
+    probs = [_problem(N, M, P, seed=20 + w) for w in range(nwin)]
+    X0, Y0, Z0, kl0 = probs[0]
+    make = lambda h: _model(X0, Y0, Z0, kl0, 1.0, h)
+    wins = [(p[0], 20. * p[1], p[2]) for p in probs]          # transcription.py:255 scales y by 20
+
+    def after(model, idx):
+        mean, var = model.predict_f(wins[idx][0][::50])
+        return {"bound": model.build_likelihood(), "var": np.array([k.variance.value[0] for k in model.kern.kern_list]),
+                "noise": model.likelihood.variance.value[0], "mean": mean}
+
+    # sequential reference loop on the test's own handle
+    seq = []
+    for idx, (x, y, z) in enumerate(wins):
+        m = make(gp_handle)
+        default_reset(m, x, y, z)
+        m.optimize(maxiter=8)
+        seq.append(after(m, idx))
+    for ns in (1, 3):
+        got = fit_windows(make, wins, maxiter=8, num_streams=ns, after_fit=after)
+        assert len(got) == nwin
+        for a, b in zip(got, seq):
+            assert abs(a["bound"] - b["bound"]) <= 1e-9 * abs(b["bound"])
+            np.testing.assert_allclose(a["var"], b["var"], rtol=1e-8)
+            np.testing.assert_allclose(a["mean"], b["mean"], rtol=1e-7, atol=1e-9)
+    # windows dealt over two ranks: each rank returns its own, None elsewhere
+    r0 = fit_windows(make, wins, maxiter=2, num_streams=2, rank=0, world_size=2)
+    r1 = fit_windows(make, wins, maxiter=2, num_streams=2, rank=1, world_size=2)
+    assert [r is not None for r in r0] == [True, False] * 3 and [r is not None for r in r1] == [False, True] * 3
+    assert r0[0]["bound"] > -1e300 and r0[0]["nfev"] >= 1
+
+
+def test_sgpr_graph_replay_is_bitwise_eager():
+    """gp_sgpr_bound_grad records its launch sequence into a hipGraph from the second call with the same buffers
+    (handle on its own stream): replayed evaluations must reproduce the eager ones bit for bit, also after the
+    parameters change in place and after a prediction call invalidated the recording."""
+    import ctypes as C
+    import torch
+    from gpitch_amd import _lib
+    X, Y, Z, kl = _problem(700, 24, 2, seed=31)
+    eager_model = _model(X, Y, Z, kl, 0.7, _lib.default_handle())     # null stream: never captured
+    eager_model._compile(); eager_model._pack()
+    ps = eager_model._param_list()
+    x0 = np.array([p.transform.backward(p.value)[0] for p in ps if not p.fixed])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        h = _lib.Handle(torch.cuda.current_device(), stream=s)
+        m = _model(X, Y, Z, kl, 0.7, h)
+        m._compile(); m._pack()
+        for step in range(5):
+            xs = x0 + 0.01 * step
+            f_e, g_e = eager_model._objective(xs)
+            f_g, g_g = m._objective(xs)
+            assert f_e == f_g and np.array_equal(g_e, g_g), step
+        m.predict_f(X[::10])                      # rewrites a descriptor block -> recording dropped, re-captured
+        for step in range(3):
+            xs = x0 - 0.02 * step
+            f_e, g_e = eager_model._objective(xs)
+            f_g, g_g = m._objective(xs)
+            assert f_e == f_g and np.array_equal(g_e, g_g), step
+        c = [C.c_int64() for _ in range(3)]
+        h.check(h.lib.gp_sgpr_eval_counts(m._plan, *[C.byref(v) for v in c]))
+        assert c[1].value == 2 and c[2].value == 4 and c[0].value == 2, [v.value for v in c]
+        m._destroy()
+        s.synchronize()
+        h.close()

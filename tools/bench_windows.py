@@ -1,0 +1,80 @@
+"""Window-fit throughput: SGPRSS fits of many small windows (ws = 2001 frames), the way
+transcription.py:265-288 loops them, sequentially and with several HIP streams."""
+import argparse, os, sys, time, threading
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_windows(nwin, ws, M, P, m, seed=0):
+    from gpitch_amd.synth import make_problem
+    out = []
+    for w in range(nwin):
+        prob = make_problem(ws, M, P, num_partials=m, seed=seed + w)
+        out.append((prob["x"], prob["y"], prob["zc"][0], prob))
+    return out
+
+
+def build_model(prob, handle):
+    import gpitch_amd
+    from gpitch_amd.kernels import Add
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm
+    from gpitch_amd.sgpr_ss import SGPRSS
+    ks = [MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=1.0,
+                           lengthscales=d["lengthscales"]) for d in prob["kern_com"]]
+    return SGPRSS(prob["x"], prob["y"], Add(ks), prob["zc"][0], handle=handle)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nwin", type=int, default=16)
+    ap.add_argument("--ws", type=int, default=2001)
+    ap.add_argument("--M", type=int, default=64)
+    ap.add_argument("--P", type=int, default=3)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--maxiter", type=int, default=10)
+    ap.add_argument("--streams", type=int, nargs="+", default=[1, 2, 4, 8])
+    args = ap.parse_args()
+    import torch
+    from gpitch_amd import _lib
+    wins = make_windows(args.nwin, args.ws, args.M, args.P, args.m)
+    import ctypes as C
+
+    def time_eval(h, label):
+        model = build_model(wins[0][3], h)
+        model._compile(); model._pack()
+        ps = model._param_list()
+        x0 = np.array([p.transform.backward(p.value)[0] for p in ps if not p.fixed])
+        for _ in range(3):
+            model._objective(x0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            model._objective(x0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 100 * 1e3
+        c = [C.c_int64() for _ in range(3)]
+        h.lib.gp_sgpr_eval_counts(model._plan, *[C.byref(v) for v in c])
+        print("one bound+grad evaluation, %s: %.3f ms  (eager %d / captured %d / replayed %d)"
+              % (label, dt, c[0].value, c[1].value, c[2].value))
+        model._destroy()
+
+    time_eval(_lib.default_handle(), "null stream, eager launches")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hs = _lib.Handle(torch.cuda.current_device(), stream=s)
+        time_eval(hs, "own stream, hipGraph replay")
+        hs.close()
+
+    from gpitch_amd.windows import fit_windows
+    for ns in args.streams:
+        t0 = time.perf_counter()
+        res = fit_windows(lambda hh: build_model(wins[0][3], hh), [(w[0], w[1], w[2]) for w in wins],
+                          maxiter=args.maxiter, num_streams=ns)
+        dt = time.perf_counter() - t0
+        print("streams=%d: %d windows in %.3f s = %.1f windows/s; nfev total %d; bound[0]=%.6f"
+              % (ns, args.nwin, dt, args.nwin / dt, sum(r["nfev"] for r in res), res[0]["bound"]))
+
+
+if __name__ == "__main__":
+    main()
