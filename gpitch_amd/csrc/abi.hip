@@ -224,7 +224,8 @@ static gp_status gauss_kl_impl(gp_handle h, const double* q_mu, const double* q_
   const size_t item_bytes = kl_item_bytes() > klu_item_bytes() ? kl_item_bytes() : klu_item_bytes();
   char* d_item = ar.take<char>(item_bytes);
   GemmProblem* d_prob = ar.take<GemmProblem>(1);
-  double* d_out = ar.take<double>(4);
+  double* d_out = ar.take<double>(GP_KL_BLOCKS + 4);
+  double* d_res = d_out;
   if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, who);
   std::vector<char> item(item_bytes);
   GemmProblem r;
@@ -256,8 +257,10 @@ static gp_status gauss_kl_impl(gp_handle h, const double* q_mu, const double* q_
     kl_item_fill(item.data(), q_mu, q_sqrt, M, d_out, nullptr, nullptr);
     GP_HIP_CHECK(h, hipMemcpyAsync(d_item, item.data(), item.size(), hipMemcpyHostToDevice, h->stream));
     GP_CHECK(launch_kl_white(h, d_item, 1));
+    d_res = d_out + GP_KL_BLOCKS;
+    GP_CHECK(launch_finish_sum(h, d_out, GP_KL_BLOCKS, 1, 1, d_res, 1.0, 0));
   }
-  GP_HIP_CHECK(h, hipMemcpyAsync(out_host, d_out, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(out_host, d_res, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // also keeps the host-side `r` / `item` alive long enough
   return check_not_pd(h);
 }

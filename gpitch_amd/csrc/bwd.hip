@@ -555,7 +555,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
       { GemmProblem& r = P(S_GQ_L); r.A = t.W; r.B = b.g_Lq_w; r.C = grad + q.off_qsqrt; }
       { GemmProblem& r = P(S_WB_R1); r.C = b.Wbar; r.v0 = b.g_qmu_w; r.v1 = qm; }
       { GemmProblem& r = P(S_WB_L); r.A = b.g_Lq_w; r.B = qs; r.C = b.Wbar; }
-      kl_item_fill(p->h_misc.data() + p->off_kl2 + g * kl_item_bytes(), b.qmu_w, b.Lq_w, M, p->kl_dummy + g, b.g_qmu_w,
+      kl_item_fill(p->h_misc.data() + p->off_kl2 + g * kl_item_bytes(), b.qmu_w, b.Lq_w, M, p->kl_dummy + (size_t)g * GP_KL_BLOCKS, b.g_qmu_w,
                    b.g_Lq_w);
     }
     { GemmProblem& r = P(S_E); r.A = q_sqrt; r.B = q_sqrt; r.C = b.E; }

@@ -147,6 +147,8 @@ int gemm_nt_nsplit(int M, int Nlong, int batch);
 int gemm_rowblocks(int M, int big_tiles);
 
 // lik.hip
+// whitened KL: each item writes GP_KL_BLOCKS partial sums to out[0..GP_KL_BLOCKS)
+#define GP_KL_BLOCKS 16
 gp_status launch_mpd_lik(gp_handle h, const double* Fmu, const double* Fvar, int64_t f_rs, int64_t f_cs,
                          const double* y, int N, int P, int nlin, const double* noise_var, double scale,
                          double* per_frame, double* partial_sums, int* num_partials_out,

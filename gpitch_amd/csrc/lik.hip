@@ -237,42 +237,46 @@ void cond_finish_fill(void* host_item, const double* s1, int rb1, const double* 
 // and, when g_mu/g_L != NULL, ACCUMULATES  -dKL  into the ELBO gradient vector.
 struct KlItem {
   const double* q_mu; const double* q_sqrt; int M;
-  double* out;       // kl value
+  double* out;       // kl value as GP_KL_BLOCKS partial sums (their total is the KL)
   double* g_mu; double* g_sqrt;
 };
 
-__global__ void __launch_bounds__(1024) kl_white_kernel(const KlItem* __restrict__ items) {
+// grid (items, GP_KL_BLOCKS): block b of an item takes a contiguous band of rows, so that the M^2-element sweep
+// (and its read-modify-write of the gradient) is not serialised behind one workgroup's memory latency.
+__global__ void __launch_bounds__(256) kl_white_kernel(const KlItem* __restrict__ items) {
   const KlItem it = items[blockIdx.x];
-  const int M = it.M;
+  const int M = it.M, nb = gridDim.y, b = blockIdx.y;
+  const int rows_per = (M + nb - 1) / nb;
+  const int r0 = b * rows_per, r1 = min(M, r0 + rows_per);
   double acc = 0.0;
-  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+  for (int i = r0 + (int)threadIdx.x; i < r1; i += 256) {
     const double mu = it.q_mu[i];
     const double d = it.q_sqrt[(int64_t)i * M + i];
     acc += mu * mu - log(d * d);
     if (it.g_mu) it.g_mu[i] -= mu;
   }
-  for (int64_t idx = threadIdx.x; idx < (int64_t)M * M; idx += blockDim.x) {
-    const int i = (int)(idx / M), j = (int)(idx % M);
-    if (j <= i) {
-      const double l = it.q_sqrt[idx];
+  for (int i = r0; i < r1; i++) {
+    const double* row = it.q_sqrt + (int64_t)i * M;
+    double* grow = it.g_sqrt ? it.g_sqrt + (int64_t)i * M : nullptr;
+    for (int j = threadIdx.x; j <= i; j += 256) {
+      const double l = row[j];
       acc = fma(l, l, acc);
-      if (it.g_sqrt) it.g_sqrt[idx] -= (i == j) ? (l - 1.0 / l) : l;
+      if (grow) grow[j] -= (i == j) ? (l - 1.0 / l) : l;
     }
   }
-  __shared__ double red[16];
+  __shared__ double red[4];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
-    it.out[0] = 0.5 * (s - (double)M);
+    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    it.out[b] = 0.5 * (s - (b == 0 ? (double)M : 0.0));
   }
 }
 
 gp_status launch_kl_white(gp_handle h, const void* d_items, int count) {
   if (count <= 0) return GP_OK;
-  hipLaunchKernelGGL(kl_white_kernel, dim3(count), dim3(1024), 0, h->stream, (const KlItem*)d_items);
+  hipLaunchKernelGGL(kl_white_kernel, dim3(count, GP_KL_BLOCKS), dim3(256), 0, h->stream, (const KlItem*)d_items);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }

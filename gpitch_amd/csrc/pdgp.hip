@@ -23,7 +23,7 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
   add(p->G + 8);
   if (!p->whiten) {
     for (int g = 0; g < p->G; g++) { const size_t M = p->gps[g].M; add(2 * (M + M * M) + 8); }
-    add(p->G + 8);
+    add((size_t)p->G * GP_KL_BLOCKS);
   }
   return d;
 }
@@ -100,7 +100,7 @@ size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   for (int g = 0; g < p->G; g++) d += cond_task_workspace_doubles(p->gps[g].M, p->maxN, p->gps[g].m, p->whiten != 0);
   auto addd = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   for (int i = 0; i < 4; i++) addd((size_t)p->G * p->maxN);
-  addd(p->G);
+  addd((size_t)p->G * GP_KL_BLOCKS);
   addd(2 * ((size_t)(p->maxN + 255) / 256) + 8);
   if (!p->whiten)
     for (int g = 0; g < p->G; g++) addd((size_t)gemm_rowblocks(p->gps[g].M, 0) * p->gps[g].M);
@@ -130,7 +130,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
   p->fvar = ar.take<double>((size_t)p->G * p->maxN);
   p->gFmu = ar.take<double>((size_t)p->G * p->maxN);
   p->gFvar = ar.take<double>((size_t)p->G * p->maxN);
-  p->kl = ar.take<double>(p->G);
+  p->kl = ar.take<double>((size_t)p->G * GP_KL_BLOCKS);
   p->lik_partials = ar.take<double>(2 * ((size_t)(p->maxN + 255) / 256) + 8);
   for (int g = 0; g < p->G; g++) {
     CondTask& t = p->cb.tasks[g];
@@ -177,7 +177,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
         BwdBufs& b = p->bw[g];
         b.qmu_w = c; c += ev(M); b.Lq_w = c; c += ev(M * M); b.g_qmu_w = c; c += ev(M); b.g_Lq_w = c; c += ev(M * M);
       }
-      p->kl_dummy = ar.take<double>(p->G + 8);
+      p->kl_dummy = ar.take<double>((size_t)p->G * GP_KL_BLOCKS);
     }
   }
   if (!ar.ok) return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_pdgp_set_workspace: arena exhausted");
@@ -219,10 +219,10 @@ static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x
     const CondTask& t = p->cb.tasks[g];
     if (p->whiten) {
       kl_item_fill(p->h_misc.data() + p->off_kl_items + g * kl_item_bytes(), params + q.off_qmu, params + q.off_qsqrt,
-                   q.M, p->kl + g, grad ? grad + q.off_qmu : nullptr, grad ? grad + q.off_qsqrt : nullptr);
+                   q.M, p->kl + (size_t)g * GP_KL_BLOCKS, grad ? grad + q.off_qmu : nullptr, grad ? grad + q.off_qsqrt : nullptr);
     } else {
       klu_item_fill(p->h_misc.data() + p->off_kl_items + g * klu_item_bytes(), params + q.off_qmu, params + q.off_qsqrt,
-                    t.L, t.W, p->tr_part[g], gemm_rowblocks(q.M, 0), q.M, p->kl + g);
+                    t.L, t.W, p->tr_part[g], gemm_rowblocks(q.M, 0), q.M, p->kl + (size_t)g * GP_KL_BLOCKS);
       // trace term: column sums of squares of W Lq (its own descriptor slot, after the backward ones)
       GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + pdgp_kltr_offset(p->G) + g * sizeof(GemmProblem));
       memset(&r, 0, sizeof(r));
@@ -255,12 +255,14 @@ static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double
     GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl_items, p->G));
   } else {
     // gauss_kl(q_mu, q_sqrt, K = Kuu + jitter I) (pdgp.py:123-129): L and W of the conditional are reused
+    // (one value per GP: the other partial-sum slots of the whitened layout stay zero)
+    GP_HIP_CHECK(h, hipMemsetAsync(p->kl, 0, (size_t)p->G * GP_KL_BLOCKS * sizeof(double), h->stream));
     GemmFlags f;
     f.triA = TRI_LOWER; f.triB = TRI_LOWER; f.epilogue = EPI_COLSUMSQ;
     GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(p->d_misc + pdgp_kltr_offset(p->G)), p->G, p->maxM, p->maxM, f));
     GP_CHECK(launch_kl_unwhite(h, p->d_misc + p->off_kl_items, p->G));
   }
-  if (xchg) GP_CHECK(launch_finish_sum(h, p->kl, p->G, 1, 1, xchg + 3 * (size_t)n, 1.0, 0));
+  if (xchg) GP_CHECK(launch_finish_sum(h, p->kl, p->G * GP_KL_BLOCKS, 1, 1, xchg + 3 * (size_t)n, 1.0, 0));
   return GP_OK;
 }
 
@@ -272,7 +274,7 @@ static gp_status pdgp_finish(gp_pdgp_plan p, const double* params, const double*
   GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
                           grad ? p->gFmu : nullptr, grad ? p->gFvar : nullptr, nullptr, xchg));
   if (xchg) GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, xchg + 3 * (size_t)n, 1, elbo_dev, grad ? grad : nullptr));
-  else GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G, elbo_dev, grad ? grad : nullptr));
+  else GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G * GP_KL_BLOCKS, elbo_dev, grad ? grad : nullptr));
   if (grad) GP_CHECK(pdgp_backward(p, params, x, n, grad));
   if (elbo_host) {
     GP_HIP_CHECK(h, hipMemcpyAsync(elbo_host, elbo_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
