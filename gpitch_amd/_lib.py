@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libgpitch_hip.so")
 
 GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_HIP, GP_ERR_NO_DEVICE, GP_ERR_WORKSPACE, GP_ERR_UNSUPPORTED = range(7)
 
-KERN_MATERN12, KERN_MATERN32, KERN_MATERN52, KERN_RBF, KERN_MERCER_MATERN12SM, KERN_MATERN12SM = range(6)
+(KERN_MATERN12, KERN_MATERN32, KERN_MATERN52, KERN_RBF, KERN_MERCER_MATERN12SM, KERN_MATERN12SM, KERN_MATERN32SM,
+ KERN_MERCER_MATERN52SM) = range(8)
 NLIN_LOGISTIC, NLIN_SOFTPLUS, NLIN_GAUSS = range(3)
 (TIMER_KUF_BUILD, TIMER_COND_A, TIMER_COND_LTA, TIMER_NT_GEMM, TIMER_KUF_BAR, TIMER_CHOL, TIMER_LIK, TIMER_SMALL_GEMM,
  TIMER_HYPER, TIMER_KUF_BUILD_SM) = range(10)
@@ -28,7 +29,7 @@ ABI_SYMBOLS = [
     "gp_conditional_workspace_bytes", "gp_conditional_diag", "gp_gauss_kl_workspace_bytes", "gp_gauss_kl", "gp_gauss_kl_matrix", "gp_mpd_varexp",
     "gp_pdgp_create", "gp_pdgp_destroy", "gp_pdgp_num_params", "gp_pdgp_layout", "gp_pdgp_workspace_bytes",
     "gp_pdgp_set_workspace", "gp_pdgp_set_grad_needs", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_predict",
-    "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
+    "gp_transform_register_logistic", "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace",
     "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
@@ -111,6 +112,7 @@ def load_library():
         "gp_pdgp_elbo_begin": (i32, [vp, vp, vp, vp, i32, vp, vp]),
         "gp_pdgp_elbo_end": (i32, [vp, vp, vp, vp, i32, dbl, vp, vp, C.POINTER(dbl), vp]),
         "gp_pdgp_predict": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+        "gp_transform_register_logistic": (i32, [vp, dbl, dbl, C.POINTER(C.c_uint8)]),
         "gp_transform_forward": (i32, [vp, vp, vp, i64, vp]),
         "gp_transform_backward": (i32, [vp, vp, vp, i64, vp]),
         "gp_adam_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i64, dbl, dbl, dbl, dbl]),

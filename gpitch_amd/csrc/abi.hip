@@ -102,8 +102,8 @@ gp_status gp_timers_read(gp_handle h, int32_t which, double* total_ms, int64_t* 
 // L2 operators
 static bool kern_ok(const gp_kernel_desc* k) {
   if (!k || !k->theta) return false;
-  if (k->type < GP_KERN_MATERN12 || k->type > GP_KERN_MATERN12SM) return false;
-  if ((k->type == GP_KERN_MERCER_MATERN12SM || k->type == GP_KERN_MATERN12SM) && k->num_partials < 1) return false;
+  if (k->type < GP_KERN_MATERN12 || k->type > GP_KERN_LAST) return false;
+  if (gp_kern_has_partials(k->type) && (k->num_partials < 1 || k->num_partials > 32)) return false;
   return true;
 }
 
@@ -116,7 +116,7 @@ gp_status gp_kernel_build(gp_handle h, const gp_kernel_desc* kern, const double*
   if (n1 == 0 || n2 == 0) return GP_OK;
   DevKern k = dev_kern(kern);
   double* feat = nullptr;
-  if (k.type == GP_KERN_MERCER_MATERN12SM) {
+  if (gp_kern_is_mercer(k.type)) {
     // one-shot operator: the feature scratch is a transient allocation (the plans carry their own)
     size_t nd = kernel_build_feat_ws_doubles(k.m, n1, x2 ? n2 : n1);
     GP_HIP_CHECK(h, hipMallocAsync((void**)&feat, nd * sizeof(double), h->stream));
@@ -144,7 +144,7 @@ gp_status gp_kuu_cholesky(gp_handle h, const gp_kernel_desc* kern, const double*
   GpArena ar(workspace, workspace_bytes);
   double* Lbuf = L ? L : ar.take<double>((size_t)M * M);
   DevKern k = dev_kern(kern);
-  double* feat = (k.type == GP_KERN_MERCER_MATERN12SM) ? ar.take<double>(kernel_build_feat_ws_doubles(k.m, M, M)) : nullptr;
+  double* feat = gp_kern_is_mercer(k.type) ? ar.take<double>(kernel_build_feat_ws_doubles(k.m, M, M)) : nullptr;
   if (!ar.ok || !Lbuf) return gp_fail(h, GP_ERR_WORKSPACE, "gp_kuu_cholesky: workspace too small");
   GP_CHECK(launch_kernel_build(h, k, z, M, nullptr, M, Lbuf, M, 0, jitter, feat));
   GP_CHECK(launch_cholesky_single(h, Lbuf, M, M));
@@ -280,6 +280,18 @@ gp_status gp_gauss_kl_matrix(gp_handle h, const double* q_mu, const double* q_sq
   if (!q_mu || !q_sqrt || M < 1 || !out_host || !K) return gp_fail(h, GP_ERR_BAD_ARG, "gp_gauss_kl_matrix: bad argument");
   return gauss_kl_impl(h, q_mu, q_sqrt, M, nullptr, nullptr, 0.0, K, out_host, workspace, workspace_bytes,
                        "gp_gauss_kl_matrix: workspace too small (gp_gauss_kl_workspace_bytes)");
+}
+
+gp_status gp_transform_register_logistic(gp_handle h, double a, double b, uint8_t* code_out) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!code_out || !(b > a)) return gp_fail(h, GP_ERR_BAD_ARG, "gp_transform_register_logistic: need b > a");
+  for (int i = 0; i < h->num_logistic; i++)
+    if (h->logistic.a[i] == a && h->logistic.b[i] == b) { *code_out = (uint8_t)(3 + i); return GP_OK; }
+  if (h->num_logistic >= GP_MAX_LOGISTIC)
+    return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_transform_register_logistic: table full (8 distinct (a, b) pairs per handle)");
+  h->logistic.a[h->num_logistic] = a; h->logistic.b[h->num_logistic] = b;
+  *code_out = (uint8_t)(3 + h->num_logistic++);
+  return GP_OK;
 }
 
 gp_status gp_transform_forward(gp_handle h, const double* fs, const uint8_t* tcode, int64_t n, double* params) {

@@ -199,8 +199,14 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
     } else {
       const double r = __dsqrt_rn(__dadd_rn(r2, 1e-12));
       if (SM) {
-        const double E = exp(-r);
-        const double wvE = w * var * E;
+        // envelope phi(r) and phi'(r): Matern-1/2 (MercerMatern12sm) or Matern-5/2 (Matern52 * MercerCosMix)
+        double E, dE;
+        if (k.type == GP_KERN_MERCER_MATERN12SM) { E = exp(-r); dE = -E; }
+        else {
+          const double s5 = 2.23606797749979, e5 = exp(-s5 * r);
+          E = (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e5; dE = -(5.0 / 3.0) * r * (1.0 + s5 * r) * e5;
+        }
+        const double wvE = w * var * E, wvD = w * var * dE;
         const double wd = wvE * d;
         const double* fz = &fzs[(i - i0) * 2 * MPAD];
         double S = 0.0, Ssin = 0.0;
@@ -216,8 +222,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
         }
         const double rinv = 1.0 / r;
         acc_v = fma(w * E, S, acc_v);
-        acc_l = fma(wvE * S, r2 * rinv * inv_ls, acc_l);
-        if (GZ) dz = wvE * (-S * d * inv_ls2 * rinv - Ssin);
+        acc_l = fma(-wvD * S, r2 * rinv * inv_ls, acc_l);
+        if (GZ) dz = wvD * S * d * inv_ls2 * rinv - wvE * Ssin;
       } else {
         double phi, dphi;  // K = var * phi(r), dphi = phi'(r)
         if (k.type == GP_KERN_MATERN12) { phi = exp(-r); dphi = -phi; }
@@ -273,8 +279,9 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
 }
 
 
-// Legacy broadcast-form kernel Matern12sm (matern12_spectral_mixture.py:38-56):
-//   d = x1_i - x2_j + 1e-12,  r = |d|,  K = var * exp(-r / ls) * sum_q e_q cos(2 pi f_q r).
+// Broadcast-form kernels Matern12sm (matern12_spectral_mixture.py:38-56) and Matern32sm (kernels.py:204-258):
+//   d = x1_i - x2_j + 1e-12,  r = |d|,  K = var * phi(r; ls) * sum_q e_q cos(2 pi f_q r),
+//   phi = exp(-r / ls)  or  (1 + r1) exp(-r1), r1 = sqrt(3) r / ls.
 // Same grid and partial layout as hyper_contract_kernel; m cosines per entry, as the reference.
 template <bool GZ>
 __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, const double* __restrict__ x1, int n1,
@@ -326,7 +333,14 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
       const double dji = __dadd_rn(__dadd_rn(xb, -x1[i]), 1e-12);
       sg = 0.5 * (sg - (dji < 0.0 ? -1.0 : 1.0));
     }
-    const double E = exp(-(r / ls));
+    // envelope phi(r; l), d phi / d r, d phi / d l
+    double E, dEr, dEl;
+    if (k.type == GP_KERN_MATERN12SM) {
+      E = exp(-(r / ls)); dEr = -E / ls; dEl = E * r / (ls * ls);
+    } else {   // Matern32sm: r1 = sqrt(3) r / l
+      const double s3 = 1.7320508075688772, r1 = s3 * (r / ls), e1 = exp(-r1);
+      E = (1.0 + r1) * e1; dEr = -r1 * e1 * s3 / ls; dEl = r1 * r1 * e1 / ls;
+    }
     const double wvE = w * var * E;
     double S = 0.0, Sf = 0.0;
 #pragma unroll
@@ -341,9 +355,9 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
       }
     }
     acc_v = fma(w * E, S, acc_v);
-    acc_l = fma(wvE * S, r / (ls * ls), acc_l);
+    acc_l = fma(w * var * dEl, S, acc_l);
     if (GZ) {
-      double dz = sg * wvE * (-S / ls - Sf);
+      double dz = sg * (w * var * dEr * S - wvE * Sf);
       for (int o = 32; o > 0; o >>= 1) dz += __shfl_down(dz, o, 64);
       if (lane == 0) red[wave * HY_ROWS + (i - i0)] = dz;
     }
@@ -394,7 +408,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
                                 const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
                                 const double* feat, double* partials, int* nparts, double* gz_partials) {
   GpTimerScope ts(h, GP_TIMER_HYPER);
-  if (k.type == GP_KERN_MATERN12SM) {
+  if (gp_kern_is_broadcast(k.type)) {
     dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + HY_ROWS - 1) / HY_ROWS);
     const int ns = 2 + 2 * k.m;
     const int redw = ns > HY_ROWS ? ns : HY_ROWS;
@@ -409,7 +423,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     if (nparts) *nparts = grid.x * grid.y;
     return GP_OK;
   }
-  const bool sm = (k.type == GP_KERN_MERCER_MATERN12SM);
+  const bool sm = gp_kern_is_mercer(k.type);
   const int mp = sm ? sm_mpad(k.m) : 0;
   const double* f1 = feat;
   const double* f2 = (x2 == x1 || !feat) ? feat : feat + gp_align_up((size_t)2 * mp * n1, 32);
@@ -457,7 +471,7 @@ __global__ void __launch_bounds__(256) hyper_finish_kernel(DevKern k, const doub
       double v = red[0];
       if (gv_sum) {  // d kdiag / d theta contribution: kdiag = var (stationary) or var * sum(e)
         const double gs = gv_sum[0];
-        const bool smk = (k.type == GP_KERN_MERCER_MATERN12SM || k.type == GP_KERN_MATERN12SM);
+        const bool smk = gp_kern_kdiag_energy(k.type);
         if (s == 0) {
           double se = 1.0;
           if (smk) { se = 0.0; for (int q = 0; q < k.m; q++) se += k.theta[2 + q]; }

@@ -9,6 +9,10 @@
 
 #define GP_WAVE 64
 
+// gpflow.transforms.Logistic(a, b) bounds registered on a handle (transform code = 3 + index)
+#define GP_MAX_LOGISTIC 8
+struct GpLogisticTable { double a[GP_MAX_LOGISTIC]; double b[GP_MAX_LOGISTIC]; };
+
 struct gp_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -17,6 +21,7 @@ struct gp_handle_s {
   int32_t not_pd_index = -1;
   int32_t* d_status = nullptr;   // device int[4]: {not_pd_flag, pivot_index, gp_index, spare}
   int num_cus = 256;
+  GpLogisticTable logistic = {}; int num_logistic = 0;
   // timers
   bool timers_on = false;
   struct TimerRec { hipEvent_t e0, e1; int which; };
@@ -50,6 +55,16 @@ static inline gp_status gp_fail(gp_handle h, gp_status s, const char* msg) {
 }
 
 // scoped timer for a kernel class; records HIP events on the handle's stream when enabled
+// kernel families (include/gpitch_abi.h gp_kernel_type)
+#define GP_KERN_LAST GP_KERN_MERCER_MATERN52SM
+static inline __host__ __device__ bool gp_kern_has_partials(int t) { return t >= GP_KERN_MERCER_MATERN12SM && t <= GP_KERN_LAST; }
+// feature ("Mercer") form: K = var * env(r) * Phi(x)^T Phi(x'), r = euclid_dist
+static inline __host__ __device__ bool gp_kern_is_mercer(int t) { return t == GP_KERN_MERCER_MATERN12SM || t == GP_KERN_MERCER_MATERN52SM; }
+// broadcast form: r = |x - x' + 1e-12|, m cosines per entry
+static inline __host__ __device__ bool gp_kern_is_broadcast(int t) { return t == GP_KERN_MATERN12SM || t == GP_KERN_MATERN32SM; }
+// Kdiag = variance * sum_k energy_k (true) or just variance (false)
+static inline __host__ __device__ bool gp_kern_kdiag_energy(int t) { return gp_kern_has_partials(t) && t != GP_KERN_MERCER_MATERN52SM; }
+
 struct GpTimerScope {
   gp_handle h;
   int which;

@@ -53,9 +53,10 @@ __global__ void __launch_bounds__(256) sm_features_kernel(DevKern k, const doubl
   f[(size_t)(p + mpad) * n + j] = s;
 }
 
-// MODE 0: stationary (Matern12/32/52/RBF); MODE 1: Mercer Matern-1/2 SM (feature form);
-// MODE 2: Matern12sm (broadcast cosine form).  CPT = columns per thread (16-byte stores when 2).
-template <int MODE, int CPT, int MPAD>
+// MODE 0: stationary (Matern12/32/52/RBF); MODE 1: Mercer spectral mixture (feature form) with envelope ENV
+// (0: Matern-1/2, MercerMatern12sm; 2: Matern-5/2, the Matern52 * MercerCosMix product of init_models.py:183-198);
+// MODE 2: broadcast cosine form (Matern12sm, Matern32sm).  CPT = columns per thread (16-byte stores when 2).
+template <int MODE, int CPT, int MPAD, int ENV = 0>
 __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const double* __restrict__ x1, int n1,
                                                                 const double* __restrict__ x2, int n2,
                                                                 double* __restrict__ out, int64_t ld,
@@ -120,7 +121,12 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
 #pragma unroll
       for (int c = 0; c < CPT; c++) {
         double r = __dsqrt_rn(__dadd_rn(r2_expand(a, aa, b[c], bb[c]), 1e-12));
-        res[c] = var * exp(-r) * acc[c];
+        if (ENV == 0) {
+          res[c] = var * exp(-r) * acc[c];
+        } else {   // GPflow Matern52.K profile
+          const double s5 = 2.23606797749979;
+          res[c] = var * ((1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r)) * acc[c];
+        }
         if (x2 == x1 && i == j0 + c) res[c] += diag_add;
       }
       double* o = out + (size_t)i * ld + j0;
@@ -145,7 +151,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
 #pragma unroll
       for (int c = 0; c < CPT; c++) res[c] = stat_profile(k.type, r2_expand(a, aa, b[c], bb[c]), var);
     } else {
-      // Matern12sm (m12sm.py:46-56): r = sqrt((x - x' + 1e-12)^2)
+      // Matern12sm (m12sm.py:46-56) / Matern32sm (kernels.py:232-247): r = sqrt((x - x' + 1e-12)^2)
 #pragma unroll
       for (int c = 0; c < CPT; c++) {
         double d = __dadd_rn(__dadd_rn(xa, -xb[c]), 1e-12);
@@ -153,7 +159,12 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
         double s = 0.0;
         for (int p = 0; p < m; p++)
           s += th[2 + p] * cos(__dmul_rn(__dmul_rn(6.283185307179586, th[2 + m + p]), r));
-        res[c] = var * exp(-(r / ls)) * s;
+        if (k.type == GP_KERN_MATERN12SM) {
+          res[c] = var * exp(-(r / ls)) * s;
+        } else {   // Matern32sm: r1 = sqrt(3) r / l, (1 + r1) exp(-r1) sum_k variance_k cos(2 pi f_k r)
+          const double r1 = 1.7320508075688772 * (r / ls);
+          res[c] = var * ((1.0 + r1) * exp(-r1)) * s;
+        }
       }
     }
 #pragma unroll
@@ -177,7 +188,7 @@ __global__ void __launch_bounds__(256) cov_diag_kernel(DevKern k, int n, double*
   if (j >= n) return;
   const double* th = k.theta;
   double v = th[0];
-  if (k.type == GP_KERN_MERCER_MATERN12SM || k.type == GP_KERN_MATERN12SM) {
+  if (gp_kern_kdiag_energy(k.type)) {
     double s = th[2];
     for (int p = 1; p < k.m; p++) s += th[2 + p];
     v = v * s;
@@ -198,8 +209,12 @@ static void launch_mercer(gp_handle h, dim3 grid, DevKern k, const double* x1, i
                           double* out, int64_t ld, int accumulate, double diag_add, const double* f1, const double* f2,
                           int vec_ok) {
   size_t sh = (size_t)COV_ROWS * 2 * MPAD * sizeof(double);
-  hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out, ld,
-                     accumulate, diag_add, f1, f2, vec_ok);
+  if (k.type == GP_KERN_MERCER_MATERN12SM)
+    hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 0>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
+                       ld, accumulate, diag_add, f1, f2, vec_ok);
+  else
+    hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 2>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
+                       ld, accumulate, diag_add, f1, f2, vec_ok);
 }
 
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
@@ -209,8 +224,8 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
   const int vec_ok = ((ld % 2) == 0) && ((((uintptr_t)out) & 15) == 0);
   const bool big = (int64_t)n1 * n2 >= (1 << 20);   // M x N strips; the small Kuu builds are booked elsewhere
   GpTimerScope ts(h, !big ? GP_TIMER_SMALL_GEMM
-                          : (k.type == GP_KERN_MERCER_MATERN12SM ? GP_TIMER_KUF_BUILD_SM : GP_TIMER_KUF_BUILD));
-  if (k.type == GP_KERN_MERCER_MATERN12SM) {
+                          : (gp_kern_is_mercer(k.type) ? GP_TIMER_KUF_BUILD_SM : GP_TIMER_KUF_BUILD));
+  if (gp_kern_is_mercer(k.type)) {
     if (k.m < 1 || k.m > 32) return gp_fail(h, GP_ERR_UNSUPPORTED, "num_partials must be in [1, 32]");
     if (!feat_ws) return gp_fail(h, GP_ERR_WORKSPACE, "feature workspace missing");
     const int mp = sm_mpad(k.m);
@@ -233,7 +248,7 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
       case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
       default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
     }
-  } else if (k.type == GP_KERN_MATERN12SM) {
+  } else if (gp_kern_is_broadcast(k.type)) {
     if (k.m < 1) return gp_fail(h, GP_ERR_BAD_ARG, "num_partials must be >= 1");
     dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + COV_ROWS - 1) / COV_ROWS);
     hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
@@ -251,7 +266,7 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
 
 // (re)build the spectral-mixture feature tables of kernel k for (x1, x2) without building a covariance
 gp_status launch_sm_features(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2, double* feat_ws) {
-  if (k.type != GP_KERN_MERCER_MATERN12SM) return GP_OK;
+  if (!gp_kern_is_mercer(k.type)) return GP_OK;
   const int mp = sm_mpad(k.m);
   double* f1 = feat_ws;
   double* f2 = feat_ws + gp_align_up((size_t)2 * mp * n1, 32);

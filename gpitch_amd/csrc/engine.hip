@@ -28,7 +28,7 @@ bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten) {
   t.Kuf = ar.take<double>((size_t)t.M * ldN);
   t.A = ar.take<double>((size_t)t.M * ldN);
   t.A2 = whiten ? nullptr : ar.take<double>((size_t)t.M * ldN);
-  t.feat = (t.kern.m > 0 && t.kern.type == GP_KERN_MERCER_MATERN12SM)
+  t.feat = (t.kern.m > 0 && gp_kern_is_mercer(t.kern.type))
                ? ar.take<double>(kernel_build_feat_ws_doubles(t.kern.m, t.M, N)) : nullptr;
   t.s1 = ar.take<double>((size_t)rb * N);
   t.s2 = ar.take<double>((size_t)rb * N);

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) cond_finish_kernel(const CondFinish* __re
   if (n >= N) return;
   const double* th = it.kern.theta;
   double kd = th[0];
-  if (it.kern.type == GP_KERN_MERCER_MATERN12SM || it.kern.type == GP_KERN_MATERN12SM) {
+  if (gp_kern_kdiag_energy(it.kern.type)) {
     double s = th[2];
     for (int p = 1; p < it.kern.m; p++) s += th[2 + p];
     kd = kd * s;

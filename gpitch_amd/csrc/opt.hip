@@ -8,17 +8,29 @@
 
 __device__ __forceinline__ double softplus_pos(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))) + 1e-6; }
 
+// transform codes: 0 identity, 1 positive (Log1pe + 1e-6), 2 fixed, 3.. = gpflow.transforms.Logistic(a, b) with
+// (a, b) = the handle's table entry code - 3 (gp_transform_register_logistic; kernels.py:219-223,333,
+// init_models.py:189):  y = a + (b - a) / (1 + exp(-x)),  x = -log((b - a) / (y - a) - 1)
+__device__ __forceinline__ double logistic_fwd(const GpLogisticTable& T, int t, double x) {
+  const double a = T.a[t - 3], b = T.b[t - 3];
+  return a + (b - a) / (1.0 + exp(-x));
+}
+
 __global__ void __launch_bounds__(256) transform_fwd_kernel(const double* __restrict__ fs, const uint8_t* __restrict__ tc,
-                                                            int64_t n, double* __restrict__ params) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    params[i] = (tc[i] == 1) ? softplus_pos(fs[i]) : fs[i];
+                                                            int64_t n, double* __restrict__ params, GpLogisticTable T) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int t = tc[i];
+    params[i] = (t == 1) ? softplus_pos(fs[i]) : (t >= 3 ? logistic_fwd(T, t, fs[i]) : fs[i]);
+  }
 }
 
 __global__ void __launch_bounds__(256) transform_bwd_kernel(const double* __restrict__ params, const uint8_t* __restrict__ tc,
-                                                            int64_t n, double* __restrict__ fs) {
+                                                            int64_t n, double* __restrict__ fs, GpLogisticTable T) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double y = params[i];
-    if (tc[i] == 1) { y -= 1e-6; y = y + log(-expm1(-y)); }
+    const int t = tc[i];
+    if (t == 1) { y -= 1e-6; y = y + log(-expm1(-y)); }
+    else if (t >= 3) { const double a = T.a[t - 3], b = T.b[t - 3]; y = -log((b - a) / (y - a) - 1.0); }
     fs[i] = y;
   }
 }
@@ -27,19 +39,20 @@ __global__ void __launch_bounds__(256) transform_bwd_kernel(const double* __rest
 __global__ void __launch_bounds__(256) adam_kernel(double* __restrict__ fs, double* __restrict__ params,
                                                    const double* __restrict__ grad, const uint8_t* __restrict__ tc,
                                                    double* __restrict__ m, double* __restrict__ v, int64_t n, double lr_t,
-                                                   double b1, double b2, double eps) {
+                                                   double b1, double b2, double eps, GpLogisticTable T) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint8_t t = tc[i];
     if (t == 2) continue;
     double x = fs[i];
     double g = -grad[i];
     if (t == 1) g *= 1.0 / (1.0 + exp(-x));
+    else if (t >= 3) { const double s = 1.0 / (1.0 + exp(-x)); g *= (T.b[t - 3] - T.a[t - 3]) * s * (1.0 - s); }
     double mi = b1 * m[i] + (1.0 - b1) * g;
     double vi = b2 * v[i] + (1.0 - b2) * g * g;
     m[i] = mi; v[i] = vi;
     x -= lr_t * mi / (sqrt(vi) + eps);
     fs[i] = x;
-    params[i] = (t == 1) ? softplus_pos(x) : x;
+    params[i] = (t == 1) ? softplus_pos(x) : (t >= 3 ? logistic_fwd(T, t, x) : x);
   }
 }
 
@@ -50,14 +63,14 @@ static int ew_blocks(int64_t n) {
 
 gp_status launch_transform_forward(gp_handle h, const double* fs, const uint8_t* tc, int64_t n, double* params) {
   if (n <= 0) return GP_OK;
-  hipLaunchKernelGGL(transform_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, fs, tc, n, params);
+  hipLaunchKernelGGL(transform_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, fs, tc, n, params, h->logistic);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
 
 gp_status launch_transform_backward(gp_handle h, const double* params, const uint8_t* tc, int64_t n, double* fs) {
   if (n <= 0) return GP_OK;
-  hipLaunchKernelGGL(transform_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, params, tc, n, fs);
+  hipLaunchKernelGGL(transform_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, params, tc, n, fs, h->logistic);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -67,7 +80,7 @@ gp_status launch_adam(gp_handle h, double* fs, double* params, const double* gra
   if (n <= 0) return GP_OK;
   const double lr_t = lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, fs, params, grad, tc, m, v, n, lr_t, b1,
-                     b2, eps);
+                     b2, eps, h->logistic);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }

@@ -48,8 +48,8 @@ gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* o
     q.M = act ? cfg->M_act[i] : cfg->M_com[i];
     q.ktype = act ? cfg->kern_type_act[i] : cfg->kern_type_com[i];
     q.m = act ? cfg->partials_act[i] : cfg->partials_com[i];
-    const bool sm = (q.ktype == GP_KERN_MERCER_MATERN12SM || q.ktype == GP_KERN_MATERN12SM);
-    if (q.M < 1 || q.ktype < 0 || q.ktype > GP_KERN_MATERN12SM || (sm && (q.m < 1 || q.m > 32)) || (!sm && q.m != 0)) {
+    const bool sm = gp_kern_has_partials(q.ktype);
+    if (q.M < 1 || q.ktype < 0 || q.ktype > GP_KERN_LAST || (sm && (q.m < 1 || q.m > 32)) || (!sm && q.m != 0)) {
       delete p;
       return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_create: bad per-GP config");
     }

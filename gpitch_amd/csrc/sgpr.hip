@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) sgpr_finish_kernel(const double* __restri
       const double* th = params + toff[p];
       double v = th[0];
       vabs += fabs(v);
-      if (ktype[p] == GP_KERN_MERCER_MATERN12SM || ktype[p] == GP_KERN_MATERN12SM) {
+      if (gp_kern_kdiag_energy(ktype[p])) {
         double s = 0.0;
         for (int q = 0; q < km[p]; q++) s += th[2 + q];
         v *= s;
@@ -194,8 +194,8 @@ gp_status gp_sgpr_create(gp_handle h, const gp_sgpr_config* cfg, gp_sgpr_plan* o
   int64_t off = 1;
   for (int i = 0; i < p->P; i++) {
     const int t = cfg->kern_type[i], m = cfg->partials[i];
-    const bool sm = (t == GP_KERN_MERCER_MATERN12SM || t == GP_KERN_MATERN12SM);
-    if (t < 0 || t > GP_KERN_MATERN12SM || (sm && (m < 1 || m > 32)) || (!sm && m != 0)) {
+    const bool sm = gp_kern_has_partials(t);
+    if (t < 0 || t > GP_KERN_LAST || (sm && (m < 1 || m > 32)) || (!sm && m != 0)) {
       delete p;
       return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_create: bad kernel config");
     }
@@ -447,7 +447,7 @@ static gp_status sgpr_enqueue_bound_grad(gp_sgpr_plan p, const double* params, c
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
     // the feature tables hold the LAST kernel built: rebuild this kernel's (Z and X) before contracting
-    if (k.type == GP_KERN_MERCER_MATERN12SM) {
+    if (gp_kern_is_mercer(k.type)) {
       // cheap: two feature passes; the covariance values themselves are not needed again
       GP_CHECK(launch_sm_features(h, k, Z, M, X, N, p->feat));
     }
@@ -647,7 +647,7 @@ gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const dou
     for (int i = 0; i < p->P; i++) {
       const double* t = th.data() + p->off_theta[i];
       double v = t[0];
-      if (p->ktype[i] == GP_KERN_MERCER_MATERN12SM || p->ktype[i] == GP_KERN_MATERN12SM) {
+      if (gp_kern_kdiag_energy(p->ktype[i])) {
         double s = 0.0;
         for (int q = 0; q < p->m[i]; q++) s += t[2 + q];
         v *= s;

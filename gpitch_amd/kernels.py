@@ -67,6 +67,9 @@ class Kern(Parameterized):
     def __add__(self, other):
         return Add([self, other])
 
+    def __mul__(self, other):
+        return Prod(self, other)
+
     def __radd__(self, other):
         if other == 0:  # np.sum(list_of_kernels) starts from 0
             return self
@@ -114,6 +117,111 @@ class Matern52(Stationary):
 class RBF(Stationary):
     type_code = _lib.KERN_RBF
     oracle_name = "rbf"
+
+
+class Matern32sm(Kern):
+    """Matern spectral mixture kernel with single lengthscale (gpitch/kernels.py:204-258; init_models.py:84,96):
+    K = (1 + r1) exp(-r1) sum_k variance_k cos(2 pi f_k r),  r = |x - x' + 1e-12|,  r1 = sqrt(3) r / l.
+    lengthscales ~ Logistic(0, 2), variance_k ~ Logistic(0, 0.25), frequency_k positive (:219-223)."""
+    type_code = _lib.KERN_MATERN32SM
+    oracle_name = "matern32sm"
+
+    def __init__(self, input_dim, num_partials, lengthscales=None, variances=None, frequencies=None):
+        Kern.__init__(self, input_dim, active_dims=None)
+        self.ARD = False
+        self.num_partials = int(num_partials)
+        if lengthscales is None:      # kernels.py:215-218
+            lengthscales = 1.
+            variances = 0.125 * np.ones((num_partials, 1))
+            frequencies = 1. * (1. + np.arange(num_partials))
+        variances = np.asarray(variances, dtype=np.float64).reshape(-1)
+        frequencies = np.asarray(frequencies, dtype=np.float64).reshape(-1)
+        self.lengthscales = Param(lengthscales, transforms.Logistic(0., 2.))
+        self.variance = ParamList([Param(variances[i], transforms.Logistic(0., 0.25)) for i in range(self.num_partials)])
+        self.frequency = ParamList([Param(frequencies[i], transforms.positive) for i in range(self.num_partials)])
+        self._unit = Param(1.0)       # the C-ABI layout keeps a global variance slot: 1, never trained
+        self._unit.fixed = True
+
+    def vars_n_freqs_fixed(self, fix_var=True, fix_freq=False):
+        """kernels.py:255-258"""
+        for i in range(self.num_partials):
+            self.variance[i].fixed = fix_var
+            self.frequency[i].fixed = fix_freq
+
+    def theta(self):
+        return np.concatenate([[1.0, self.lengthscales.value[0]], [v.value[0] for v in self.variance],
+                               [f.value[0] for f in self.frequency]])
+
+    def theta_params(self):
+        return [self._unit, self.lengthscales] + list(self.variance) + list(self.frequency)
+
+    def oracle_dict(self):
+        return {"type": self.oracle_name, "variance": 1.0, "lengthscales": float(self.lengthscales.value[0]),
+                "energy": [float(v.value[0]) for v in self.variance],
+                "frequency": [float(f.value[0]) for f in self.frequency]}
+
+
+class MercerCosMix(Kern):
+    """The Mercer Cosine Mixture kernel (gpitch/kernels.py:321-376): K = variance * Phi(x)^T Phi(x'),
+    Kdiag = variance.  On the gpitch path it only appears as a factor of Matern52 * MercerCosMix
+    (init_models.py:183-198), which is what the engine implements (see Prod)."""
+
+    def __init__(self, input_dim, energy=np.asarray([1.]), frequency=np.asarray([2 * np.pi]), variance=1.0,
+                 features_as_params=False):
+        Kern.__init__(self, input_dim, active_dims=None)
+        self.num_features = len(frequency)
+        self.variance = Param(variance, transforms.Logistic(0., 0.25))
+        energy = np.asarray(energy, dtype=np.float64).reshape(-1)
+        frequency = np.asarray(frequency, dtype=np.float64).reshape(-1)
+        self.energy = ParamList([Param(e, transforms.positive) for e in energy])
+        self.frequency = ParamList([Param(f, transforms.positive) for f in frequency])
+        if not features_as_params:      # plain arrays in the reference: never trained
+            self.energy.fixed = True
+            self.frequency.fixed = True
+
+
+class Prod(Kern):
+    """k1 * k2 for the one product the reference builds: Matern52 * MercerCosMix (init_models.py:188-193)
+    = v52 v_c (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r) sum_k e_k cos(2 pi f_k (x - x')).
+    The engine carries the product v52 * v_c as one (fixed) variance: the reference fixes both factors' variances
+    (init_models.py:189,192); the Matern52 lengthscale and, with features_as_params, energies / frequencies train."""
+    type_code = _lib.KERN_MERCER_MATERN52SM
+    oracle_name = "mercer_matern52sm"
+
+    def __init__(self, k1, k2):
+        Kern.__init__(self, 1)
+        if isinstance(k2, Matern52) and isinstance(k1, MercerCosMix):
+            k1, k2 = k2, k1
+        if not (isinstance(k1, Matern52) and isinstance(k2, MercerCosMix)):
+            raise NotImplementedError("only Matern52 * MercerCosMix products are used on the gpitch path")
+        self.kern_list = [k1, k2]
+        self._kern_params = ParamList([k1, k2])
+        self.num_partials = k2.num_features
+        self._variance = Param(1.0, transforms.positive)
+
+    def _sync_variance(self):
+        k1, k2 = self.kern_list
+        if not (k1.variance.fixed and k2.variance.fixed):
+            # a trainable factor variance would need its own transform slot; the reference fixes both
+            raise NotImplementedError("Matern52 * MercerCosMix: both variances must be fixed (init_models.py:189,192)")
+        self._variance.value = k1.variance.value * k2.variance.value
+        self._variance.fixed = True
+        return self._variance
+
+    def theta(self):
+        k1, k2 = self.kern_list
+        return np.concatenate([[self._sync_variance().value[0], k1.lengthscales.value[0]],
+                               [e.value[0] for e in k2.energy], [f.value[0] for f in k2.frequency]])
+
+    def theta_params(self):
+        k1, k2 = self.kern_list
+        return [self._sync_variance(), k1.lengthscales] + list(k2.energy) + list(k2.frequency)
+
+    def oracle_dict(self):
+        k1, k2 = self.kern_list
+        return {"type": self.oracle_name, "variance": float(self._sync_variance().value[0]),
+                "lengthscales": float(k1.lengthscales.value[0]),
+                "energy": [float(e.value[0]) for e in k2.energy], "frequency": [float(f.value[0]) for f in k2.frequency]}
 
 
 class Add(Kern):

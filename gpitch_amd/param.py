@@ -15,6 +15,14 @@ class Identity(object):
     def backward(self, y):
         return np.asarray(y, dtype=np.float64)
 
+    def dforward(self, x):
+        """d forward(x) / dx (the factor GPflow's free-state gradient carries)"""
+        return np.ones_like(np.asarray(x, dtype=np.float64))
+
+    def device_code(self, handle):
+        """transform code of the C-ABI (include/gpitch_abi.h gp_transform_forward)"""
+        return self.code
+
 
 class Log1pe(object):
     """GPflow transforms.positive: y = log(1 + exp(x)) + 1e-6."""
@@ -30,10 +38,44 @@ class Log1pe(object):
         y = np.asarray(y, dtype=np.float64) - self._lower
         return y + np.log(-np.expm1(-y))
 
+    def dforward(self, x):
+        return 1. / (1. + np.exp(-np.asarray(x, dtype=np.float64)))
+
+    def device_code(self, handle):
+        return self.code
+
+
+class Logistic(object):
+    """gpflow.transforms.Logistic(a, b): y = a + (b - a) / (1 + exp(-x)) (kernels.py:219-223,333;
+    init_models.py:189).  On the device the (a, b) pair is registered per handle."""
+
+    def __init__(self, a=0., b=1.):
+        if not b > a:
+            raise ValueError("Logistic(a, b) needs b > a")
+        self.a, self.b = float(a), float(b)
+
+    def forward(self, x):
+        ex = np.exp(-np.asarray(x, dtype=np.float64))
+        return self.a + (self.b - self.a) / (1. + ex)
+
+    def backward(self, y):
+        return -np.log((self.b - self.a) / (np.asarray(y, dtype=np.float64) - self.a) - 1.)
+
+    def dforward(self, x):
+        s = 1. / (1. + np.exp(-np.asarray(x, dtype=np.float64)))
+        return (self.b - self.a) * s * (1. - s)
+
+    def device_code(self, handle):
+        import ctypes as C
+        code = C.c_uint8()
+        handle.check(handle.lib.gp_transform_register_logistic(handle.h, self.a, self.b, C.byref(code)))
+        return int(code.value)
+
 
 class transforms(object):
     Identity = Identity
     Log1pe = Log1pe
+    Logistic = Logistic
     positive = Log1pe()
 
 

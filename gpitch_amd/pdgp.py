@@ -180,7 +180,7 @@ class Pdgp(Parameterized):
         for off, p in self._segments():
             v = p.value.reshape(-1)
             host[off:off + v.size] = v
-            tc[off:off + v.size] = 2 if p.fixed else p.transform.code
+            tc[off:off + v.size] = 2 if p.fixed else p.transform.device_code(h)
         self._params.copy_(h.torch.as_tensor(host))
         self._tcode.copy_(h.torch.as_tensor(tc))
         # `.fixed` Params drop out of the backward pass (GPflow removes them from the free state)
@@ -275,10 +275,13 @@ class Pdgp(Parameterized):
                                            self._params.data_ptr()))
         f = self._elbo(True)
         g = self._grad.cpu().numpy()
-        tc = self._tcode.cpu().numpy()
         xf = np.asarray(x_free, dtype=np.float64)
-        g = np.where(tc == 1, g / (1. + np.exp(-xf)), g)
-        g = np.where(tc == 2, 0., g)
+        # chain rule through each Param's transform (fixed Params drop out)
+        scale = np.zeros_like(g)
+        for off, p in self._segments():
+            if not p.fixed:
+                scale[off:off + p.size] = p.transform.dforward(xf[off:off + p.size])
+        g = g * scale
         return -f, -g
 
     def get_free_state(self):

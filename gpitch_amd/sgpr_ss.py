@@ -175,7 +175,7 @@ class SGPRSS(Parameterized):
         g = grad.cpu().numpy()
         gf = np.empty(len(free_idx))
         for j, i in enumerate(free_idx):
-            dydx = 1. / (1. + np.exp(-x_free[j])) if ps[i].transform.code == 1 else 1.
+            dydx = float(ps[i].transform.dforward(np.array([x_free[j]]))[0])
             gf[j] = g[i] * dydx
         return -out.value, -gf
 

@@ -48,7 +48,12 @@ enum {
   GP_KERN_MATERN52 = 2,          /* gpflow.kernels.Matern52  (init_models.py:188)                */
   GP_KERN_RBF = 3,               /* gpflow.kernels.RBF                                            */
   GP_KERN_MERCER_MATERN12SM = 4, /* gpitch/matern12_spectral_mixture.py:70-133                    */
-  GP_KERN_MATERN12SM = 5         /* gpitch/matern12_spectral_mixture.py:14-67                     */
+  GP_KERN_MATERN12SM = 5,        /* gpitch/matern12_spectral_mixture.py:14-67                     */
+  GP_KERN_MATERN32SM = 6,        /* gpitch/kernels.py:204-258 (init_models.py:84,96): broadcast form, Matern-3/2
+                                  * envelope; theta = [1 (unused, fixed), lengthscales, variance_k.., frequency_k..] */
+  GP_KERN_MERCER_MATERN52SM = 7  /* Matern52 * MercerCosMix product (init_models.py:183-198, kernels.py:321-376):
+                                  * theta = [v52 * v_cosmix, lengthscales, energy_k.., frequency_k..];
+                                  * Kdiag = variance (MercerCosMix.Kdiag fills its variance, no energy sum) */
 };
 
 /* nonlinearities of the modulated likelihood — gpitch/methods.py:216-233 */
@@ -196,7 +201,10 @@ gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xn
 
 /* ---- optimiser on the free state (GPflow Model.optimize with tf.train.AdamOptimizer;
  *      demo-modgp.py:44-45; transforms: GPflow Log1pe 'positive') -----------------------------------
- * tcode[i]: 0 identity, 1 positive (y = log(1+e^x) + 1e-6), 2 fixed (identity, no update). */
+ * tcode[i]: 0 identity, 1 positive (y = log(1+e^x) + 1e-6), 2 fixed (identity, no update),
+ *           3.. gpflow.transforms.Logistic(a, b): y = a + (b-a)/(1+e^-x), with (a, b) registered on the handle
+ *           (kernels.py:219-223 Logistic(0,2) / Logistic(0,0.25); init_models.py:189 Logistic(0,0.5)). */
+gp_status gp_transform_register_logistic(gp_handle h, double a, double b, uint8_t* code_out);
 gp_status gp_transform_forward(gp_handle h, const double* free_state, const uint8_t* tcode, int64_t n,
                                double* params);
 gp_status gp_transform_backward(gp_handle h, const double* params, const uint8_t* tcode, int64_t n,

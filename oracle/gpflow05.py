@@ -101,6 +101,28 @@ def K(kern, X, X2=None, xp=NP):
         for i in range(1, len(kern["frequency"])):
             k = k + xp.scalar(kern["energy"][i]) * xp.cos(2. * np.pi * xp.scalar(kern["frequency"][i]) * r)
         return v * xp.exp(-r1) * k
+    if t == "matern32sm":
+        # gpitch/kernels.py:232-247: r = sqrt((x-x'+1e-12)^2); r1 = sqrt(3) r / l;
+        # k = sum_i variance_i (1 + r1) exp(-r1) cos(2 pi f_i r)   (the dict's "energy" holds variance_i;
+        # there is no global variance: kern["variance"] is 1)
+        if X2 is None:
+            X2 = X
+        r = xp.sqrt(xp.square(xp.reshape(X, (-1, 1)) - xp.reshape(X2, (1, -1)) + 1e-12))
+        r1 = np.sqrt(3.) * (r / xp.scalar(kern["lengthscales"]))
+        k = xp.scalar(kern["energy"][0]) * (1. + r1) * xp.exp(-r1) * xp.cos(2. * np.pi * xp.scalar(kern["frequency"][0]) * r)
+        for i in range(1, len(kern["frequency"])):
+            k = k + xp.scalar(kern["energy"][i]) * (1. + r1) * xp.exp(-r1) * \
+                xp.cos(2. * np.pi * xp.scalar(kern["frequency"][i]) * r)
+        return v * k
+    if t == "mercer_matern52sm":
+        # Matern52 * MercerCosMix (init_models.py:183-198): GPflow Prod = elementwise product of
+        # Matern52.K (variance v52, euclid_dist) and MercerCosMix.K = (phi * v_c)^T phi2 (kernels.py:358-370).
+        # kern["variance"] holds v52 * v_c.
+        r = euclid_dist(X, X2, xp.scalar(kern["lengthscales"]), xp)
+        phi = phi_features(kern, X, xp)
+        phi2 = phi if X2 is None else phi_features(kern, X2, xp)
+        k52 = (1. + np.sqrt(5.) * r + 5. / 3. * xp.square(r)) * xp.exp(-np.sqrt(5.) * r)
+        return v * k52 * xp.matmul(xp.t(phi), phi2)
     # GPflow 0.5 stationary kernels (call sites init_kernels.py:12, init_models.py:83,
     # demo-modgp.py:32)
     ls = xp.scalar(kern["lengthscales"])
@@ -120,7 +142,9 @@ def Kdiag(kern, X, xp=NP):
     """Kern.Kdiag(X): exact fill, NOT diag(K(X)) (m12sm.py:58-62, :119-121; GPflow Stationary)."""
     n = X.shape[0]
     v = xp.scalar(kern["variance"])
-    if kern["type"] in ("mercer_matern12sm", "matern12sm"):
+    # (Matern32sm.Kdiag, kernels.py:249-253: sum of its variances; the Matern52 * MercerCosMix product has
+    #  Kdiag = v52 * v_c: MercerCosMix.Kdiag fills its variance, kernels.py:372-373 — no energy sum)
+    if kern["type"] in ("mercer_matern12sm", "matern12sm", "matern32sm"):
         s = xp.scalar(kern["energy"][0])
         for i in range(1, len(kern["energy"])):
             s = s + xp.scalar(kern["energy"][i])

@@ -13,6 +13,18 @@ def kernels_from_problem(prob):
         if d["type"] == "mercer_matern12sm":
             return MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]),
                                     variance=d["variance"], lengthscales=d["lengthscales"])
+        if d["type"] == "matern32sm":
+            from gpitch_amd.kernels import Matern32sm
+            return Matern32sm(1, len(d["frequency"]), lengthscales=d["lengthscales"], variances=np.array(d["energy"]),
+                              frequencies=np.array(d["frequency"]))
+        if d["type"] == "mercer_matern52sm":
+            from gpitch_amd.kernels import Matern52, MercerCosMix
+            a = Matern52(1, lengthscales=d["lengthscales"], variance=1.0)
+            a.variance.fixed = True
+            b = MercerCosMix(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=d["variance"],
+                             features_as_params=True)
+            b.variance.fixed = True
+            return a * b
         if d["type"] == "matern12sm":
             return Matern12sm(1, variance=d["variance"], lengthscales=d["lengthscales"],
                               energy=np.array(d["energy"]), frequency=np.array(d["frequency"]))

@@ -123,3 +123,55 @@ def test_windowing_and_overlap_add():
     assert len(xs) == 3 and ys[2].shape == (3000, 1)
     xa, ya = wo.segmented(x, y, window_size=3000, aug=True)
     assert ya[0].shape == (3000 + 3200, 1) and ya[0][:1600].max() == 0
+
+
+def test_init_cparam_and_kernel_initialisers():
+    """host-side initialisers of SURVEY 8f rank 1 / 4 (methods.py:91-153, init_models.py:74-121,154-198): spectral
+    peaks of a synthetic note become the Matern32sm frequencies / variances; the reference's quirks are kept."""
+    import gpitch_amd
+    from gpitch_amd import init_models
+    from gpitch_amd.kernels import Matern32sm, Prod
+    from gpitch_amd.methods import find_ideal_f0, init_cparam, midi2freq, peak_indexes
+    from gpitch_amd.param import Logistic
+    assert find_ideal_f0(['011PFNOF_M60_train.wav']) == [261.6255653005986]      # demo_modgp-real-audio.ipynb:66
+    # peak picker: plateau -> its middle; weaker neighbours within min_dist are suppressed
+    y = np.array([0., 1., 0., 2., 2., 2., 0., .5, 3., .5, 0.])
+    assert list(peak_indexes(y, thres=0.1, min_dist=1)) == [1, 4, 8]
+    assert list(peak_indexes(y, thres=0.1, min_dist=3)) == [4, 8]      # 4 (height 2) shadows 1 (height 1)
+    assert list(peak_indexes(y, thres=0.1, min_dist=4)) == [1, 8]      # 8 (height 3) shadows 4, which then spares 1
+    assert list(peak_indexes(y, thres=0.8, min_dist=1)) == [8]
+    fs, N = 16000, 16000
+    x = np.arange(N) / float(fs)
+    f0 = midi2freq(60)
+    amps = {1: 1.0, 2: 0.5, 3: 0.25}
+    y = sum(a * np.sin(2 * np.pi * k * f0 * x) for k, a in amps.items()) + 1e-3 * np.random.RandomState(0).randn(N)
+    freq, var, F, S, thres = init_cparam(y, fs, maxh=3, ideal_f0=f0)
+    assert freq.size == 3 and np.all(np.abs(freq - f0 * np.array([1, 2, 3])) < 1.5)
+    assert abs(var.sum() - 1.) < 1e-12 and var[0] > var[1] > var[2]
+    kern, iparam = init_models.init_kernel_training([y], ['note_M60_x.wav'], fs, maxh=3)
+    kc = kern[1][0]
+    assert isinstance(kc, Matern32sm) and kc.num_partials == 3
+    assert all(v.fixed for v in kc.variance) and not any(f.fixed for f in kc.frequency)     # vars_n_freqs_fixed()
+    assert isinstance(kc.lengthscales.transform, Logistic) and kc.lengthscales.transform.b == 2.
+    np.testing.assert_allclose([f.value[0] for f in kc.frequency], iparam[0][0])
+
+    class _M(object):           # a "trained per-pitch model" as init_kernel_with_trained_models reads it
+        kern_act, kern_com = [kern[0][0]], [kc]
+    kern[0][0].lengthscales = 0.3
+    k2 = init_models.init_kernel_with_trained_models([_M()])
+    assert k2[0][0].lengthscales.value[0] == 0.3 and not k2[0][0].lengthscales.fixed
+    assert not k2[1][0].lengthscales.fixed and all(v.fixed for v in k2[1][0].variance)
+    np.testing.assert_allclose(k2[1][0].theta(), kc.theta())
+    k3 = init_models.init_kern(2, [np.array([.6, .4])] * 2, [np.array([100., 200.])] * 2)
+    p = k3[1][0]
+    assert isinstance(p, Prod) and p.type_code == 7
+    np.testing.assert_allclose(p.theta(), [0.25, 0.25, .6, .4, 100., 200.])
+    assert [q.fixed for q in p.theta_params()] == [True, False, True, True, True, True]
+    f, e = init_models.get_features(np.arange(10.), np.arange(10.) + 1., None, 1, False, 3)
+    np.testing.assert_allclose(f, [9., 8., 7.])
+    np.testing.assert_allclose(e, np.array([10., 9., 8.]) / 27.)
+    # Logistic transform round trip and derivative (host mirror of the device kernels)
+    t = Logistic(0., 0.5)
+    xs = np.linspace(-4, 4, 9)
+    np.testing.assert_allclose(t.backward(t.forward(xs)), xs, atol=1e-12)
+    np.testing.assert_allclose(t.dforward(xs), (t.forward(xs + 1e-6) - t.forward(xs - 1e-6)) / 2e-6, rtol=1e-6)

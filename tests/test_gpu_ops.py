@@ -13,7 +13,8 @@ def _theta(k):
     return np.array([k["variance"], k["lengthscales"]] + list(k["energy"]) + list(k["frequency"]), dtype=np.float64)
 
 
-_KT = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3, "mercer_matern12sm": 4, "matern12sm": 5}
+_KT = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3, "mercer_matern12sm": 4, "matern12sm": 5,
+       "matern32sm": 6, "mercer_matern52sm": 7}
 
 
 def _desc(h, k):
@@ -33,6 +34,10 @@ KERNELS = [
     {"type": "mercer_matern12sm", "variance": 1.0, "lengthscales": 0.1, "energy": [1. / 20] * 20,
      "frequency": [261.6 * (i + 1) for i in range(20)]},
     {"type": "matern12sm", "variance": 0.9, "lengthscales": 0.2, "energy": [0.6, 0.4], "frequency": [100., 205.]},
+    {"type": "matern32sm", "variance": 1.0, "lengthscales": 0.7, "energy": [0.12, 0.2, 0.05],
+     "frequency": [110., 221., 330.5]},
+    {"type": "mercer_matern52sm", "variance": 0.25, "lengthscales": 0.25, "energy": [0.5, 0.3, 0.1, 0.1],
+     "frequency": [196., 392., 588., 784.]},
 ]
 
 
@@ -191,3 +196,39 @@ def test_gauss_kl_whitened(gp_handle):
                               C.byref(out), ws.data_ptr(), ws.numel()))
     ref = orc.gauss_kl(q_mu, q_sqrt)
     assert abs(out.value - ref) <= 1e-12 * abs(ref)
+
+
+def test_logistic_transform_and_adam_step(gp_handle):
+    """gpflow.transforms.Logistic(a, b) (kernels.py:219-223, init_models.py:189) on the device: forward / backward
+    round trip, and one Adam step on a mixed free-state vector against the host formulas."""
+    from gpitch_amd.param import Identity, Log1pe, Logistic
+    h = gp_handle
+    tr = [Identity(), Log1pe(), Logistic(0., 2.), Logistic(0., 0.25), Logistic(0., 0.5), Logistic(-1., 3.)]
+    codes = [t.device_code(h) for t in tr]
+    assert codes[:2] == [0, 1] and len(set(codes)) == len(codes) and all(c >= 3 for c in codes[2:])
+    assert Logistic(0., 2.).device_code(h) == codes[2]            # registering the same pair again reuses its code
+    rng = np.random.RandomState(0)
+    n = 600
+    which = rng.randint(0, len(tr), n)
+    x = rng.randn(n) * 2.0
+    tc = np.array([codes[w] for w in which], dtype=np.uint8)
+    y_ref = np.array([tr[w].forward(np.array([xi]))[0] for w, xi in zip(which, x)])
+    t = h.torch
+    dx, dtc, dy, dback = h.to_device(x), t.as_tensor(tc, device=h.device), h.empty(n), h.empty(n)
+    h.check(h.lib.gp_transform_forward(h.h, dx.data_ptr(), dtc.data_ptr(), n, dy.data_ptr()))
+    np.testing.assert_allclose(dy.cpu().numpy(), y_ref, rtol=1e-14, atol=1e-15)
+    h.check(h.lib.gp_transform_backward(h.h, dy.data_ptr(), dtc.data_ptr(), n, dback.data_ptr()))
+    np.testing.assert_allclose(dback.cpu().numpy(), x, rtol=1e-8, atol=1e-8)
+    # one Adam step (TF-1.2 rule) maximising: g_free = -(grad * dy/dx)
+    grad = rng.randn(n)
+    m, v = h.zeros(n), h.zeros(n)
+    dg = h.to_device(grad)
+    lr, b1, b2, eps = 0.01, 0.9, 0.999, 1e-8
+    h.check(h.lib.gp_adam_step(h.h, dx.data_ptr(), dy.data_ptr(), dg.data_ptr(), dtc.data_ptr(), m.data_ptr(),
+                               v.data_ptr(), n, 1, lr, b1, b2, eps))
+    gf = -grad * np.array([tr[w].dforward(np.array([xi]))[0] for w, xi in zip(which, x)])
+    m1, v1 = (1 - b1) * gf, (1 - b2) * gf * gf
+    x1 = x - lr * np.sqrt(1 - b2) / (1 - b1) * m1 / (np.sqrt(v1) + eps)
+    np.testing.assert_allclose(dx.cpu().numpy(), x1, rtol=1e-12, atol=1e-14)
+    y1 = np.array([tr[w].forward(np.array([xi]))[0] for w, xi in zip(which, x1)])
+    np.testing.assert_allclose(dy.cpu().numpy(), y1, rtol=1e-13, atol=1e-15)
