@@ -8,8 +8,8 @@
 //   tf.matmul(A, A, transpose_b=True)     ->  split-K "NT" product over the frame dimension
 // plus every M x M x M product of the backward pass (Cholesky adjoint etc.).
 //
-// Design for CDNA4: 256-thread workgroups (4 wavefronts as 2 x 2), v_mfma_f64_16x16x4_f64,
-// 128 x 128 (strip) or 64 x 64 (small) output tiles, BK = 16, operands staged global -> registers ->
+// Design for CDNA4: 256-thread workgroups (4 wavefronts: 1 x 4 for the 128-tiles, 2 x 2 for the 64-tiles),
+// v_mfma_f64_16x16x4_f64, 128 x 128 (strip) or 64 x 64 (small) output tiles, BK = 16, operands staged global -> registers ->
 // LDS with one barrier per K-tile (double-buffered LDS, next tile's global loads in flight during the
 // MFMAs), LDS strides padded so that every fragment read is bank-conflict free for ds_read_b64
 // (k-contiguous tiles use the odd stride BK+1, row-contiguous tiles use stride B+16).
