@@ -15,6 +15,7 @@
 // walks one block column with MFMA products; a 16x16 f64 accumulator register r is exactly the
 // B-fragment of k-step r, so the chained product -W_ii * (sum_k L_ik W_kj) needs no data movement.
 #include "common.h"
+#include <string.h>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -32,7 +33,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 // Factor the 32 x 32 diagonal block at (k0, k0) entirely in the registers of ONE wavefront (lane i holds row i;
 // pivots / columns are broadcast with v_readlane), write L_kk to global and its inverse to Dinv (LDS).
 __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t ld, int M, int k0, int lane,
-                                                double (*Dinv)[CH_NB + 1], int* __restrict__ status, int b) {
+                                                double (*Dinv)[CH_NB + 1], int* __restrict__ status, int b, int pbase) {
   const int nb = min(CH_NB, M - k0);
   double row[CH_NB];
   const int i = lane & 31;
@@ -44,7 +45,7 @@ __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t 
     double djj = lane_bcast(row[j], j);
     if (!(djj > 0.0)) {  // non-positive or NaN pivot: report the first one, keep going finite
       if (lane == 0 && j < nb) {
-        if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = k0 + j; status[2] = b; }
+        if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = pbase + k0 + j; status[2] = b; }
       }
       djj = 1.0;
     }
@@ -79,7 +80,8 @@ __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t 
 
 __global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,
                                                           const int* __restrict__ lds_, int* __restrict__ status,
-                                                          double* single_mat, int single_M, int single_ld, int panel_rows_cap) {
+                                                          double* single_mat, int single_M, int single_ld, int panel_rows_cap,
+                                                          int pivot_base) {
   const int b = blockIdx.x;
   double* A = mats ? mats[b] : single_mat;
   const int M = mats ? Ms[b] : single_M;
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restr
   const int kq = lane >> 4, lc = lane & 15;
   const bool p_lds = (panel_rows_cap >= M - CH_NB);   // operands of the trailing update come from LDS
 
-  if (wave == 0) chol_diag_block(A, ld, M, 0, lane, D[0], status, b);
+  if (wave == 0) chol_diag_block(A, ld, M, 0, lane, D[0], status, b, pivot_base);
   __syncthreads();
 
   int pb = 0;
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restr
       }
       if (t == 0) {
         __threadfence_block();  // this wave's own updates of the block it is about to read back
-        chol_diag_block(A, ld, M, r0, lane, D[pb ^ 1], status, b);
+        chol_diag_block(A, ld, M, r0, lane, D[pb ^ 1], status, b, pivot_base);
       }
     }
     __threadfence_block();
@@ -343,19 +345,19 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
   size_t sh = chol_smem_bytes(maxM, &cap);
   GP_CHECK(chol_set_attr(h));
   hipLaunchKernelGGL(chol_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_M, d_ld, h->d_status,
-                     (double*)nullptr, 0, 0, cap);
+                     (double*)nullptr, 0, 0, cap, 0);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
 
-gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld) {
+gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld, int pivot_base) {
   if (M <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_CHOL);
   int cap = 0;
   size_t sh = chol_smem_bytes(M, &cap);
   GP_CHECK(chol_set_attr(h));
   hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(CH_THREADS), sh, h->stream, (double* const*)nullptr,
-                     (const int*)nullptr, (const int*)nullptr, h->d_status, A, M, (int)ld, cap);
+                     (const int*)nullptr, (const int*)nullptr, h->d_status, A, M, (int)ld, cap, pivot_base);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -376,6 +378,79 @@ gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, doub
   hipLaunchKernelGGL(tri_inverse_kernel, dim3(batch), dim3(CH_THREADS), 0, h->stream, d_L, d_W, d_M, d_ld,
                      (const double*)nullptr, (double*)nullptr, 0, 0);
   GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One LARGE matrix (the exact-GP N x N covariance of SGPRSS.predict_s, N = 2001 per window: sgpr_ss.py:88-94):
+// the one-workgroup kernels above would serialise 2 N^3/3 flops on a single CU (72 ms at N = 2001), so the
+// factorisation is blocked on the host over 128-column panels and the O(N^3) parts go to the matrix-core GEMMs:
+//   for each panel k:  L_kk = chol(A_kk) and W_kk = L_kk^-1 (one-workgroup kernels, 128 x 128)
+//                      P = A[k+1:, k] W_kk^T                 (GEMM)   -> written back as L[k+1:, k]
+//                      A[k+1:, k+1:] -= P P^T  (lower part)  (GEMM)
+//   W = L^-1 by block rows:  W[i, :i] = -W_ii (L[i, :i] W[:i, :i])      (2 GEMMs per block row)
+// A is overwritten by L (lower triangle; the strict upper triangle is NOT cleared), W gets zeros above the diagonal.
+#define CHL_NB 128
+size_t cholesky_large_workspace_bytes(int N) {
+  const int nblk = (N + CHL_NB - 1) / CHL_NB;
+  const size_t ldT = (size_t)((N + 1) & ~1);
+  return gp_align_up((size_t)4 * nblk * sizeof(GemmProblem), 256) + gp_align_up((size_t)CHL_NB * ldT * sizeof(double), 256) + 512;
+}
+
+gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_t ld, void* ws, size_t ws_bytes) {
+  if (N <= 0) return GP_OK;
+  if ((ld & 1) || ld < N) return gp_fail(h, GP_ERR_BAD_ARG, "launch_cholesky_large: ld must be even and >= N");
+  GpArena ar(ws, ws_bytes);
+  const int nblk = (N + CHL_NB - 1) / CHL_NB;
+  GemmProblem* d_probs = ar.take<GemmProblem>((size_t)4 * nblk);
+  const int64_t ldT = (N + 1) & ~1;
+  double* T = ar.take<double>((size_t)CHL_NB * ldT);     // panel (N x 128, ld 128) or block row (128 x N, ld ldT)
+  if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, "launch_cholesky_large: workspace too small");
+  std::vector<GemmProblem> hp((size_t)4 * nblk);
+  memset(hp.data(), 0, hp.size() * sizeof(GemmProblem));
+  for (int k = 0; k < nblk; k++) {
+    const int c0 = k * CHL_NB, nb = (N - c0 < CHL_NB) ? N - c0 : CHL_NB, r0 = c0 + nb, mrem = N - r0;
+    double* Akk = A + (int64_t)c0 * ld + c0;
+    double* Wkk = W + (int64_t)c0 * ld + c0;
+    { GemmProblem& r = hp[4 * k + 0];   // P = A[r0:, c0:c0+nb] W_kk^T
+      r.A = A + (int64_t)r0 * ld + c0; r.lda = ld; r.B = Wkk; r.ldb = ld; r.C = T; r.ldc = CHL_NB; r.M = mrem; r.N = nb; r.K = nb; }
+    { GemmProblem& r = hp[4 * k + 1];   // A[r0:, r0:] -= P P^T
+      r.A = T; r.lda = CHL_NB; r.B = T; r.ldb = CHL_NB; r.C = A + (int64_t)r0 * ld + r0; r.ldc = ld; r.M = mrem; r.N = mrem; r.K = nb; }
+    { GemmProblem& r = hp[4 * k + 2];   // T = L[c0:c0+nb, :c0] W[:c0, :c0]
+      r.A = A + (int64_t)c0 * ld; r.lda = ld; r.B = W; r.ldb = ld; r.C = T; r.ldc = ldT; r.M = nb; r.N = c0; r.K = c0; }
+    { GemmProblem& r = hp[4 * k + 3];   // W[c0:c0+nb, :c0] = -W_kk T
+      r.A = Wkk; r.lda = ld; r.B = T; r.ldb = ldT; r.C = W + (int64_t)c0 * ld; r.ldc = ld; r.M = nb; r.N = c0; r.K = nb; }
+    (void)Akk;
+  }
+  GP_HIP_CHECK(h, hipMemcpyAsync(d_probs, hp.data(), hp.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // hp is a stack object
+  GP_HIP_CHECK(h, hipMemsetAsync(W, 0, (size_t)N * ld * sizeof(double), h->stream));
+  for (int k = 0; k < nblk; k++) {
+    const int c0 = k * CHL_NB, nb = (N - c0 < CHL_NB) ? N - c0 : CHL_NB, r0 = c0 + nb, mrem = N - r0;
+    double* Akk = A + (int64_t)c0 * ld + c0;
+    double* Wkk = W + (int64_t)c0 * ld + c0;
+    GP_CHECK(launch_cholesky_single(h, Akk, nb, ld, c0));
+    GP_CHECK(launch_tri_inverse_single(h, Akk, Wkk, nb, ld));
+    if (mrem > 0) {
+      GemmFlags f;
+      f.transB = 1; f.triB = TRI_UPPER;
+      GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 0, 1, mrem, nb, f));
+      GP_HIP_CHECK(h, hipMemcpy2DAsync(A + (int64_t)r0 * ld + c0, (size_t)ld * sizeof(double), T, CHL_NB * sizeof(double),
+                                       (size_t)nb * sizeof(double), (size_t)mrem, hipMemcpyDeviceToDevice, h->stream));
+      f = GemmFlags();
+      f.transB = 1; f.triC = TRI_LOWER; f.alpha = -1.0; f.beta = 1.0;
+      GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 1, 1, mrem, mrem, f));
+    }
+  }
+  for (int k = 1; k < nblk; k++) {
+    const int c0 = k * CHL_NB, nb = (N - c0 < CHL_NB) ? N - c0 : CHL_NB;
+    GemmFlags f;
+    f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 2, 1, nb, c0, f));
+    f = GemmFlags();
+    f.triA = TRI_LOWER; f.alpha = -1.0;
+    GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 3, 1, nb, c0, f));
+  }
   return GP_OK;
 }
 

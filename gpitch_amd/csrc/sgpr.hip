@@ -592,8 +592,9 @@ size_t gp_sgpr_predict_source_workspace_bytes(int32_t N, int32_t n) {
   const int rb = gemm_rowblocks(N, 1);
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
-  add((size_t)N * N); add((size_t)N * N);     // K -> L, W
+  add((size_t)N * ldN64(N)); add((size_t)N * ldN64(N));     // K -> L, W
   add((size_t)N * ld); add((size_t)N * ld);   // Kx, A
+  d += cholesky_large_workspace_bytes(N) / sizeof(double) + 64;
   add(kernel_build_feat_ws_doubles(32, N, n > N ? n : N));
   add((size_t)rb * n); add((size_t)rb * n); add(N); add(64);
   return d * sizeof(double) + SG_DESC_BYTES + 4096;
@@ -613,8 +614,10 @@ gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const dou
   const int64_t ld = ldN64(n);
   const int rb = gemm_rowblocks(N, 1);
   char* d_desc = ar.take<char>(SG_DESC_BYTES);
-  double* L = ar.take<double>((size_t)N * N);
-  double* W = ar.take<double>((size_t)N * N);
+  const int64_t ldL = ldN64(N);      // even leading dimension: 16-byte operand loads in the GEMMs
+  double* L = ar.take<double>((size_t)N * ldL);
+  double* W = ar.take<double>((size_t)N * ldL);
+  void* chol_ws = ar.take<char>(cholesky_large_workspace_bytes(N));
   double* Kx = ar.take<double>((size_t)N * ld);
   double* A = ar.take<double>((size_t)N * ld);
   double* feat = ar.take<double>(kernel_build_feat_ws_doubles(32, N, n > N ? n : N));
@@ -625,14 +628,19 @@ gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const dou
   if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_predict_source: arena exhausted");
   // K = K_sum(X) + sigma^2 I ; L = chol(K) ; W = L^-1 ; V = W y   (sgpr_ss.py:88-90)
   for (int i = 0; i < p->P; i++)
-    GP_CHECK(launch_kernel_build(h, sg_kern(p, params, i), X, N, nullptr, N, L, N, i > 0, 0.0, feat));
-  hipLaunchKernelGGL(add_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, L, N, (int64_t)N, params, 1.0, 0.0);
-  GP_CHECK(launch_cholesky_single(h, L, N, N));
-  GP_CHECK(launch_tri_inverse_single(h, L, W, N, N));
+    GP_CHECK(launch_kernel_build(h, sg_kern(p, params, i), X, N, nullptr, N, L, ldL, i > 0, 0.0, feat));
+  hipLaunchKernelGGL(add_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, L, N, ldL, params, 1.0, 0.0);
+  if (N > 512) {
+    // N = 2001 per window: blocked over the GEMM kernels instead of one workgroup (72 ms -> a few ms)
+    GP_CHECK(launch_cholesky_large(h, L, W, N, ldL, chol_ws, cholesky_large_workspace_bytes(N)));
+  } else {
+    GP_CHECK(launch_cholesky_single(h, L, N, ldL));
+    GP_CHECK(launch_tri_inverse_single(h, L, W, N, ldL));
+  }
   std::vector<GemmProblem> probs(2);
   memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
-  { GemmProblem& r = probs[0]; r.A = W; r.lda = N; r.M = N; r.v0 = Y; r.o0 = V; }
-  { GemmProblem& r = probs[1]; r.A = W; r.lda = N; r.B = Kx; r.ldb = ld; r.C = A; r.ldc = ld; r.M = N; r.N = n; r.K = N;
+  { GemmProblem& r = probs[0]; r.A = W; r.lda = ldL; r.M = N; r.v0 = Y; r.o0 = V; }
+  { GemmProblem& r = probs[1]; r.A = W; r.lda = ldL; r.B = Kx; r.ldb = ld; r.C = A; r.ldc = ld; r.M = N; r.N = n; r.K = N;
     r.v0 = V; r.o0 = s1; r.o1 = dot; }
   GP_HIP_CHECK(h, hipMemcpyAsync(d_desc, probs.data(), probs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, h->stream));
   GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // probs is a stack object
