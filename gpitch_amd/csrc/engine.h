@@ -69,4 +69,5 @@ size_t cond_batch_desc_bytes(int count);
 bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten);
 gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten);
 // run: Kuu -> chol -> W ; Kuf ; A = W Kuf ; (A2 = W^T A) ; Lq^T A ; reductions -> fmean, fvar
-gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter);
+gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter,
+                         bool reuse_factor = false);

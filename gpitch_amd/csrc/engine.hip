@@ -100,23 +100,27 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten) {
   return GP_OK;
 }
 
-gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter) {
+gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter,
+                         bool reuse_factor) {
   const int G = (int)cb.tasks.size();
   if (G == 0 || N <= 0) return GP_OK;
   if (!cb.uploaded || cb.N != N) return gp_fail(h, GP_ERR_BAD_ARG, "conditional batch descriptors not uploaded");
   const int64_t ldN = ldN_of(N);
-  // 1. Kuu + jitter I
-  for (int g = 0; g < G; g++) {
+  // 1. Kuu + jitter I   (steps 1-2 are skipped when the caller vouches that L and W already hold the factor of
+  //    the current parameters: repeated predictions at new inputs, pdgp.py:17-44 predict_windowed)
+  for (int g = 0; g < G && !reuse_factor; g++) {
     const CondTask& t = cb.tasks[g];
     GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat));
   }
   // 2. Cholesky and inverse (one workgroup per GP)
-  GP_CHECK(launch_cholesky_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
-                                   (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
-                                   cb.maxM));
-  GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)(cb.d_desc + cb.off_chol_ptrs),
-                                      (double* const*)(cb.d_desc + cb.off_w_ptrs),
-                                      (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G));
+  if (!reuse_factor) {
+    GP_CHECK(launch_cholesky_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                     (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
+                                     cb.maxM));
+    GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                        (double* const*)(cb.d_desc + cb.off_w_ptrs),
+                                        (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G));
+  }
   // 3. Kuf
   for (int g = 0; g < G; g++) {
     const CondTask& t = cb.tasks[g];

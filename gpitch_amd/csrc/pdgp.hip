@@ -244,6 +244,7 @@ extern "C" {
 static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double* x, const double* y, int n,
                               double* grad, double* xchg) {
   gp_handle h = p->h;
+  p->factor_valid = false;   // an optimiser step normally follows: predictions must re-factorise
   GP_CHECK(pdgp_bind(p, params, x, n, grad, p->fmean, p->fvar));
   if (grad) GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
   GP_CHECK(cond_batch_run(h, p->cb, x, n, p->whiten != 0, p->jitter));
@@ -316,16 +317,30 @@ gp_status gp_pdgp_elbo_end(gp_pdgp_plan p, const double* params, const double* x
   return pdgp_finish(p, params, x, y, n, num_data, exchange, elbo_dev, elbo_host, grad);
 }
 
-gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n, double* fmean,
-                          double* fvar, double* mean_source) {
+static gp_status pdgp_predict_impl(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n, double* fmean,
+                                   double* fvar, double* mean_source, bool reuse_factor) {
   if (!p) return GP_ERR_BAD_ARG;
   gp_handle h = p->h;
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_predict: workspace not set");
   if (!params || !xnew || !fmean || !fvar || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_predict: bad argument");
+  if (reuse_factor && !p->factor_valid)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_predict_reuse: no factorisation to reuse (call gp_pdgp_predict first)");
   GP_CHECK(pdgp_bind(p, params, xnew, n, nullptr, fmean, fvar));
-  GP_CHECK(cond_batch_run(h, p->cb, xnew, n, p->whiten != 0, p->jitter));
+  GP_CHECK(cond_batch_run(h, p->cb, xnew, n, p->whiten != 0, p->jitter, reuse_factor));
   if (mean_source) GP_CHECK(launch_mean_source(h, fmean, p->P, n, p->nlin, mean_source));
-  return check_not_pd(h);
+  gp_status st = check_not_pd(h);
+  p->factor_valid = (st == GP_OK);
+  return st;
+}
+
+gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n, double* fmean,
+                          double* fvar, double* mean_source) {
+  return pdgp_predict_impl(p, params, xnew, n, fmean, fvar, mean_source, false);
+}
+
+gp_status gp_pdgp_predict_reuse(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n, double* fmean,
+                                double* fvar, double* mean_source) {
+  return pdgp_predict_impl(p, params, xnew, n, fmean, fvar, mean_source, true);
 }
 
 }  // extern "C"

@@ -79,6 +79,14 @@ class transforms(object):
     positive = Log1pe()
 
 
+_version = [0]
+
+
+def param_version():
+    """bumped by every Param assignment anywhere: lets models tell whether their packed device copy is stale"""
+    return _version[0]
+
+
 class Param(object):
     def __init__(self, array, transform=None):
         self._array = np.atleast_1d(np.array(array, dtype=np.float64))
@@ -92,6 +100,7 @@ class Param(object):
     @value.setter
     def value(self, v):
         self._array = np.asarray(v, dtype=np.float64).reshape(self._array.shape).copy()
+        _version[0] += 1
 
     def assign(self, v):
         self.value = np.broadcast_to(np.asarray(v, dtype=np.float64), self._array.shape)

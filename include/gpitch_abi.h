@@ -198,6 +198,11 @@ gp_status gp_pdgp_elbo_end(gp_pdgp_plan p, const double* params, const double* x
  * = nlinfun(mean_act_i) * mean_com_i (pdgp.py:207). */
 gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n,
                           double* fmean, double* fvar, double* mean_source);
+/* The same at further inputs WITHOUT rebuilding Kuu and its Cholesky factor / inverse: valid only when params hold
+ * the values of the preceding gp_pdgp_predict[_reuse] call on this plan (no ELBO evaluation or parameter update in
+ * between).  pdgp.py:17-44 (predict_windowed) re-factorises for every window and for act / com separately. */
+gp_status gp_pdgp_predict_reuse(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n,
+                                double* fmean, double* fvar, double* mean_source);
 
 /* ---- optimiser on the free state (GPflow Model.optimize with tf.train.AdamOptimizer;
  *      demo-modgp.py:44-45; transforms: GPflow Log1pe 'positive') -----------------------------------

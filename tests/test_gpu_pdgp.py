@@ -399,3 +399,38 @@ def test_pitch_sharded_end_requires_matching_begin(gp_handle):
     s._last_batch = s._batch_keep[:2]
     with pytest.raises(Exception):
         s._elbo_end(True)
+
+
+def test_predictions_reuse_factorisation_and_memoise(gp_handle):
+    """predict_windowed (pdgp.py:17-44) calls predict_act and predict_com per window: here the pair is one engine
+    evaluation and later windows reuse Kuu's factorisation (gp_pdgp_predict_reuse) until a Param changes."""
+    import ctypes as C
+    from gpitch_amd.synth import make_problem
+    from gpitch_amd.pdgp import predict_windowed
+    prob = make_problem(1200, 20, 2, num_partials=3, seed=2)
+    m = pdgp_from_problem(prob, handle=gp_handle)
+    x = prob["x"]
+    ref = pdgp_from_problem(prob, handle=gp_handle)          # fresh model: every call factorises
+    full = ref.predict_act_n_com(x)
+    out = predict_windowed(m, x, ws=300)
+    for j in range(2):
+        np.testing.assert_allclose(out[0][j], full[0][j], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(out[1][j], full[1][j], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(out[2][j], full[2][j], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(out[3][j], full[3][j], rtol=1e-11, atol=1e-14)
+    # a parameter change invalidates both the memo and the factorisation
+    m.kern_act[0].lengthscales = 0.7
+    ref.kern_act[0].lengthscales = 0.7
+    a1 = m.predict_act(x[:300])
+    a2 = ref.predict_act(x[:300])
+    np.testing.assert_allclose(a1[0][0], a2[0][0], rtol=1e-12, atol=1e-14)
+    assert not np.allclose(a1[0][0], out[0][0][:300])
+    # reuse without a preceding factorisation is refused by the library
+    fresh = pdgp_from_problem(prob, handle=gp_handle)
+    fresh._pack()
+    h = fresh._handle
+    xs = h.to_device(x[:10].reshape(-1))
+    fm, fv = h.empty(4, 10), h.empty(4, 10)
+    with pytest.raises(Exception):
+        h.check(h.lib.gp_pdgp_predict_reuse(fresh._plan, fresh._params.data_ptr(), xs.data_ptr(), 10, fm.data_ptr(),
+                                            fv.data_ptr(), None))
