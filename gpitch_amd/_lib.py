@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "gp_pdgp_set_workspace", "gp_pdgp_set_grad_needs", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_predict", "gp_pdgp_predict_reuse",
     "gp_transform_register_logistic", "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace",
-    "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
+    "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_exchange_doubles", "gp_sgpr_bound_begin", "gp_sgpr_bound_end", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
 ]
 
@@ -124,6 +124,9 @@ def load_library():
         "gp_sgpr_set_workspace": (i32, [vp, vp, sz]),
         "gp_sgpr_bound": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl)]),
         "gp_sgpr_bound_grad": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl), vp]),
+        "gp_sgpr_exchange_doubles": (i64, [vp]),
+        "gp_sgpr_bound_begin": (i32, [vp, vp, vp, vp, i32, vp, vp]),
+        "gp_sgpr_bound_end": (i32, [vp, vp, vp, vp, i32, i64, vp, vp, vp, C.POINTER(dbl), vp, i32]),
         "gp_sgpr_set_graphs": (i32, [vp, i32]),
         "gp_sgpr_eval_counts": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
         "gp_sgpr_predict_f": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),

@@ -40,6 +40,8 @@ struct gp_sgpr_plan_s {
   bool skip_upload = false;                    // set while re-enqueueing with valid device descriptors
   int graphs = 1;                              // gp_sgpr_set_graphs
   int64_t n_eager = 0, n_captured = 0, n_replayed = 0;
+  // frame-sharded evaluation: what gp_sgpr_bound_begin staged for gp_sgpr_bound_end
+  int staged_N = -1; const double* staged_params = nullptr; const double* staged_X = nullptr;
   ~gp_sgpr_plan_s() { if (gexec) (void)hipGraphExecDestroy(gexec); }
 };
 
@@ -270,9 +272,18 @@ static gp_status sg_upload(gp_sgpr_plan p, const std::vector<GemmProblem>& probs
   return GP_OK;
 }
 
-// shared front part: L, W, Kuf, A' = W Kuf (+ colsumsq), H = A' A'^T, B, LB, WB, u = A' y, c, bound scalar
-static gp_status sgpr_common(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N,
-                             const double* Z, SgDesc* desc) {
+// device pointers of a descriptor block without touching it
+static void sg_desc_ptrs(gp_sgpr_plan p, int slot, SgDesc* out) {
+  const size_t off_int = gp_align_up(20 * sizeof(GemmProblem), 256);
+  char* dd = p->d_desc + (size_t)slot * SG_DESC_BYTES;
+  out->probs = (GemmProblem*)dd;
+  out->toff = (int*)(dd + off_int); out->ktype = out->toff + 256; out->km = out->toff + 512;
+}
+
+// front part over THIS caller's frames (all of them, or one rank's slice of a frame-sharded window):
+// L, W, Kuf, A' = W Kuf (+ colsumsq), H = A' A'^T, u = A' y, sum y^2, sum colsumsq
+static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N,
+                            const double* Z, SgDesc* desc) {
   gp_handle h = p->h;
   const int M = p->M;
   const int64_t ld = ldN64(N);
@@ -299,14 +310,28 @@ static gp_status sgpr_common(gp_sgpr_plan p, const double* params, const double*
   hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, p->scal + 2);
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, h->stream, Y, N, p->scal + 1);
   GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
+  GP_CHECK(launch_rowdot_batched(h, desc->probs + 2, 1, M));
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// back part on the window-wide H, u, sum y^2, tr(H): B, LB, WB, c and the bound scalar (Ntotal frames)
+static gp_status sgpr_global(gp_sgpr_plan p, const double* params, int Ntotal, const SgDesc* desc) {
+  gp_handle h = p->h;
+  const int M = p->M;
   hipLaunchKernelGGL(sgpr_B_kernel, dim3(64), dim3(256), 0, h->stream, p->H, p->LB, M, params);
   GP_CHECK(launch_cholesky_single(h, p->LB, M, M));
   GP_CHECK(launch_tri_inverse_single(h, p->LB, p->WB, M, M));
-  GP_CHECK(launch_rowdot_batched(h, desc->probs + 2, 1, M));
-  hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->WB, p->LB, p->u, p->c, M, N, params, p->P,
-                     desc->toff, desc->ktype, desc->km, p->reg, p->scal);
+  hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->WB, p->LB, p->u, p->c, M, Ntotal, params,
+                     p->P, desc->toff, desc->ktype, desc->km, p->reg, p->scal);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
+}
+
+static gp_status sgpr_common(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N,
+                             const double* Z, SgDesc* desc) {
+  GP_CHECK(sgpr_local(p, params, X, Y, N, Z, desc));
+  return sgpr_global(p, params, N, desc);
 }
 
 // With ubar = WB^T c = Binv u / s:  Bbar = dF/dB = -1/2 Binv - 1/2 ubar ubar^T,  dF/du = ubar / s,
@@ -377,12 +402,12 @@ extern "C" {
  * SGPRSS.optimize: transcription.py:283, separation.py:298).  Z is a DataHolder (sgpr_ss.py:26): no gradient. */
 }  // extern "C"
 
-// every launch of one bound + gradient evaluation, in stream order (no host synchronisation inside)
-static gp_status sgpr_enqueue_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N,
-                                         const double* Z, double* grad) {
+// backward pass given the forward state; N = this caller's frames, Ntotal = the window's.  The terms that do not
+// depend on which frames the caller holds (noise, Kdiag, Kuu side, L1 penalty) are added only when
+// include_replicated != 0, so that a sum of the gradient vectors over the ranks of a frame-sharded window is exact.
+static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N, int Ntotal,
+                               const double* Z, double* grad, int include_replicated, const SgDesc& d) {
   gp_handle h = p->h;
-  SgDesc d;
-  GP_CHECK(sgpr_common(p, params, X, Y, N, Z, &d));
   const int M = p->M;
   const int64_t ld = ldN64(N);
   GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
@@ -413,8 +438,8 @@ static gp_status sgpr_enqueue_bound_grad(gp_sgpr_plan p, const double* params, c
   GP_CHECK(launch_gemm_batched(h, D + Q_BINV, 1, M, M, f));
   GP_CHECK(launch_matvec_batched(h, D + Q_UBAR, 1, M, 1));
   hipLaunchKernelGGL(sgpr_E2_kernel, dim3(64), dim3(256), 0, h->stream, p->Binv, p->ubar, p->E2, M, params);
-  hipLaunchKernelGGL(sgpr_noise_grad_kernel, dim3(1), dim3(256), 0, h->stream, p->Binv, p->H, p->ubar, p->u, M, N, params,
-                     p->scal, grad);
+  hipLaunchKernelGGL(sgpr_noise_grad_kernel, dim3(1), dim3(256), 0, h->stream, p->Binv, p->H, p->ubar, p->u, M, Ntotal,
+                     params, p->scal, include_replicated ? grad : p->scal + 6);
   // from here on ubar holds dF/du = ubar / s
   hipLaunchKernelGGL(div_scalar_kernel, dim3((M + 255) / 256), dim3(256), 0, h->stream, p->ubar, M, params);
   // Wbar = tril(E2 H L^T + ubar (L u)^T)
@@ -453,16 +478,78 @@ static gp_status sgpr_enqueue_bound_grad(gp_sgpr_plan p, const double* params, c
     }
     int np_uf = 0, np_uu = 0;
     GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, p->feat, p->hyp, &np_uf, nullptr));
-    GP_CHECK(launch_hyper_finish(h, k, p->hyp, np_uf, p->scal + 4, grad + p->off_theta[i], nullptr, 0, M, nullptr));
-    GP_CHECK(launch_hyper_contract(h, k, Z, M, Z, M, p->E2, M, nullptr, nullptr, 1, p->feat, p->hyp_uu, &np_uu, nullptr));
-    GP_CHECK(launch_hyper_finish(h, k, p->hyp_uu, np_uu, nullptr, grad + p->off_theta[i], nullptr, 0, M, nullptr));
+    GP_CHECK(launch_hyper_finish(h, k, p->hyp, np_uf, include_replicated ? p->scal + 4 : nullptr, grad + p->off_theta[i],
+                                 nullptr, 0, M, nullptr));
+    if (include_replicated) {
+      GP_CHECK(launch_hyper_contract(h, k, Z, M, Z, M, p->E2, M, nullptr, nullptr, 1, p->feat, p->hyp_uu, &np_uu, nullptr));
+      GP_CHECK(launch_hyper_finish(h, k, p->hyp_uu, np_uu, nullptr, grad + p->off_theta[i], nullptr, 0, M, nullptr));
+    }
   }
-  if (p->reg) hipLaunchKernelGGL(sgpr_reg_grad_kernel, dim3(1), dim3(256), 0, h->stream, params, grad, d.toff, p->P);
+  if (p->reg && include_replicated)
+    hipLaunchKernelGGL(sgpr_reg_grad_kernel, dim3(1), dim3(256), 0, h->stream, params, grad, d.toff, p->P);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
 
+// every launch of one bound + gradient evaluation, in stream order (no host synchronisation inside)
+static gp_status sgpr_enqueue_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int N,
+                                         const double* Z, double* grad) {
+  SgDesc d;
+  GP_CHECK(sgpr_common(p, params, X, Y, N, Z, &d));
+  return sgpr_backward(p, params, X, Y, N, N, Z, grad, 1, d);
+}
+
+// frame-sharded window: exchange layout [H (M x M) | u (M) | sum y^2 | tr(H)]
+static size_t sg_xchg_doubles(const gp_sgpr_plan_s* p) { return (size_t)p->M * p->M + p->M + 2; }
+
 extern "C" {
+
+// ---- one window sharded over its frames: each rank holds a slice of (X, Y) ------------------
+int64_t gp_sgpr_exchange_doubles(gp_sgpr_plan p) { return p ? (int64_t)sg_xchg_doubles(p) : 0; }
+
+gp_status gp_sgpr_bound_begin(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                              const double* Z, double* exchange) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  sg_invalidate(p);
+  p->staged_N = -1;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgpr_bound_begin: workspace not set");
+  if (!params || !X || !Y || !Z || !exchange || N < 1 || N > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound_begin: bad argument");
+  SgDesc d;
+  GP_CHECK(sgpr_local(p, params, X, Y, N, Z, &d));
+  const size_t mm = (size_t)p->M * p->M;
+  GP_HIP_CHECK(h, hipMemcpyAsync(exchange, p->H, mm * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(exchange + mm, p->u, p->M * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(exchange + mm + p->M, p->scal + 1, 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  p->staged_N = N; p->staged_params = params; p->staged_X = X;
+  return GP_OK;
+}
+
+gp_status gp_sgpr_bound_end(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                            int64_t N_total, const double* Z, const double* exchange, double* bound_dev,
+                            double* bound_host, double* grad, int32_t include_replicated) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!params || !X || !Y || !Z || !exchange || N_total < N || N_total > 2147483647LL)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound_end: bad argument");
+  if (p->staged_N != N || p->staged_params != params || p->staged_X != X)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_bound_end: no matching gp_sgpr_bound_begin (same params, X and N required)");
+  p->staged_N = -1;
+  const size_t mm = (size_t)p->M * p->M;
+  GP_HIP_CHECK(h, hipMemcpyAsync(p->H, exchange, mm * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(p->u, exchange + mm, p->M * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(p->scal + 1, exchange + mm + p->M, 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  SgDesc d;
+  sg_desc_ptrs(p, 0, &d);
+  GP_CHECK(sgpr_global(p, params, (int)N_total, &d));
+  if (grad) GP_CHECK(sgpr_backward(p, params, X, Y, N, (int)N_total, Z, grad, include_replicated, d));
+  if (bound_dev) GP_HIP_CHECK(h, hipMemcpyAsync(bound_dev, p->scal, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (bound_host) {
+    GP_HIP_CHECK(h, hipMemcpyAsync(bound_host, p->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return check_not_pd(h);
+  }
+  return GP_OK;
+}
 
 gp_status gp_sgpr_set_graphs(gp_sgpr_plan p, int32_t enable) {
   if (!p) return GP_ERR_BAD_ARG;

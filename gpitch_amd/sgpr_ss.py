@@ -23,7 +23,11 @@ class _Gaussian(Parameterized):
 
 
 class SGPRSS(Parameterized):
-    def __init__(self, X, Y, kern, Z, mean_function=None, reg=False, handle=None):
+    def __init__(self, X, Y, kern, Z, mean_function=None, reg=False, handle=None, shard=None):
+        """shard=(rank, world): ONE window spread over `world` GPUs by frames (one process each).  Every rank is
+        built with the full X, Y; it uploads only its contiguous slice, and each bound / gradient evaluation
+        exchanges one all-reduce of M^2 + M + 2 doubles (plus one of the small gradient vector): see
+        include/gpitch_abi.h gp_sgpr_bound_begin / _end.  Predictions need the whole window on one GPU."""
         if mean_function is not None:
             raise NotImplementedError("only the zero mean function is used on the gpitch path")
         if not isinstance(kern, Add):
@@ -43,6 +47,22 @@ class SGPRSS(Parameterized):
         self._handle = handle
         self._plan = None
         self._plan_key = None
+        if shard is not None:
+            rank, world = int(shard[0]), int(shard[1])
+            if not (0 <= rank < world):
+                raise ValueError("shard=(rank, world) needs 0 <= rank < world")
+            shard = (rank, world)
+        object.__setattr__(self, "_shard", shard)
+
+    def _frames(self):
+        """frame indices this rank holds (all of them when unsharded): contiguous, sizes differ by at most one"""
+        N = self.X.shape[0]
+        if not self._shard:
+            return slice(0, N)
+        rank, world = self._shard
+        base, extra = divmod(N, world)
+        lo = rank * base + min(rank, extra)
+        return slice(lo, lo + base + (1 if rank < extra else 0))
 
     # data can be swapped between windows (transcription.py:253-263: model.X = x; model.Y = 20*y; model.Z = z)
     def __setattr__(self, name, value):
@@ -57,7 +77,10 @@ class SGPRSS(Parameterized):
     def _compile(self, n_pred=0):
         h = self._handle = self._handle or _lib.default_handle()
         kl = self.kern.kern_list
-        N, M = self.X.shape[0], self.Z.shape[0]
+        fr = self._frames()
+        N, M = fr.stop - fr.start, self.Z.shape[0]
+        if N < 1:
+            raise ValueError("more ranks than frames")
         maxN = max(N, n_pred)
         key = (maxN, M, tuple((k.type_code, int(k.num_partials)) for k in kl), bool(self.reg))
         if self._plan is not None and self._plan_key == key:
@@ -93,26 +116,55 @@ class SGPRSS(Parameterized):
             vec.append(k.theta())
         host = np.concatenate(vec)
         assert host.size == self._nparams
+        fr = self._frames()
         self._dev("_params", host)
-        self._dev("_Xd", self.X._array)
-        self._dev("_Yd", self.Y._array)
+        self._dev("_Xd", self.X._array[fr])
+        self._dev("_Yd", self.Y._array[fr])
         self._dev("_Zd", self.Z._array)
+        object.__setattr__(self, "_n_local", fr.stop - fr.start)
+
+    def _bound(self, grad=None):
+        """one evaluation of the bound (and gradient into the device vector `grad`) on this model's frames; the
+        frame-sharded form runs begin -> all-reduce -> end -> all-reduce(grad)"""
+        h = self._handle
+        out = C.c_double()
+        n = self._n_local
+        args = (self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(), n)
+        if not self._shard:
+            if grad is None:
+                h.check(h.lib.gp_sgpr_bound(*args, self._Zd.data_ptr(), self._bound_dev.data_ptr(), C.byref(out)))
+            else:
+                h.check(h.lib.gp_sgpr_bound_grad(*args, self._Zd.data_ptr(), self._bound_dev.data_ptr(), C.byref(out),
+                                                 grad.data_ptr()))
+            return out.value
+        from .dist import allreduce_sum_
+        xchg = self.__dict__.get("_xchg")
+        need = int(h.lib.gp_sgpr_exchange_doubles(self._plan))
+        if xchg is None or xchg.numel() != need:
+            xchg = h.empty(need)
+            object.__setattr__(self, "_xchg", xchg)
+        h.check(h.lib.gp_sgpr_bound_begin(*args, self._Zd.data_ptr(), xchg.data_ptr()))
+        allreduce_sum_(xchg)
+        h.check(h.lib.gp_sgpr_bound_end(*args, self.X.shape[0], self._Zd.data_ptr(), xchg.data_ptr(),
+                                        self._bound_dev.data_ptr(), C.byref(out),
+                                        None if grad is None else grad.data_ptr(), int(self._shard[0] == 0)))
+        if grad is not None:
+            allreduce_sum_(grad)
+        return out.value
 
     def build_likelihood(self):
         """the bound on the marginal likelihood (sgpr_ss.py:29-71)"""
         self._compile()
         self._pack()
-        h = self._handle
-        out = C.c_double()
-        h.check(h.lib.gp_sgpr_bound(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
-                                    self.X.shape[0], self._Zd.data_ptr(), self._bound_dev.data_ptr(), C.byref(out)))
-        return out.value
+        return self._bound()
 
     def compute_log_likelihood(self):
         return self.build_likelihood()
 
     def predict_f(self, Xnew):
         """mean and variance of the mixture at Xnew (GPflow 0.5 SGPR.build_predict, full_cov=False)"""
+        if self._shard:
+            raise NotImplementedError("predictions of a frame-sharded window: build the model unsharded on one GPU")
         Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1)
         n = Xnew.size
         self._compile(n_pred=n)
@@ -130,6 +182,8 @@ class SGPRSS(Parameterized):
         (sgpr_ss.py:73-106; the variance uses the SUM kernel's Kdiag as the reference does)."""
         if full_cov:
             raise NotImplementedError("full_cov=True is never used on the gpitch path")
+        if self._shard:
+            raise NotImplementedError("predictions of a frame-sharded window: build the model unsharded on one GPU")
         Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1)
         n, N, P = Xnew.size, self.X.shape[0], len(self.kern.kern_list)
         self._compile()
@@ -168,16 +222,13 @@ class SGPRSS(Parameterized):
         if grad is None or grad.numel() != self._nparams:
             grad = h.empty(self._nparams)
             object.__setattr__(self, "_grad_dev", grad)
-        out = C.c_double()
-        h.check(h.lib.gp_sgpr_bound_grad(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
-                                         self.X.shape[0], self._Zd.data_ptr(), self._bound_dev.data_ptr(), C.byref(out),
-                                         grad.data_ptr()))
+        value = self._bound(grad)
         g = grad.cpu().numpy()
         gf = np.empty(len(free_idx))
         for j, i in enumerate(free_idx):
             dydx = float(ps[i].transform.dforward(np.array([x_free[j]]))[0])
             gf[j] = g[i] * dydx
-        return -out.value, -gf
+        return -value, -gf
 
     def optimize(self, method='L-BFGS-B', tol=None, callback=None, maxiter=1000, disp=False, **kw):
         from scipy.optimize import minimize

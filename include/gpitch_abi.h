@@ -244,6 +244,23 @@ gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, c
 gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                              const double* Z, double* bound_dev, double* bound_host, double* grad);
 
+/* One window sharded over its FRAMES across several GPUs (one process per GPU; SURVEY 8e: "SGPRSS single large
+ * window").  Each rank holds a slice (X, Y) of N frames; Z and params are replicated.  The collapsed bound couples
+ * the slices only through H = A'A'^T (M x M), u = A'y (M), sum y^2 and tr(H):
+ *   gp_sgpr_bound_begin : local Kuf, A' = L^-1 Kuf, H, u, scalars -> exchange[0 .. gp_sgpr_exchange_doubles())
+ *   -- caller: ncclAllReduce(exchange, M*M + M + 2, sum) --
+ *   gp_sgpr_bound_end   : Cholesky of B, the bound for N_total frames (identical on every rank) and, when
+ *                         grad != NULL, this rank's share of the gradient: the frame-dependent terms of its slice,
+ *                         plus the frame-independent ones (noise, Kdiag, Kuu side, L1 penalty) only when
+ *                         include_replicated != 0 (pass 1 on exactly one rank)
+ *   -- caller: ncclAllReduce(grad, gp_sgpr_num_params, sum) -> the full gradient everywhere. */
+int64_t gp_sgpr_exchange_doubles(gp_sgpr_plan p);
+gp_status gp_sgpr_bound_begin(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                              const double* Z, double* exchange);
+gp_status gp_sgpr_bound_end(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                            int64_t N_total, const double* Z, const double* exchange, double* bound_dev,
+                            double* bound_host, double* grad, int32_t include_replicated);
+
 /* gp_sgpr_bound_grad is launch-bound at window sizes (N ~ 2001, ~50 small kernels), and L-BFGS-B calls it dozens
  * of times per window with the same buffers: from the second call with identical pointer arguments the launch
  * sequence is recorded into a hipGraph and replayed.  Needs a handle created on a real stream (the legacy null

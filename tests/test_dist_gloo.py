@@ -130,3 +130,70 @@ def test_pitch_assignment_covers_all():
         got = sorted(sum((pitch_assignment(P, world, r) for r in range(world)), []))
         assert got == list(range(P))
     assert [len(pitch_assignment(12, 8, r)) for r in range(8)] == [2, 2, 2, 2, 1, 1, 1, 1]
+
+
+# ---------------------------------------------------------------------------------------------
+# Frame-sharded SGPRSS window: ranks hold frame slices and exchange [H | u | sum y^2 | tr H].
+# Per-rank arithmetic is numpy here (no GPU in this container); the exchange layout, the frame split and the
+# reduction are the product's (gpitch_amd/sgpr_ss.py:_frames, include/gpitch_abi.h gp_sgpr_bound_begin/_end).
+def _sgpr_problem():
+    rng = np.random.RandomState(3)
+    N, M = 257, 12
+    X = np.linspace(0, 0.02, N).reshape(-1, 1)
+    Y = np.sin(2 * np.pi * 220. * X) + 0.1 * rng.randn(N, 1)
+    Z = X[::N // M][:M].copy()
+    kl = [{"type": "mercer_matern12sm", "variance": 1.0, "lengthscales": 0.05, "energy": [0.6, 0.4],
+           "frequency": [220., 440.]},
+          {"type": "matern32", "variance": 0.5, "lengthscales": 0.01, "energy": [], "frequency": []}]
+    return X, Y, Z, kl, 0.3
+
+
+def _sgpr_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from gpitch_amd import dist as gd
+    from gpitch_amd.sgpr_ss import SGPRSS
+    from oracle import gpflow05 as orc
+    d = gd.init_process_group("gloo")
+    X, Y, Z, kl, s2 = _sgpr_problem()
+    M = Z.shape[0]
+    probe = SGPRSS.__new__(SGPRSS)                       # only the frame-split rule of the product is needed here
+    object.__setattr__(probe, "_shard", (rank, world))
+    probe.__dict__["X"] = type("D", (), {"shape": X.shape})()
+    fr = probe._frames()
+    Xs, Ys = X[fr], Y[fr]
+    L = np.linalg.cholesky(orc.K_sum(kl, Z) + 1e-6 * np.eye(M))
+    A = np.linalg.solve(L, orc.K_sum(kl, Z, Xs))          # A' = L^-1 Kuf (not yet divided by sigma)
+    xchg = np.concatenate([(A @ A.T).reshape(-1), (A @ Ys).reshape(-1), [float((Ys ** 2).sum())], [float((A * A).sum())]])
+    t = torch.as_tensor(xchg)
+    gd.allreduce_sum_(t)
+    v = t.numpy()
+    H, u, yy, trH = v[:M * M].reshape(M, M), v[M * M:M * M + M], v[M * M + M], v[M * M + M + 1]
+    N = X.shape[0]
+    LB = np.linalg.cholesky(H / s2 + np.eye(M))
+    c = np.linalg.solve(LB, u) / s2
+    kd = float(orc.Kdiag_sum(kl, X[:1])[0])
+    bound = (-0.5 * N * np.log(2 * np.pi) - np.log(np.diag(LB)).sum() - 0.5 * N * np.log(s2) - 0.5 * yy / s2
+             + 0.5 * (c ** 2).sum() - 0.5 * N * kd / s2 + 0.5 * trH / s2)
+    out.put((rank, float(bound), fr.start, fr.stop))
+    d.destroy_process_group()
+
+
+def test_frame_sharded_sgpr_exchange_gloo():
+    from oracle import gpflow05 as orc
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sgpr_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(q.get() for _ in range(world))
+    X, Y, Z, kl, s2 = _sgpr_problem()
+    ref = float(orc.sgpr_bound(X, Y, Z, kl, s2))
+    assert got[0][1] == got[1][1]
+    assert abs(got[0][1] - ref) <= 1e-10 * abs(ref)
+    assert (got[0][2], got[0][3], got[1][2], got[1][3]) == (0, 129, 129, 257)     # contiguous, sizes differ by <= 1

@@ -205,3 +205,50 @@ def test_sgpr_graph_replay_is_bitwise_eager():
         m._destroy()
         s.synchronize()
         h.close()
+
+
+@pytest.mark.parametrize("world,reg", [(2, False), (3, True)])
+def test_frame_sharded_window_matches_unsharded(gp_handle, world, reg):
+    """ONE window sharded over its frames (gp_sgpr_bound_begin -> sum of the M^2+M+2 exchange vectors ->
+    gp_sgpr_bound_end -> sum of the gradient vectors), the ranks emulated in this process: every rank must report
+    the unsharded bound, and the summed gradient must equal the unsharded gradient."""
+    import ctypes as C
+    X, Y, Z, kl = _problem(1101, 40, 3, seed=41)
+    h = gp_handle
+    full = _model(X, Y, Z, kl, 0.6, h, reg=reg)
+    full._compile(); full._pack()
+    g_full = h.zeros(full._nparams)
+    b_full = full._bound(g_full)
+    from gpitch_amd.sgpr_ss import SGPRSS
+    shards = []
+    for r in range(world):
+        m = _model(X, Y, Z, kl, 0.6, h, reg=reg)
+        object.__setattr__(m, "_shard", (r, world))
+        m._compile(); m._pack()
+        shards.append(m)
+    assert sum(m._n_local for m in shards) == 1101
+    need = int(h.lib.gp_sgpr_exchange_doubles(shards[0]._plan))
+    assert need == 40 * 40 + 40 + 2
+    parts = []
+    for m in shards:
+        x = h.empty(need)
+        h.check(h.lib.gp_sgpr_bound_begin(m._plan, m._params.data_ptr(), m._Xd.data_ptr(), m._Yd.data_ptr(), m._n_local,
+                                          m._Zd.data_ptr(), x.data_ptr()))
+        parts.append(x)
+    total = sum(parts)
+    gsum = h.zeros(full._nparams)
+    for r, m in enumerate(shards):
+        out = C.c_double()
+        g = h.zeros(full._nparams)
+        h.check(h.lib.gp_sgpr_bound_end(m._plan, m._params.data_ptr(), m._Xd.data_ptr(), m._Yd.data_ptr(), m._n_local, 1101,
+                                        m._Zd.data_ptr(), total.data_ptr(), m._bound_dev.data_ptr(), C.byref(out),
+                                        g.data_ptr(), int(r == 0)))
+        assert abs(out.value - b_full) <= 1e-10 * abs(b_full), (r, out.value, b_full)
+        gsum += g
+    gf, gs = g_full.cpu().numpy(), gsum.cpu().numpy()
+    np.testing.assert_allclose(gs, gf, rtol=1e-8, atol=1e-9 * np.abs(gf).max())
+    # end without a matching begin is refused
+    with pytest.raises(Exception):
+        m = shards[0]
+        h.check(h.lib.gp_sgpr_bound_end(m._plan, m._params.data_ptr(), m._Xd.data_ptr(), m._Yd.data_ptr(), m._n_local, 1101,
+                                        m._Zd.data_ptr(), total.data_ptr(), m._bound_dev.data_ptr(), None, None, 1))
