@@ -546,8 +546,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     auto P = [&](int slot) -> GemmProblem& {
       // the kernel-gradient chain (slots S_R..S_S) is batched over the GPs that need it only
       const bool kchain = (slot >= S_E);   // E, Wbar, R, alpha, Kuf_bar and the Cholesky-adjoint chain
-      static GemmProblem dummy;
-      if (kchain && !kneed) { memset(&dummy, 0, sizeof(dummy)); return dummy; }
+      if (kchain && !kneed) { memset(&p->dummy_prob, 0, sizeof(p->dummy_prob)); return p->dummy_prob; }
       const int idx = kchain ? kslot : g;
       GemmProblem& r = *(GemmProblem*)(p->h_misc.data() + p->off_bwd[slot] + idx * sizeof(GemmProblem));
       memset(&r, 0, sizeof(r));

@@ -16,6 +16,7 @@
 // B-fragment of k-step r, so the chained product -W_ii * (sum_k L_ik W_kj) needs no data movement.
 #include "common.h"
 #include <string.h>
+#include <atomic>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -328,10 +329,10 @@ static size_t chol_smem_bytes(int maxM, int* cap) {
   return dbytes;
 }
 static gp_status chol_set_attr(gp_handle h) {
-  static bool done = false;
-  if (!done) {
+  static std::atomic<bool> done{false};   // several handles / threads may race here: a repeated call is harmless
+  if (!done.load(std::memory_order_acquire)) {
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    done = true;
+    done.store(true, std::memory_order_release);
   }
   return GP_OK;
 }

@@ -19,6 +19,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 // Pointers fetched from the problem descriptor are generic to the compiler, which then emits flat_load:
@@ -521,11 +522,11 @@ static gp_status launch_one(gp_handle h, const GemmProblem* d_probs, int batch, 
   int ntiles = df.tilesM * df.tilesN;
   if (ksplit > 1 && df.triC == TRI_LOWER) ntiles = df.tilesM * (df.tilesM + 1) / 2;
   dim3 grid(ntiles * (ksplit > 1 ? ksplit : 1), 1, batch);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};   // per instantiation; a repeated call from another thread is harmless
+  if (!attr_set.load(std::memory_order_acquire)) {
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f64_kernel<BM, BN, TA, TB, TAG>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, TA, TB, TAG>), grid, dim3(GEMM_THREADS), S::BYTES, h->stream, d_probs, df);
   GP_HIP_CHECK(h, hipGetLastError());
