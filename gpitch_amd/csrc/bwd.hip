@@ -150,6 +150,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   const int i0 = blockIdx.y * HY_ROWS;
   const int iend = min(i0 + HY_ROWS, n1);
   double* fzs = smem;
+  __shared__ double etab[GP_EXP_TAB];  // 2^(j/64) for gp_exp_neg
+  gp_exp_tab_init(etab);
   __shared__ double row_a[HY_ROWS];   // x1[i] / lengthscale, once per row
   if (threadIdx.x < HY_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / ls : 0.0;
   double* omega = smem + (SM ? HY_ROWS * 2 * MPAD : 0);
@@ -192,18 +194,18 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
     const double d = xa - xb;
     double dz = 0.0;  // w * dK/dx1
     if (!SM && k.type == GP_KERN_RBF) {
-      const double e = exp(-0.5 * r2);
+      const double e = gp_exp_neg(-0.5 * r2, etab);
       acc_v = fma(w, e, acc_v);
       acc_l = fma(w, var * e * r2 * inv_ls, acc_l);
       if (GZ) dz = -w * var * e * d * inv_ls2;
     } else {
-      const double r = __dsqrt_rn(__dadd_rn(r2, 1e-12));
+      const double r = gp_sqrt_pos(__dadd_rn(r2, 1e-12));
       if (SM) {
         // envelope phi(r) and phi'(r): Matern-1/2 (MercerMatern12sm) or Matern-5/2 (Matern52 * MercerCosMix)
         double E, dE;
-        if (k.type == GP_KERN_MERCER_MATERN12SM) { E = exp(-r); dE = -E; }
+        if (k.type == GP_KERN_MERCER_MATERN12SM) { E = gp_exp_neg(-r, etab); dE = -E; }
         else {
-          const double s5 = 2.23606797749979, e5 = exp(-s5 * r);
+          const double s5 = 2.23606797749979, e5 = gp_exp_neg(-s5 * r, etab);
           E = (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e5; dE = -(5.0 / 3.0) * r * (1.0 + s5 * r) * e5;
         }
         const double wvE = w * var * E, wvD = w * var * dE;
@@ -226,12 +228,12 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
         if (GZ) dz = wvD * S * d * inv_ls2 * rinv - wvE * Ssin;
       } else {
         double phi, dphi;  // K = var * phi(r), dphi = phi'(r)
-        if (k.type == GP_KERN_MATERN12) { phi = exp(-r); dphi = -phi; }
+        if (k.type == GP_KERN_MATERN12) { phi = gp_exp_neg(-r, etab); dphi = -phi; }
         else if (k.type == GP_KERN_MATERN32) {
-          const double s3 = 1.7320508075688772, e = exp(-s3 * r);
+          const double s3 = 1.7320508075688772, e = gp_exp_neg(-s3 * r, etab);
           phi = (1.0 + s3 * r) * e; dphi = -3.0 * r * e;
         } else {
-          const double s5 = 2.23606797749979, e = exp(-s5 * r);
+          const double s5 = 2.23606797749979, e = gp_exp_neg(-s5 * r, etab);
           phi = (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e; dphi = -(5.0 / 3.0) * r * (1.0 + s5 * r) * e;
         }
         const double rinv = 1.0 / r;

@@ -55,6 +55,42 @@ static inline gp_status gp_fail(gp_handle h, gp_status s, const char* msg) {
 }
 
 // scoped timer for a kernel class; records HIP events on the handle's stream when enabled
+// ---- lean device math for the covariance kernels -------------------------------------------------------------
+// The M x N covariance builds and their gradient contraction are bound by float64 VALU issue, not by HBM (about 57
+// instructions per entry with the library sqrt / exp).  Both functions below drop the range handling the arguments
+// cannot need and stay within 1.5 ulp, far inside the 1e-9 parity bar.
+// sqrt(x) for 1e-13 <= x <= 1e300 (a squared distance + 1e-12): v_rsq_f64 and the library's two correction steps,
+// without its input scaling and class checks.
+__device__ __forceinline__ double gp_sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  return fma(d, h, g);
+}
+// table for gp_exp_neg: tab[j] = 2^(j/64), j < 64 (filled per workgroup into LDS by gp_exp_tab_init)
+#define GP_EXP_TAB 64
+__device__ __forceinline__ void gp_exp_tab_init(double* tab) {
+  if (threadIdx.x < GP_EXP_TAB) tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+}
+// exp(x) for x <= 0: x = (64 q + j) ln2/64 + r, |r| <= ln2/128 -> 2^q * tab[j] * P5(r); x < -744 returns 0.
+__device__ __forceinline__ double gp_exp_neg(double x, const double* __restrict__ tab) {
+  x = fmax(x, -744.0);
+  const double n = __builtin_rint(x * 92.33248261689366);             // 64 / ln2
+  double r = fma(n, -0x1.62e42fe000000p-7, x);                         // ln2/64, high 29 bits (n * hi is exact)
+  r = fma(n, -0x1.f473de6af278fp-36, r);                               // ln2/64, low part
+  const int ni = (int)n;
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(tab[ni & 63] * p, ni >> 6);
+}
+
 // kernel families (include/gpitch_abi.h gp_kernel_type)
 #define GP_KERN_LAST GP_KERN_MERCER_MATERN52SM
 static inline __host__ __device__ bool gp_kern_has_partials(int t) { return t >= GP_KERN_MERCER_MATERN12SM && t <= GP_KERN_LAST; }

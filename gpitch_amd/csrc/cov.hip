@@ -11,22 +11,23 @@
 //   r2 = ((-2*(a*b)) + a*a) + b*b,  a = x/l, b = x'/l     (each op rounded separately, no FMA)
 // so that coincident inducing/data points give r = sqrt(r2 + 1e-12) exactly as TF does.
 #include "common.h"
+#include <type_traits>
 
 #define COV_THREADS 256
 #define COV_ROWS 32  // rows (inducing points) handled per block
 
-__device__ __forceinline__ double stat_profile(int type, double r2, double var) {
+__device__ __forceinline__ double stat_profile(int type, double r2, double var, const double* __restrict__ etab) {
   // r2 is the literal expansion; the kernels below follow GPflow 0.5 Stationary subclasses
-  if (type == GP_KERN_RBF) return var * exp(-r2 * 0.5);
-  double r = __dsqrt_rn(__dadd_rn(r2, 1e-12));
-  if (type == GP_KERN_MATERN12) return var * exp(-r);
+  if (type == GP_KERN_RBF) return var * gp_exp_neg(-r2 * 0.5, etab);
+  double r = gp_sqrt_pos(__dadd_rn(r2, 1e-12));
+  if (type == GP_KERN_MATERN12) return var * gp_exp_neg(-r, etab);
   if (type == GP_KERN_MATERN32) {
     const double s3 = 1.7320508075688772;
-    return var * (1.0 + s3 * r) * exp(-s3 * r);
+    return var * (1.0 + s3 * r) * gp_exp_neg(-s3 * r, etab);
   }
   // Matern52
   const double s5 = 2.23606797749979;
-  return var * (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r);
+  return var * (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * gp_exp_neg(-s5 * r, etab);
 }
 
 __device__ __forceinline__ double r2_expand(double a, double aa, double b, double bb) {
@@ -56,6 +57,7 @@ __global__ void __launch_bounds__(256) sm_features_kernel(DevKern k, const doubl
 // MODE 0: stationary (Matern12/32/52/RBF); MODE 1: Mercer spectral mixture (feature form) with envelope ENV
 // (0: Matern-1/2, MercerMatern12sm; 2: Matern-5/2, the Matern52 * MercerCosMix product of init_models.py:183-198);
 // MODE 2: broadcast cosine form (Matern12sm, Matern32sm).  CPT = columns per thread (16-byte stores when 2).
+// MODE 0 takes the stationary kernel type as ENV, so the row loop carries no type switch.
 template <int MODE, int CPT, int MPAD, int ENV = 0>
 __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const double* __restrict__ x1, int n1,
                                                                 const double* __restrict__ x2, int n2,
@@ -65,6 +67,8 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
                                                                 const double* __restrict__ f2, int vec_ok) {
   extern __shared__ double smem[];  // MODE 1: z-features for this block's rows [COV_ROWS][2m]
   __shared__ double row_a[COV_ROWS];  // x1[i] / lengthscale (the exact quotient, computed once per row, not per entry)
+  __shared__ double etab[GP_EXP_TAB];
+  gp_exp_tab_init(etab);
   const double* th = k.theta;
   const double var = th[0];
   const double ls = th[1];
@@ -72,6 +76,9 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   const int j0 = (blockIdx.x * COV_THREADS + threadIdx.x) * CPT;
   const int i0 = blockIdx.y * COV_ROWS;
   const int iend = min(i0 + COV_ROWS, n1);
+  // K(x, x) + diag_add I: only the workgroups whose column range meets their row range carry the diagonal test
+  const int jb0 = blockIdx.x * COV_THREADS * CPT;
+  const bool self_cov = (x2 == x1) && (diag_add != 0.0) && (jb0 < i0 + COV_ROWS) && (jb0 + COV_THREADS * CPT > i0);
 
   if (threadIdx.x < COV_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / th[1] : 0.0;
   if (MODE != 1) __syncthreads();
@@ -120,18 +127,18 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
       double res[CPT];
 #pragma unroll
       for (int c = 0; c < CPT; c++) {
-        double r = __dsqrt_rn(__dadd_rn(r2_expand(a, aa, b[c], bb[c]), 1e-12));
+        double r = gp_sqrt_pos(__dadd_rn(r2_expand(a, aa, b[c], bb[c]), 1e-12));
         if (ENV == 0) {
-          res[c] = var * exp(-r) * acc[c];
+          res[c] = var * gp_exp_neg(-r, etab) * acc[c];
         } else {   // GPflow Matern52.K profile
           const double s5 = 2.23606797749979;
-          res[c] = var * ((1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r)) * acc[c];
+          res[c] = var * ((1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * gp_exp_neg(-s5 * r, etab)) * acc[c];
         }
-        if (x2 == x1 && i == j0 + c) res[c] += diag_add;
+        if (self_cov && i == j0 + c) res[c] += diag_add;
       }
       double* o = out + (size_t)i * ld + j0;
       if (CPT == 2 && vec_ok && j0 + 1 < n2) {
-        double2 v = make_double2(res[0], res[1]);
+        double2 v = make_double2(res[0], res[CPT - 1]);
         if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
         *reinterpret_cast<double2*>(o) = v;
       } else {
@@ -143,44 +150,49 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
     return;
   }
 
-  for (int i = i0; i < iend; i++) {
-    double xa = x1[i];
-    double res[CPT];
-    if (MODE == 0) {
-      double a = row_a[i - i0], aa = __dmul_rn(a, a);
-#pragma unroll
-      for (int c = 0; c < CPT; c++) res[c] = stat_profile(k.type, r2_expand(a, aa, b[c], bb[c]), var);
-    } else {
-      // Matern12sm (m12sm.py:46-56) / Matern32sm (kernels.py:232-247): r = sqrt((x - x' + 1e-12)^2)
-#pragma unroll
-      for (int c = 0; c < CPT; c++) {
-        double d = __dadd_rn(__dadd_rn(xa, -xb[c]), 1e-12);
-        double r = __dsqrt_rn(__dmul_rn(d, d));
-        double s = 0.0;
-        for (int p = 0; p < m; p++)
-          s += th[2 + p] * cos(__dmul_rn(__dmul_rn(6.283185307179586, th[2 + m + p]), r));
-        if (k.type == GP_KERN_MATERN12SM) {
-          res[c] = var * exp(-(r / ls)) * s;
-        } else {   // Matern32sm: r1 = sqrt(3) r / l, (1 + r1) exp(-r1) sum_k variance_k cos(2 pi f_k r)
-          const double r1 = 1.7320508075688772 * (r / ls);
-          res[c] = var * ((1.0 + r1) * exp(-r1)) * s;
+  // the diagonal test lives in its own copy of the row loop (a select per entry otherwise: 8 of ~90 instructions)
+  auto rows = [&](auto diag_tag) {
+    constexpr bool DIAG = decltype(diag_tag)::value;
+    for (int i = i0; i < iend; i++) {
+      double xa = x1[i];
+      double res[CPT];
+      if (MODE == 0) {
+        double a = row_a[i - i0], aa = __dmul_rn(a, a);
+  #pragma unroll
+        for (int c = 0; c < CPT; c++) res[c] = stat_profile(MODE == 0 ? ENV : k.type, r2_expand(a, aa, b[c], bb[c]), var, etab);
+      } else {
+        // Matern12sm (m12sm.py:46-56) / Matern32sm (kernels.py:232-247): r = sqrt((x - x' + 1e-12)^2)
+  #pragma unroll
+        for (int c = 0; c < CPT; c++) {
+          double d = __dadd_rn(__dadd_rn(xa, -xb[c]), 1e-12);
+          double r = __dsqrt_rn(__dmul_rn(d, d));
+          double s = 0.0;
+          for (int p = 0; p < m; p++)
+            s += th[2 + p] * cos(__dmul_rn(__dmul_rn(6.283185307179586, th[2 + m + p]), r));
+          if (k.type == GP_KERN_MATERN12SM) {
+            res[c] = var * exp(-(r / ls)) * s;
+          } else {   // Matern32sm: r1 = sqrt(3) r / l, (1 + r1) exp(-r1) sum_k variance_k cos(2 pi f_k r)
+            const double r1 = 1.7320508075688772 * (r / ls);
+            res[c] = var * ((1.0 + r1) * exp(-r1)) * s;
+          }
         }
       }
-    }
-#pragma unroll
-    for (int c = 0; c < CPT; c++)
-      if (x2 == x1 && i == j0 + c) res[c] += diag_add;
-    double* o = out + (size_t)i * ld + j0;
-    if (CPT == 2 && vec_ok && j0 + 1 < n2) {
-      double2 v = make_double2(res[0], res[1]);
-      if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
-      *reinterpret_cast<double2*>(o) = v;
-    } else {
-#pragma unroll
+  #pragma unroll
       for (int c = 0; c < CPT; c++)
-        if (j0 + c < n2) o[c] = accumulate ? o[c] + res[c] : res[c];
+        if (DIAG && i == j0 + c) res[c] += diag_add;
+      double* o = out + (size_t)i * ld + j0;
+      if (CPT == 2 && vec_ok && j0 + 1 < n2) {
+        double2 v = make_double2(res[0], res[CPT - 1]);
+        if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
+        *reinterpret_cast<double2*>(o) = v;
+      } else {
+  #pragma unroll
+        for (int c = 0; c < CPT; c++)
+          if (j0 + c < n2) o[c] = accumulate ? o[c] + res[c] : res[c];
+      }
     }
-  }
+  };
+  if (self_cov) rows(std::true_type{}); else rows(std::false_type{});
 }
 
 __global__ void __launch_bounds__(256) cov_diag_kernel(DevKern k, int n, double* __restrict__ out, int accumulate) {
@@ -255,8 +267,15 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
                        accumulate, diag_add, nullptr, nullptr, vec_ok);
   } else if (k.type >= GP_KERN_MATERN12 && k.type <= GP_KERN_RBF) {
     dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
-    hipLaunchKernelGGL((cov_build_kernel<0, 2, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
-                       accumulate, diag_add, nullptr, nullptr, vec_ok);
+#define COV_STAT(T) hipLaunchKernelGGL((cov_build_kernel<0, 2, 1, T>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, \
+                                      x2, n2, out, ld, accumulate, diag_add, nullptr, nullptr, vec_ok)
+    switch (k.type) {
+      case GP_KERN_MATERN12: COV_STAT(GP_KERN_MATERN12); break;
+      case GP_KERN_MATERN32: COV_STAT(GP_KERN_MATERN32); break;
+      case GP_KERN_MATERN52: COV_STAT(GP_KERN_MATERN52); break;
+      default: COV_STAT(GP_KERN_RBF); break;
+    }
+#undef COV_STAT
   } else {
     return gp_fail(h, GP_ERR_BAD_ARG, "unknown kernel type");
   }
