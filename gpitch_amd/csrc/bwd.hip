@@ -132,7 +132,8 @@ int hyper_num_sums(int m) { return 2 + 2 * m; }
 
 // MPAD = spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded, so the
 // inner loop carries no guards); SM = Mercer Matern-1/2 SM kernel; GZ = also produce the inducing-input gradient.
-template <int MPAD, bool SM, bool GZ>
+// KT >= 0: the (stationary) kernel type as a compile-time constant, so the row loop carries no type switch.
+template <int MPAD, bool SM, bool GZ, int KT = -1>
 __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, const double* __restrict__ x1, int n1,
                                                                     const double* __restrict__ x2, int n2,
                                                                     const double* __restrict__ G, int64_t ldg,
@@ -193,7 +194,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
     const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b), aa), bb);
     const double d = xa - xb;
     double dz = 0.0;  // w * dK/dx1
-    if (!SM && k.type == GP_KERN_RBF) {
+    const int ktype = (KT >= 0) ? KT : k.type;
+    if (!SM && ktype == GP_KERN_RBF) {
       const double e = gp_exp_neg(-0.5 * r2, etab);
       acc_v = fma(w, e, acc_v);
       acc_l = fma(w, var * e * r2 * inv_ls, acc_l);
@@ -228,8 +230,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
         if (GZ) dz = wvD * S * d * inv_ls2 * rinv - wvE * Ssin;
       } else {
         double phi, dphi;  // K = var * phi(r), dphi = phi'(r)
-        if (k.type == GP_KERN_MATERN12) { phi = gp_exp_neg(-r, etab); dphi = -phi; }
-        else if (k.type == GP_KERN_MATERN32) {
+        if (ktype == GP_KERN_MATERN12) { phi = gp_exp_neg(-r, etab); dphi = -phi; }
+        else if (ktype == GP_KERN_MATERN32) {
           const double s3 = 1.7320508075688772, e = gp_exp_neg(-s3 * r, etab);
           phi = (1.0 + s3 * r) * e; dphi = -3.0 * r * e;
         } else {
@@ -394,16 +396,16 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
   }
 }
 
-template <int MPAD, bool SM>
+template <int MPAD, bool SM, int KT = -1>
 static void launch_hyper_t(gp_handle h, dim3 grid, size_t sh, DevKern k, const double* x1, int n1, const double* x2,
                            int n2, const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
                            const double* f1, const double* f2, double* partials, double* gz) {
   if (gz)
-    hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, true>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2,
-                       G, ldg, alpha, gm, symmetric, f1, f2, partials, gz);
-  else
-    hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, false>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2,
+    hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, true, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2,
                        n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz);
+  else
+    hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, false, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1,
+                       x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz);
 }
 
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
@@ -434,7 +436,12 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
   const int redw = ns > HY_ROWS ? ns : HY_ROWS;
   size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
 #define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials
-  if (!sm) launch_hyper_t<1, false>(h, HY_ARGS);
+  if (!sm) switch (k.type) {
+    case GP_KERN_MATERN12: launch_hyper_t<1, false, GP_KERN_MATERN12>(h, HY_ARGS); break;
+    case GP_KERN_MATERN32: launch_hyper_t<1, false, GP_KERN_MATERN32>(h, HY_ARGS); break;
+    case GP_KERN_MATERN52: launch_hyper_t<1, false, GP_KERN_MATERN52>(h, HY_ARGS); break;
+    default: launch_hyper_t<1, false, GP_KERN_RBF>(h, HY_ARGS); break;
+  }
   else switch (mp) {
     case 4: launch_hyper_t<4, true>(h, HY_ARGS); break;
     case 8: launch_hyper_t<8, true>(h, HY_ARGS); break;
