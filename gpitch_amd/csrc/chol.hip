@@ -338,7 +338,7 @@ static gp_status chol_set_attr(gp_handle h) {
 }
 
 gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
-                                  int maxM) {
+                                  int maxM, int pivot_base) {
   (void)maxM;
   if (batch <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_CHOL);
@@ -346,7 +346,7 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
   size_t sh = chol_smem_bytes(maxM, &cap);
   GP_CHECK(chol_set_attr(h));
   hipLaunchKernelGGL(chol_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_M, d_ld, h->d_status,
-                     (double*)nullptr, 0, 0, cap, 0);
+                     (double*)nullptr, 0, 0, cap, pivot_base);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -452,6 +452,29 @@ gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_
     f.triA = TRI_LOWER; f.alpha = -1.0;
     GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 3, 1, nb, c0, f));
   }
+  return GP_OK;
+}
+
+// after a panel-blocked factorisation: clear the blocks strictly above the block diagonal (the one-workgroup kernel
+// clears the upper triangle only inside the diagonal blocks it is given), so that L is usable as a dense operand
+__global__ void __launch_bounds__(256) zero_upper_blocks_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,
+                                                                const int* __restrict__ lds_, int nb) {
+  double* A = mats[blockIdx.y];
+  const int M = Ms[blockIdx.y];
+  const int64_t ld = lds_[blockIdx.y];
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)M * M; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx / M), j = (int)(idx % M);
+    if (j / nb > i / nb) A[(int64_t)i * ld + j] = 0.0;
+  }
+}
+
+gp_status launch_zero_upper_blocks_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
+                                           int maxM, int nb) {
+  if (batch <= 0 || maxM <= nb) return GP_OK;
+  int blocks = (int)(((int64_t)maxM * maxM + 255) / 256);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(zero_upper_blocks_kernel, dim3(blocks, batch), dim3(256), 0, h->stream, d_mats, d_M, d_ld, nb);
+  GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
 

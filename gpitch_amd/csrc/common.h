@@ -149,12 +149,14 @@ gp_status launch_sm_features(gp_handle h, DevKern k, const double* x1, int n1, c
 
 // chol.hip
 gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
-                                  int maxM);
+                                  int maxM, int pivot_base = 0);
 gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld, int pivot_base = 0);
 // one large matrix, blocked over the GEMM kernels: A -> L in place (lower), W = L^-1 (upper part zero); ld even
 size_t cholesky_large_workspace_bytes(int N);
 gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_t ld, void* ws, size_t ws_bytes);
 gp_status launch_tri_inverse_single(gp_handle h, const double* L, double* Linv, int M, int64_t ld);
+gp_status launch_zero_upper_blocks_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
+                                           int maxM, int nb);
 gp_status check_not_pd(gp_handle h);  // syncs; turns the device flag into GP_ERR_NOT_PD
 
 // gemm.hip

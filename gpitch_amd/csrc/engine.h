@@ -43,6 +43,7 @@ struct CondTask {
   // workspace (device)
   double* L = nullptr;    // M x M  Kuu -> chol
   double* W = nullptr;    // M x M  L^-1
+  double* Tblk = nullptr; // 128 x M scratch (blocked inverse)
   double* Kuf = nullptr;  // M x N
   double* A = nullptr;    // M x N  W Kuf
   double* A2 = nullptr;   // M x N  W^T A (unwhitened only)
@@ -61,6 +62,9 @@ struct CondBatch {
   // offsets of the descriptor arrays inside d_desc
   size_t off_chol_ptrs = 0, off_w_ptrs = 0, off_Ms = 0, off_lds = 0, off_f1 = 0, off_f1u = 0, off_f2 = 0, off_finish = 0;
   bool uploaded = false;
+  // blocked Kuu factorisation (engine.hip: cond_batch_factorize)
+  bool blocked = false; int nblk = 0;
+  size_t off_blk_mats[8] = {0}, off_blk_w[8] = {0}, off_blk_M[8] = {0}, off_blk_gemm[8][4] = {{0}};
 };
 
 size_t cond_task_workspace_doubles(int M, int N, int num_partials, bool whiten);

@@ -6,6 +6,8 @@
 #include <string.h>
 
 static inline int ldN_of(int N) { return (N + 1) & ~1; }
+#define CB_NB 128          // panel width of the blocked Kuu factorisation
+#define CB_MAX_PANELS 8    // M <= 1024
 
 size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten) {
   const size_t ldN = ldN_of(N);
@@ -13,6 +15,7 @@ size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten) {
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   add((size_t)M * M); add((size_t)M * M);          // L, W
+  add((size_t)CB_NB * M);                          // block-row scratch of the blocked inverse
   add((size_t)M * ldN); add((size_t)M * ldN);      // Kuf, A
   if (!whiten) add((size_t)M * ldN);               // A2
   if (m > 0) add(kernel_build_feat_ws_doubles(m, M, N));
@@ -25,6 +28,7 @@ bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten) {
   const int rb = gemm_rowblocks(t.M, 1);
   t.L = ar.take<double>((size_t)t.M * t.M);
   t.W = ar.take<double>((size_t)t.M * t.M);
+  t.Tblk = ar.take<double>((size_t)CB_NB * t.M);
   t.Kuf = ar.take<double>((size_t)t.M * ldN);
   t.A = ar.take<double>((size_t)t.M * ldN);
   t.A2 = whiten ? nullptr : ar.take<double>((size_t)t.M * ldN);
@@ -42,6 +46,10 @@ size_t cond_batch_desc_bytes(int count) {
   b += gp_align_up(count * sizeof(int), 256) * 2;      // Ms, lds
   b += gp_align_up(count * sizeof(GemmProblem), 256) * 3;
   b += gp_align_up(count * cond_finish_item_bytes(), 256);
+  // blocked Cholesky + inverse (up to CB_MAX_PANELS 128-column panels): per panel 2 pointer arrays, 1 size array,
+  // 4 GEMM problem arrays
+  b += CB_MAX_PANELS * (2 * gp_align_up(count * sizeof(double*), 256) + gp_align_up(count * sizeof(int), 256) +
+                        4 * gp_align_up(count * sizeof(GemmProblem), 256));
   return b;
 }
 
@@ -95,8 +103,92 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten) {
     cond_finish_fill(fin + g * cond_finish_item_bytes(), t.s1, rb, t.s2, t.q_sqrt ? rb : 0, t.dot, rb, t.kern,
                      t.fmean, t.fvar);
   }
+  // Blocked factorisation of the Kuu batch (M > 256): 128-column panels; the diagonal blocks go to the one-workgroup
+  // kernels (batched over the GPs), the O(M^3) panel solve / trailing update / block-row inverse to the batched GEMMs.
+  // One workgroup per GP for the whole 512 x 512 factor + inverse took 1.8 ms of a 31 ms step.
+  cb.nblk = (cb.maxM + CB_NB - 1) / CB_NB;
+  cb.blocked = (cb.maxM > 256 && cb.nblk <= CB_MAX_PANELS);
+  if (cb.blocked) {
+    for (int k = 0; k < cb.nblk; k++) {
+      cb.off_blk_mats[k] = region(G * sizeof(double*));
+      cb.off_blk_w[k] = region(G * sizeof(double*));
+      cb.off_blk_M[k] = region(G * sizeof(int));
+      for (int q = 0; q < 4; q++) cb.off_blk_gemm[k][q] = region(G * sizeof(GemmProblem));
+      double** bm = (double**)(cb.h_desc.data() + cb.off_blk_mats[k]);
+      double** bw = (double**)(cb.h_desc.data() + cb.off_blk_w[k]);
+      int* bM = (int*)(cb.h_desc.data() + cb.off_blk_M[k]);
+      GemmProblem* gp[4];
+      for (int q = 0; q < 4; q++) gp[q] = (GemmProblem*)(cb.h_desc.data() + cb.off_blk_gemm[k][q]);
+      const int c0 = k * CB_NB;
+      for (int g = 0; g < G; g++) {
+        const CondTask& t = cb.tasks[g];
+        const int64_t ld = t.M;
+        const int nb = (c0 >= t.M) ? 0 : ((t.M - c0 < CB_NB) ? t.M - c0 : CB_NB);
+        const int r0 = c0 + nb, mrem = (nb > 0) ? t.M - r0 : 0;
+        const int64_t dk = (nb > 0) ? (int64_t)c0 * ld + c0 : 0;
+        bm[g] = t.L + dk; bw[g] = t.W + dk; bM[g] = nb;
+        for (int q = 0; q < 4; q++) memset(&gp[q][g], 0, sizeof(GemmProblem));
+        if (nb == 0) continue;
+        { GemmProblem& r = gp[0][g];   // panel, in place: L[r0:, c0:c0+nb] <- L[r0:, c0:c0+nb] W_kk^T  (one 128-wide tile column)
+          r.A = t.L + (int64_t)r0 * ld + c0; r.lda = ld; r.B = t.W + dk; r.ldb = ld; r.C = t.L + (int64_t)r0 * ld + c0; r.ldc = ld;
+          r.M = mrem; r.N = nb; r.K = nb; }
+        { GemmProblem& r = gp[1][g];   // trailing: L[r0:, r0:] -= P P^T (lower)
+          r.A = t.L + (int64_t)r0 * ld + c0; r.lda = ld; r.B = r.A; r.ldb = ld; r.C = t.L + (int64_t)r0 * ld + r0; r.ldc = ld;
+          r.M = mrem; r.N = mrem; r.K = nb; }
+        { GemmProblem& r = gp[2][g];   // T = L[c0:c0+nb, :c0] W[:c0, :c0]   (128 x M scratch)
+          r.A = t.L + (int64_t)c0 * ld; r.lda = ld; r.B = t.W; r.ldb = ld; r.C = t.Tblk; r.ldc = ld; r.M = nb; r.N = c0; r.K = c0; }
+        { GemmProblem& r = gp[3][g];   // W[c0:c0+nb, :c0] = -W_kk T
+          r.A = t.W + dk; r.lda = ld; r.B = t.Tblk; r.ldb = ld; r.C = t.W + (int64_t)c0 * ld; r.ldc = ld; r.M = nb; r.N = c0; r.K = nb; }
+      }
+    }
+    if (off > need) return gp_fail(h, GP_ERR_WORKSPACE, "descriptor workspace too small (blocked factorisation)");
+  }
   GP_HIP_CHECK(h, hipMemcpyAsync(cb.d_desc, cb.h_desc.data(), need, hipMemcpyHostToDevice, h->stream));
   cb.uploaded = true;
+  return GP_OK;
+}
+
+// Kuu_g -> L_g (lower, in place) and W_g = L_g^-1 for the whole batch
+static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb) {
+  const int G = (int)cb.tasks.size();
+  if (!cb.blocked) {
+    GP_CHECK(launch_cholesky_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                     (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
+                                     cb.maxM));
+    return launch_tri_inverse_batched(h, (const double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                      (double* const*)(cb.d_desc + cb.off_w_ptrs),
+                                      (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G);
+  }
+  const int* lds = (const int*)(cb.d_desc + cb.off_lds);
+  for (int g = 0; g < G; g++)   // zero above the block diagonal of W (the diagonal blocks are written whole)
+    GP_HIP_CHECK(h, hipMemsetAsync(cb.tasks[g].W, 0, (size_t)cb.tasks[g].M * cb.tasks[g].M * sizeof(double), h->stream));
+  for (int k = 0; k < cb.nblk; k++) {
+    double* const* mats = (double* const*)(cb.d_desc + cb.off_blk_mats[k]);
+    double* const* ws = (double* const*)(cb.d_desc + cb.off_blk_w[k]);
+    const int* bM = (const int*)(cb.d_desc + cb.off_blk_M[k]);
+    const int c0 = k * CB_NB, rem = cb.maxM - c0 - CB_NB;
+    GP_CHECK(launch_cholesky_batched(h, mats, bM, lds, G, CB_NB, c0));
+    GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)mats, ws, bM, lds, G));
+    if (rem > 0) {
+      GemmFlags f;
+      f.transB = 1; f.triB = TRI_UPPER; f.big_tiles = 1;   // 128-wide tiles: each workgroup reads exactly the rows it rewrites
+      GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][0]), G, rem, CB_NB, f));
+      f = GemmFlags();
+      f.transB = 1; f.triC = TRI_LOWER; f.alpha = -1.0; f.beta = 1.0;
+      GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][1]), G, rem, rem, f));
+    }
+  }
+  GP_CHECK(launch_zero_upper_blocks_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                            (const int*)(cb.d_desc + cb.off_Ms), lds, G, cb.maxM, CB_NB));
+  for (int k = 1; k < cb.nblk; k++) {
+    const int c0 = k * CB_NB;
+    GemmFlags f;
+    f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][2]), G, CB_NB, c0, f));
+    f = GemmFlags();
+    f.triA = TRI_LOWER; f.alpha = -1.0;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][3]), G, CB_NB, c0, f));
+  }
   return GP_OK;
 }
 
@@ -113,14 +205,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat));
   }
   // 2. Cholesky and inverse (one workgroup per GP)
-  if (!reuse_factor) {
-    GP_CHECK(launch_cholesky_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
-                                     (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
-                                     cb.maxM));
-    GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)(cb.d_desc + cb.off_chol_ptrs),
-                                        (double* const*)(cb.d_desc + cb.off_w_ptrs),
-                                        (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G));
-  }
+  if (!reuse_factor) GP_CHECK(cond_batch_factorize(h, cb));
   // 3. Kuf
   for (int g = 0; g < G; g++) {
     const CondTask& t = cb.tasks[g];

@@ -434,3 +434,32 @@ def test_predictions_reuse_factorisation_and_memoise(gp_handle):
     with pytest.raises(Exception):
         h.check(h.lib.gp_pdgp_predict_reuse(fresh._plan, fresh._params.data_ptr(), xs.data_ptr(), 10, fm.data_ptr(),
                                             fv.data_ptr(), None))
+
+
+def test_blocked_kuu_factorisation_with_partial_last_panel(gp_handle):
+    """M > 256 switches the Kuu batch to the panel-blocked Cholesky + inverse (engine.hip: cond_batch_factorize);
+    M = 300 leaves a 44-column last panel.  ELBO and gradients against the oracle (cond(Kuu) ~ 1e9 here, so the
+    comparison carries cond * eps on both sides)."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(900, 300, 1, num_partials=3, seed=6)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model._pack()
+    f = model._elbo(True)
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    assert abs(f - ref_f) <= 1e-7 * abs(ref_f), (f, ref_f)
+    got_g = model_grad_dict(model)
+    for name, rg in ref_g.items():
+        gg = got_g[name]
+        if name.startswith("q_sqrt"):
+            rg = np.tril(rg[:, :, 0])[:, :, None]
+            assert np.all(np.triu(gg[:, :, 0], 1) == 0)
+        scale = max(np.abs(rg).max(), 1e-12)
+        err = np.abs(gg.reshape(rg.shape) - rg).max() / scale
+        assert err <= 2e-4, (name, err)
+    # the factor itself: L L^T reproduces Kuu + jitter I, W L = I (through the one-shot operator path, M = 300 single
+    # workgroup) vs the blocked batch path above is covered by the ELBO; here the prediction path at M = 300
+    xs = prob["x"][::9]
+    ma, va, mc, vc, ms = model.predict_act_n_com(xs)
+    from oracle import gpflow05 as orc
+    rm, rv = orc.conditional(xs, prob["za"][0], prob["kern_act"][0], prob["q_mu_act"][0], prob["q_sqrt_act"][0], whiten=True)
+    np.testing.assert_allclose(ma[0], rm, rtol=0, atol=1e-6 * np.abs(rm).max())
