@@ -68,6 +68,9 @@ gp_status gp_destroy(gp_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& r : h->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;

@@ -22,6 +22,9 @@ struct gp_handle_s {
   int32_t* d_status = nullptr;   // device int[4]: {not_pd_flag, pivot_index, gp_index, spare}
   int num_cus = 256;
   GpLogisticTable logistic = {}; int num_logistic = 0;
+  // helper stream for work that can overlap the main stream (the latency-bound Kuu factorisation runs on ~24 CUs
+  // while the Kuf builds stream over the rest): created on first use, joined through events
+  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // timers
   bool timers_on = false;
   struct TimerRec { hipEvent_t e0, e1; int which; };

@@ -48,6 +48,7 @@ struct CondTask {
   double* A = nullptr;    // M x N  W Kuf
   double* A2 = nullptr;   // M x N  W^T A (unwhitened only)
   double* feat = nullptr; // spectral-mixture features (2m x (M + N))
+  double* feat_uu = nullptr; // the same for the Kuu build (2m x M), separate because the two builds overlap
   double* s1 = nullptr; double* s2 = nullptr; double* dot = nullptr;  // [rowblocks][N] partials
   double* fmean = nullptr; double* fvar = nullptr;                    // N each
 };

@@ -18,7 +18,7 @@ size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten) {
   add((size_t)CB_NB * M);                          // block-row scratch of the blocked inverse
   add((size_t)M * ldN); add((size_t)M * ldN);      // Kuf, A
   if (!whiten) add((size_t)M * ldN);               // A2
-  if (m > 0) add(kernel_build_feat_ws_doubles(m, M, N));
+  if (m > 0) { add(kernel_build_feat_ws_doubles(m, M, N)); add(kernel_build_feat_ws_doubles(m, M, M)); }
   add((size_t)rb * N); add((size_t)rb * N); add((size_t)rb * N);  // s1, s2, dot
   return d;
 }
@@ -32,8 +32,10 @@ bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten) {
   t.Kuf = ar.take<double>((size_t)t.M * ldN);
   t.A = ar.take<double>((size_t)t.M * ldN);
   t.A2 = whiten ? nullptr : ar.take<double>((size_t)t.M * ldN);
-  t.feat = (t.kern.m > 0 && gp_kern_is_mercer(t.kern.type))
-               ? ar.take<double>(kernel_build_feat_ws_doubles(t.kern.m, t.M, N)) : nullptr;
+  const bool mercer = (t.kern.m > 0 && gp_kern_is_mercer(t.kern.type));
+  t.feat = mercer ? ar.take<double>(kernel_build_feat_ws_doubles(t.kern.m, t.M, N)) : nullptr;
+  // the Kuu build has its own feature table: it runs concurrently with the Kuf build (cond_batch_run)
+  t.feat_uu = mercer ? ar.take<double>(kernel_build_feat_ws_doubles(t.kern.m, t.M, t.M)) : nullptr;
   t.s1 = ar.take<double>((size_t)rb * N);
   t.s2 = ar.take<double>((size_t)rb * N);
   t.dot = ar.take<double>((size_t)rb * N);
@@ -198,19 +200,45 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   if (G == 0 || N <= 0) return GP_OK;
   if (!cb.uploaded || cb.N != N) return gp_fail(h, GP_ERR_BAD_ARG, "conditional batch descriptors not uploaded");
   const int64_t ldN = ldN_of(N);
-  // 1. Kuu + jitter I   (steps 1-2 are skipped when the caller vouches that L and W already hold the factor of
-  //    the current parameters: repeated predictions at new inputs, pdgp.py:17-44 predict_windowed)
-  for (int g = 0; g < G && !reuse_factor; g++) {
-    const CondTask& t = cb.tasks[g];
-    GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat));
+  // 1-2. Kuu + jitter I, its Cholesky factor and inverse — skipped when the caller vouches that L and W already hold
+  //    the factor of the current parameters (repeated predictions at new inputs, pdgp.py:17-44 predict_windowed).
+  //    The factorisation is latency-bound on ~G CUs, so it runs on the handle's helper stream while the main stream
+  //    builds the Kuf strips (HBM / VALU-bound on all CUs); they meet again before A = W Kuf.
+  bool forked = false;
+  hipStream_t main_stream = h->stream;
+  if (!reuse_factor) {
+    if (!h->aux_stream) {
+      if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) h->aux_stream = nullptr;
+      if (h->aux_stream && (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(h->aux_stream); h->aux_stream = nullptr;
+      }
+    }
+    forked = (h->aux_stream != nullptr) && (N >= 4096);
+    if (forked) {
+      GP_HIP_CHECK(h, hipEventRecord(h->ev_fork, main_stream));
+      GP_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+      h->stream = h->aux_stream;          // the launchers below enqueue on the handle's current stream
+    }
+    gp_status st = GP_OK;
+    for (int g = 0; g < G && st == GP_OK; g++) {
+      const CondTask& t = cb.tasks[g];
+      st = launch_kernel_build(h, t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat_uu);
+    }
+    if (st == GP_OK) st = cond_batch_factorize(h, cb);
+    if (forked) {
+      hipError_t e = hipEventRecord(h->ev_join, h->aux_stream);
+      h->stream = main_stream;
+      if (e != hipSuccess) return gp_fail(h, GP_ERR_HIP, "hipEventRecord(join) failed");
+    }
+    GP_CHECK(st);
   }
-  // 2. Cholesky and inverse (one workgroup per GP)
-  if (!reuse_factor) GP_CHECK(cond_batch_factorize(h, cb));
   // 3. Kuf
   for (int g = 0; g < G; g++) {
     const CondTask& t = cb.tasks[g];
     GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, x, N, t.Kuf, ldN, 0, 0.0, t.feat));
   }
+  if (forked) GP_HIP_CHECK(h, hipStreamWaitEvent(main_stream, h->ev_join, 0));
   // 4. A = W Kuf (+ column reductions)
   {
     GemmFlags f;
