@@ -22,6 +22,41 @@ GpTimerScope::~GpTimerScope() {
   h->pending.push_back({e0, e1, which});
 }
 
+bool gp_aux_fork(gp_handle h) {
+  if (h->aux_active) return false;
+  if (!h->aux_stream) {
+    if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) { h->aux_stream = nullptr; return false; }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(h->aux_stream); h->aux_stream = nullptr;
+      return false;
+    }
+  }
+  if (hipEventRecord(h->ev_fork, h->stream) != hipSuccess) return false;
+  if (hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0) != hipSuccess) return false;
+  h->main_stream_saved = h->stream;
+  h->stream = h->aux_stream;
+  h->aux_active = true;
+  return true;
+}
+
+gp_status gp_aux_end(gp_handle h) {
+  if (!h->aux_active) return GP_OK;
+  hipError_t e = hipEventRecord(h->ev_join, h->aux_stream);
+  h->stream = h->main_stream_saved;
+  h->aux_active = false;
+  h->aux_pending = true;
+  if (e != hipSuccess) return gp_fail(h, GP_ERR_HIP, "hipEventRecord on the helper stream failed");
+  return GP_OK;
+}
+
+gp_status gp_aux_join(gp_handle h) {
+  if (!h->aux_pending) return GP_OK;
+  h->aux_pending = false;
+  GP_HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  return GP_OK;
+}
+
 static gp_status drain_timers(gp_handle h) {
   for (auto& r : h->pending) {
     GP_HIP_CHECK(h, hipEventSynchronize(r.e1));

@@ -648,45 +648,81 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
     GP_CHECK(launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f));
     GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), nK, maxM, 1));
+    // From here two independent chains remain: the Kuf side (the big Kuf_bar product and its contraction with
+    // dK/dtheta over all frames) and the Kuu side (the Cholesky adjoint, six M x M products, and its contraction
+    // over M x M).  The Kuu side is ~1.4 ms of small launches: it runs on the helper stream underneath Kuf_bar.
+    const bool forked = (n >= 4096) && gp_aux_fork(h);
+    gp_status st = GP_OK;
+    std::vector<int> np_uu(p->G, 0);
+    auto kuu_side = [&]() -> gp_status {
+      GemmFlags f;
+      // Lbar = -tril(W^T Wbar W^T); P = Phi(L^T Lbar); S = W^T P W
+      f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+      GP_CHECK(launch_gemm_batched(h, D(S_T2), nK, maxM, maxM, f));
+      f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
+      GP_CHECK(launch_gemm_batched(h, D(S_LBAR), nK, maxM, maxM, f));
+      f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+      GP_CHECK(launch_gemm_batched(h, D(S_P), nK, maxM, maxM, f));
+      GP_CHECK(launch_phi_batched(h, D(S_P), nK, maxM));
+      f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+      GP_CHECK(launch_gemm_batched(h, D(S_T3), nK, maxM, maxM, f));
+      f = GemmFlags(); f.triB = TRI_LOWER;
+      GP_CHECK(launch_gemm_batched(h, D(S_S), nK, maxM, maxM, f));
+      for (int g : p->kgps) {   // contraction of Kuu_bar with dK(z, z)/d(theta, z): partial sums only
+        const PdgpGP& q = p->gps[g];
+        const CondTask& t = p->cb.tasks[g];
+        const BwdBufs& bb = p->bw[g];
+        const double* z = params + q.off_z;
+        const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS;
+        double* gz_uu = q.need_z ? bb.gz_part + (size_t)cb_uf * q.M : nullptr;
+        GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, z, q.M, bb.E, q.M, nullptr, nullptr, 1, t.feat, bb.hyp_part_uu,
+                                       &np_uu[g], gz_uu));
+      }
+      return GP_OK;
+    };
+    if (forked) {            // helper stream: Kuu side
+      st = kuu_side();
+      gp_status s2 = gp_aux_end(h);
+      if (st == GP_OK) st = s2;
+      GP_CHECK(st);
+    }
     // Kuf_bar (dense part) = R (A diag(2 gv))
     f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
     GP_CHECK(launch_gemm_batched(h, D(S_G), nK, maxM, n, f));
-    // Kuu side: Lbar = -tril(W^T Wbar W^T); P = Phi(L^T Lbar); S = W^T P W
-    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-    GP_CHECK(launch_gemm_batched(h, D(S_T2), nK, maxM, maxM, f));
-    f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
-    GP_CHECK(launch_gemm_batched(h, D(S_LBAR), nK, maxM, maxM, f));
-    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-    GP_CHECK(launch_gemm_batched(h, D(S_P), nK, maxM, maxM, f));
-    GP_CHECK(launch_phi_batched(h, D(S_P), nK, maxM));
-    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-    GP_CHECK(launch_gemm_batched(h, D(S_T3), nK, maxM, maxM, f));
-    f = GemmFlags(); f.triB = TRI_LOWER;
-    GP_CHECK(launch_gemm_batched(h, D(S_S), nK, maxM, maxM, f));
-  }
-  if (!white) {
+    if (!forked) GP_CHECK(kuu_side());
+    if (!white) {
+      GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));
+      f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;
+      GP_CHECK(launch_gemm_batched(h, D(S_GQ_L), G, maxM, maxM, f));
+    }
+    // Kuf side of the hyper-parameter and inducing-input gradients
+    for (int g : p->kgps) {
+      const PdgpGP& q = p->gps[g];
+      const CondTask& t = p->cb.tasks[g];
+      const BwdBufs& bb = p->bw[g];
+      const double* z = params + q.off_z;
+      const double* gm = p->gFmu + (size_t)g * n;
+      int np_uf = 0;
+      const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS;
+      double* gz_uf = q.need_z ? bb.gz_part : nullptr;
+      GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, x, n, bb.G, ldN, bb.alpha, gm, 0, t.feat, bb.hyp_part, &np_uf, gz_uf));
+      GP_CHECK(launch_hyper_finish(h, t.kern, bb.hyp_part, np_uf, bb.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
+                                   grad + q.off_z));
+    }
+    GP_CHECK(gp_aux_join(h));
+    for (int g : p->kgps) {   // the Kuu-side sums join the same gradient entries: after the join, on the main stream
+      const PdgpGP& q = p->gps[g];
+      const CondTask& t = p->cb.tasks[g];
+      const BwdBufs& bb = p->bw[g];
+      const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS, cb_uu = (q.M + HY_THREADS - 1) / HY_THREADS;
+      double* gz_uu = q.need_z ? bb.gz_part + (size_t)cb_uf * q.M : nullptr;
+      GP_CHECK(launch_hyper_finish(h, t.kern, bb.hyp_part_uu, np_uu[g], nullptr, grad + q.off_theta, gz_uu, cb_uu, q.M,
+                                   grad + q.off_z));
+    }
+  } else if (!white) {
     GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));
     f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;
     GP_CHECK(launch_gemm_batched(h, D(S_GQ_L), G, maxM, maxM, f));
-  }
-  // hyper-parameter and inducing-input gradients
-  for (int g : p->kgps) {
-    const PdgpGP& q = p->gps[g];
-    const CondTask& t = p->cb.tasks[g];
-    const BwdBufs& b = p->bw[g];
-    const double* z = params + q.off_z;
-    const double* gm = p->gFmu + (size_t)g * n;
-    int np_uf = 0, np_uu = 0;
-    const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS, cb_uu = (q.M + HY_THREADS - 1) / HY_THREADS;
-    double* gz_uf = q.need_z ? b.gz_part : nullptr;
-    double* gz_uu = q.need_z ? b.gz_part + (size_t)cb_uf * q.M : nullptr;
-    GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, x, n, b.G, ldN, b.alpha, gm, 0, t.feat, b.hyp_part, &np_uf, gz_uf));
-    GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part, np_uf, b.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
-                                 grad + q.off_z));
-    GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, z, q.M, b.E, q.M, nullptr, nullptr, 1, t.feat, b.hyp_part_uu,
-                                   &np_uu, gz_uu));
-    GP_CHECK(launch_hyper_finish(h, t.kern, b.hyp_part_uu, np_uu, nullptr, grad + q.off_theta, gz_uu, cb_uu, q.M,
-                                 grad + q.off_z));
   }
   return GP_OK;
 }

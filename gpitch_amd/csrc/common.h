@@ -25,6 +25,7 @@ struct gp_handle_s {
   // helper stream for work that can overlap the main stream (the latency-bound Kuu factorisation runs on ~24 CUs
   // while the Kuf builds stream over the rest): created on first use, joined through events
   hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t main_stream_saved = nullptr; bool aux_active = false, aux_pending = false;
   // timers
   bool timers_on = false;
   struct TimerRec { hipEvent_t e0, e1; int which; };
@@ -103,6 +104,13 @@ static inline __host__ __device__ bool gp_kern_is_mercer(int t) { return t == GP
 static inline __host__ __device__ bool gp_kern_is_broadcast(int t) { return t == GP_KERN_MATERN12SM || t == GP_KERN_MATERN32SM; }
 // Kdiag = variance * sum_k energy_k (true) or just variance (false)
 static inline __host__ __device__ bool gp_kern_kdiag_energy(int t) { return gp_kern_has_partials(t) && t != GP_KERN_MERCER_MATERN52SM; }
+
+// Fork / join of the handle's helper stream (see gp_handle_s::aux_stream).  Between gp_aux_fork and gp_aux_end the
+// launchers (which enqueue on h->stream) target the helper stream; gp_aux_join makes the main stream wait for it.
+// gp_aux_fork returns false (and changes nothing) when no helper stream can be had: the work then stays in line.
+bool gp_aux_fork(gp_handle h);
+gp_status gp_aux_end(gp_handle h);
+gp_status gp_aux_join(gp_handle h);
 
 struct GpTimerScope {
   gp_handle h;

@@ -204,41 +204,32 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   //    the factor of the current parameters (repeated predictions at new inputs, pdgp.py:17-44 predict_windowed).
   //    The factorisation is latency-bound on ~G CUs, so it runs on the handle's helper stream while the main stream
   //    builds the Kuf strips (HBM / VALU-bound on all CUs); they meet again before A = W Kuf.
-  bool forked = false;
-  hipStream_t main_stream = h->stream;
-  if (!reuse_factor) {
-    if (!h->aux_stream) {
-      if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) h->aux_stream = nullptr;
-      if (h->aux_stream && (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
-        (void)hipStreamDestroy(h->aux_stream); h->aux_stream = nullptr;
-      }
-    }
-    forked = (h->aux_stream != nullptr) && (N >= 4096);
-    if (forked) {
-      GP_HIP_CHECK(h, hipEventRecord(h->ev_fork, main_stream));
-      GP_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-      h->stream = h->aux_stream;          // the launchers below enqueue on the handle's current stream
-    }
-    gp_status st = GP_OK;
-    for (int g = 0; g < G && st == GP_OK; g++) {
-      const CondTask& t = cb.tasks[g];
+  // The host feeds both queues alternately (a Kuu build for the helper stream, a Kuf build for the main stream):
+  // issuing all of one stream's launches first left the other queue waiting for the host for ~0.6 ms.
+  const bool forked = !reuse_factor && (N >= 4096) && gp_aux_fork(h);
+  hipStream_t aux = h->stream, mainq = forked ? h->main_stream_saved : h->stream;
+  gp_status st = GP_OK;
+  for (int g = 0; g < G && st == GP_OK; g++) {
+    const CondTask& t = cb.tasks[g];
+    if (!reuse_factor) {
+      h->stream = aux;
       st = launch_kernel_build(h, t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat_uu);
     }
-    if (st == GP_OK) st = cond_batch_factorize(h, cb);
-    if (forked) {
-      hipError_t e = hipEventRecord(h->ev_join, h->aux_stream);
-      h->stream = main_stream;
-      if (e != hipSuccess) return gp_fail(h, GP_ERR_HIP, "hipEventRecord(join) failed");
+    if (forked && st == GP_OK) {       // 3. Kuf (main queue), interleaved
+      h->stream = mainq;
+      st = launch_kernel_build(h, t.kern, t.z, t.M, x, N, t.Kuf, ldN, 0, 0.0, t.feat);
     }
-    GP_CHECK(st);
   }
-  // 3. Kuf
-  for (int g = 0; g < G; g++) {
+  h->stream = aux;
+  if (!reuse_factor && st == GP_OK) st = cond_batch_factorize(h, cb);
+  if (forked) { gp_status s2 = gp_aux_end(h); if (st == GP_OK) st = s2; }
+  GP_CHECK(st);
+  // 3. Kuf (when it was not interleaved above)
+  for (int g = 0; g < G && !forked; g++) {
     const CondTask& t = cb.tasks[g];
     GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, x, N, t.Kuf, ldN, 0, 0.0, t.feat));
   }
-  if (forked) GP_HIP_CHECK(h, hipStreamWaitEvent(main_stream, h->ev_join, 0));
+  GP_CHECK(gp_aux_join(h));
   // 4. A = W Kuf (+ column reductions)
   {
     GemmFlags f;
