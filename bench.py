@@ -201,10 +201,12 @@ def main():
         for name, mm in (("kuf_build", 0), ("kuf_build_sm", args.partials)):
             ms, n = timers[name]
             if n:
-                byts = T * (float(M) * N + N + M) + T * 2.0 * mm * (M + N)
+                # one launch builds the Kuf strips of a whole kernel family (all P activation or all P component GPs)
+                gps = max(1, int(round(len(model._local) * args.steps / float(n))))
+                byts = gps * (T * (float(M) * N + N + M) + T * 2.0 * mm * (M + N))
                 a = byts / (ms / n * 1e-3) / 1e9
                 kuf[name] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
-                             "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": byts}
+                             "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": byts, "latent_gps_per_launch": gps}
         out = {
             "metric": "ELBO-steps/sec", "value": (1 if pitch else world) * args.steps / elapsed, "unit": "steps/s",
             "n_gpus": world,

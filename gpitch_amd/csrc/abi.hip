@@ -219,7 +219,7 @@ gp_status gp_conditional_diag(gp_handle h, const gp_kernel_desc* kern, const dou
   if (!cond_task_carve(ar, t, N, whiten != 0) || !cb.d_desc)
     return gp_fail(h, GP_ERR_WORKSPACE, "gp_conditional_diag: workspace too small");
   cb.N = N;
-  GP_CHECK(cond_batch_upload(h, cb, whiten != 0));
+  GP_CHECK(cond_batch_upload(h, cb, whiten != 0, jitter));
   GP_CHECK(cond_batch_run(h, cb, xnew, N, whiten != 0, jitter));
   return check_not_pd(h);
 }

@@ -213,6 +213,18 @@ gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, doub
 int gemm_nt_nsplit(int M, int Nlong, int batch);
 int gemm_rowblocks(int M, int big_tiles);
 
+// grouped covariance builds (cov.hip): one launch for all matrices of a kernel family
+struct CovItem {
+  DevKern k; const double* x1; const double* x2; double* out; const double* f1; const double* f2;
+  int64_t ld; double diag_add; int n1, n2, accumulate, vec_ok;
+};
+struct FeatItem { DevKern k; const double* x; double* f; int n; int pad; };
+void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const double* x2, int n2, double* out, int64_t ld,
+                   int accumulate, double diag_add, double* feat_ws);
+gp_status launch_sm_features_items(gp_handle h, const FeatItem* d_items, int count, int max_n, int mpad,
+                                   const double* x_shared, int n_shared);
+gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem* d_items, int count, int max_n1,
+                                    int max_n2, const double* x2_shared, int n2_shared);
 // lik.hip
 // whitened KL: each item writes GP_KL_BLOCKS partial sums to out[0..GP_KL_BLOCKS)
 #define GP_KL_BLOCKS 16

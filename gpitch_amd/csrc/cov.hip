@@ -37,7 +37,9 @@ __device__ __forceinline__ double r2_expand(double a, double aa, double b, doubl
 // Precompute spectral-mixture features, zero-padded to MPAD partials so the consumers can unroll without
 // guards:  f[q][j] = sqrt(e_q) cos(2 pi f_q x_j),  f[MPAD + q][j] = sqrt(e_q) sin(2 pi f_q x_j),  q < m;  0 for q >= m.
 __global__ void __launch_bounds__(256) sm_features_kernel(DevKern k, const double* __restrict__ x, int n,
-                                                          double* __restrict__ f, int mpad) {
+                                                          double* __restrict__ f, int mpad,
+                                                          const FeatItem* __restrict__ items) {
+  if (items) { const FeatItem it = items[blockIdx.z]; k = it.k; f = it.f; if (it.n >= 0) { x = it.x; n = it.n; } }
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int p = blockIdx.y;
   if (j >= n) return;
@@ -64,7 +66,15 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
                                                                 double* __restrict__ out, int64_t ld,
                                                                 int accumulate, double diag_add,
                                                                 const double* __restrict__ f1,
-                                                                const double* __restrict__ f2, int vec_ok) {
+                                                                const double* __restrict__ f2, int vec_ok,
+                                                                const CovItem* __restrict__ items) {
+  if (items) {
+    const CovItem it = items[blockIdx.z];
+    k = it.k; x1 = it.x1; n1 = it.n1; out = it.out; ld = it.ld;
+    if (it.n2 >= 0) { x2 = it.x2; n2 = it.n2; }         // n2 < 0: every item shares the launch's x2 / n2 (the frames)
+    accumulate = it.accumulate; diag_add = it.diag_add; f1 = it.f1; f2 = it.f2; vec_ok = it.vec_ok;
+    if ((int)(blockIdx.y * COV_ROWS) >= n1) return;     // the grid is sized for the largest item
+  }
   extern __shared__ double smem[];  // MODE 1: z-features for this block's rows [COV_ROWS][2m]
   __shared__ double row_a[COV_ROWS];  // x1[i] / lengthscale (the exact quotient, computed once per row, not per entry)
   __shared__ double etab[GP_EXP_TAB];
@@ -219,14 +229,14 @@ size_t kernel_build_feat_ws_doubles(int m, int n1, int n2) {
 template <int MPAD>
 static void launch_mercer(gp_handle h, dim3 grid, DevKern k, const double* x1, int n1, const double* x2, int n2,
                           double* out, int64_t ld, int accumulate, double diag_add, const double* f1, const double* f2,
-                          int vec_ok) {
+                          int vec_ok, const CovItem* items) {
   size_t sh = (size_t)COV_ROWS * 2 * MPAD * sizeof(double);
   if (k.type == GP_KERN_MERCER_MATERN12SM)
     hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 0>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
-                       ld, accumulate, diag_add, f1, f2, vec_ok);
+                       ld, accumulate, diag_add, f1, f2, vec_ok, items);
   else
     hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 2>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
-                       ld, accumulate, diag_add, f1, f2, vec_ok);
+                       ld, accumulate, diag_add, f1, f2, vec_ok, items);
 }
 
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
@@ -244,31 +254,31 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
     double* f1 = feat_ws;
     double* f2 = (x2 == x1) ? f1 : feat_ws + gp_align_up((size_t)2 * mp * n1, 32);
     dim3 g1((n1 + 255) / 256, mp);
-    hipLaunchKernelGGL(sm_features_kernel, g1, dim3(256), 0, h->stream, k, x1, n1, f1, mp);
+    hipLaunchKernelGGL(sm_features_kernel, g1, dim3(256), 0, h->stream, k, x1, n1, f1, mp, (const FeatItem*)nullptr);
     if (x2 != x1) {
       dim3 g2((n2 + 255) / 256, mp);
-      hipLaunchKernelGGL(sm_features_kernel, g2, dim3(256), 0, h->stream, k, x2, n2, f2, mp);
+      hipLaunchKernelGGL(sm_features_kernel, g2, dim3(256), 0, h->stream, k, x2, n2, f2, mp, (const FeatItem*)nullptr);
     }
     dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
     switch (mp) {
-      case 4: launch_mercer<4>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
-      case 8: launch_mercer<8>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
-      case 12: launch_mercer<12>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
-      case 16: launch_mercer<16>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
-      case 20: launch_mercer<20>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
-      case 24: launch_mercer<24>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
-      case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
-      default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok); break;
+      case 4: launch_mercer<4>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      case 8: launch_mercer<8>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      case 12: launch_mercer<12>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      case 16: launch_mercer<16>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      case 20: launch_mercer<20>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      case 24: launch_mercer<24>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
     }
   } else if (gp_kern_is_broadcast(k.type)) {
     if (k.m < 1) return gp_fail(h, GP_ERR_BAD_ARG, "num_partials must be >= 1");
     dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + COV_ROWS - 1) / COV_ROWS);
     hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
-                       accumulate, diag_add, nullptr, nullptr, vec_ok);
+                       accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr);
   } else if (k.type >= GP_KERN_MATERN12 && k.type <= GP_KERN_RBF) {
     dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
 #define COV_STAT(T) hipLaunchKernelGGL((cov_build_kernel<0, 2, 1, T>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, \
-                                      x2, n2, out, ld, accumulate, diag_add, nullptr, nullptr, vec_ok)
+                                      x2, n2, out, ld, accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr)
     switch (k.type) {
       case GP_KERN_MATERN12: COV_STAT(GP_KERN_MATERN12); break;
       case GP_KERN_MATERN32: COV_STAT(GP_KERN_MATERN32); break;
@@ -283,15 +293,83 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
   return GP_OK;
 }
 
+// ---- grouped launches: all matrices of one kernel family (same type, same padded partial count) in one launch ----
+void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const double* x2, int n2, double* out, int64_t ld,
+                   int accumulate, double diag_add, double* feat_ws) {
+  if (!x2 && n2 >= 0) { x2 = x1; n2 = n1; }      // n2 < 0: x2 / n2 come from the launch (shared frames)
+  it->k = k; it->x1 = x1; it->n1 = n1; it->x2 = x2; it->n2 = n2; it->out = out; it->ld = ld;
+  it->accumulate = accumulate; it->diag_add = diag_add;
+  it->vec_ok = ((ld % 2) == 0) && ((((uintptr_t)out) & 15) == 0);
+  it->f1 = it->f2 = nullptr;
+  if (gp_kern_is_mercer(k.type) && feat_ws) {
+    const int mp = sm_mpad(k.m);
+    it->f1 = feat_ws;
+    it->f2 = (n2 >= 0 && x2 == x1) ? feat_ws : feat_ws + gp_align_up((size_t)2 * mp * n1, 32);
+  }
+}
+
+gp_status launch_sm_features_items(gp_handle h, const FeatItem* d_items, int count, int max_n, int mpad,
+                                   const double* x_shared, int n_shared) {
+  if (count <= 0 || max_n <= 0) return GP_OK;
+  hipLaunchKernelGGL(sm_features_kernel, dim3((max_n + 255) / 256, mpad, count), dim3(256), 0, h->stream, DevKern{0, 0, nullptr},
+                     x_shared, n_shared, (double*)nullptr, mpad, d_items);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// type / m describe the whole group (the feature tables of a Mercer group must already be built)
+gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem* d_items, int count, int max_n1,
+                                    int max_n2, const double* x2_shared, int n2_shared) {
+  if (count <= 0 || max_n1 <= 0 || max_n2 <= 0) return GP_OK;
+  const bool big = (int64_t)max_n1 * max_n2 >= (1 << 20);
+  GpTimerScope ts(h, !big ? GP_TIMER_SMALL_GEMM : (gp_kern_is_mercer(type) ? GP_TIMER_KUF_BUILD_SM : GP_TIMER_KUF_BUILD));
+  DevKern k0{type, m, nullptr};
+  if (gp_kern_is_mercer(type)) {
+    if (m < 1 || m > 32) return gp_fail(h, GP_ERR_UNSUPPORTED, "num_partials must be in [1, 32]");
+    dim3 grid((max_n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
+#define COV_MERCER_ITEMS(MP) launch_mercer<MP>(h, grid, k0, nullptr, 0, x2_shared, n2_shared, nullptr, 0, 0, 0.0, nullptr, nullptr, 0, d_items)
+    switch (sm_mpad(m)) {
+      case 4: COV_MERCER_ITEMS(4); break;
+      case 8: COV_MERCER_ITEMS(8); break;
+      case 12: COV_MERCER_ITEMS(12); break;
+      case 16: COV_MERCER_ITEMS(16); break;
+      case 20: COV_MERCER_ITEMS(20); break;
+      case 24: COV_MERCER_ITEMS(24); break;
+      case 28: COV_MERCER_ITEMS(28); break;
+      default: COV_MERCER_ITEMS(32); break;
+    }
+#undef COV_MERCER_ITEMS
+  } else if (gp_kern_is_broadcast(type)) {
+    dim3 grid((max_n2 + COV_THREADS - 1) / COV_THREADS, (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
+    hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k0, (const double*)nullptr, 0,
+                       x2_shared, n2_shared, (double*)nullptr, (int64_t)0, 0, 0.0, (const double*)nullptr,
+                       (const double*)nullptr, 0, d_items);
+  } else {
+    dim3 grid((max_n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
+#define COV_STAT_ITEMS(T) hipLaunchKernelGGL((cov_build_kernel<0, 2, 1, T>), grid, dim3(COV_THREADS), 0, h->stream, k0, \
+                                            (const double*)nullptr, 0, x2_shared, n2_shared, (double*)nullptr,             \
+                                            (int64_t)0, 0, 0.0, (const double*)nullptr, (const double*)nullptr, 0, d_items)
+    switch (type) {
+      case GP_KERN_MATERN12: COV_STAT_ITEMS(GP_KERN_MATERN12); break;
+      case GP_KERN_MATERN32: COV_STAT_ITEMS(GP_KERN_MATERN32); break;
+      case GP_KERN_MATERN52: COV_STAT_ITEMS(GP_KERN_MATERN52); break;
+      default: COV_STAT_ITEMS(GP_KERN_RBF); break;
+    }
+#undef COV_STAT_ITEMS
+  }
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
 // (re)build the spectral-mixture feature tables of kernel k for (x1, x2) without building a covariance
 gp_status launch_sm_features(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2, double* feat_ws) {
   if (!gp_kern_is_mercer(k.type)) return GP_OK;
   const int mp = sm_mpad(k.m);
   double* f1 = feat_ws;
   double* f2 = feat_ws + gp_align_up((size_t)2 * mp * n1, 32);
-  hipLaunchKernelGGL(sm_features_kernel, dim3((n1 + 255) / 256, mp), dim3(256), 0, h->stream, k, x1, n1, f1, mp);
+  hipLaunchKernelGGL(sm_features_kernel, dim3((n1 + 255) / 256, mp), dim3(256), 0, h->stream, k, x1, n1, f1, mp, (const FeatItem*)nullptr);
   if (x2 && x2 != x1)
-    hipLaunchKernelGGL(sm_features_kernel, dim3((n2 + 255) / 256, mp), dim3(256), 0, h->stream, k, x2, n2, f2, mp);
+    hipLaunchKernelGGL(sm_features_kernel, dim3((n2 + 255) / 256, mp), dim3(256), 0, h->stream, k, x2, n2, f2, mp, (const FeatItem*)nullptr);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }

@@ -63,6 +63,10 @@ struct CondBatch {
   // offsets of the descriptor arrays inside d_desc
   size_t off_chol_ptrs = 0, off_w_ptrs = 0, off_Ms = 0, off_lds = 0, off_f1 = 0, off_f1u = 0, off_f2 = 0, off_finish = 0;
   bool uploaded = false;
+  // grouped covariance builds (one launch per kernel family)
+  struct Group { int type = 0, m = 0, first = 0, maxM = 0; std::vector<int> members; };
+  std::vector<Group> groups;
+  size_t off_cov_uu = 0, off_cov_uf = 0, off_feat_zuu = 0, off_feat_zuf = 0, off_feat_x = 0;
   // blocked Kuu factorisation (engine.hip: cond_batch_factorize)
   bool blocked = false; int nblk = 0;
   size_t off_blk_mats[8] = {0}, off_blk_w[8] = {0}, off_blk_M[8] = {0}, off_blk_gemm[8][4] = {{0}};
@@ -72,7 +76,7 @@ size_t cond_task_workspace_doubles(int M, int N, int num_partials, bool whiten);
 size_t cond_batch_desc_bytes(int count);
 // carve the per-task buffers out of the arena
 bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten);
-gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten);
+gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitter);
 // run: Kuu -> chol -> W ; Kuf ; A = W Kuf ; (A2 = W^T A) ; Lq^T A ; reductions -> fmean, fvar
 gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter,
                          bool reuse_factor = false);

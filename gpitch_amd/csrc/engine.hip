@@ -48,6 +48,8 @@ size_t cond_batch_desc_bytes(int count) {
   b += gp_align_up(count * sizeof(int), 256) * 2;      // Ms, lds
   b += gp_align_up(count * sizeof(GemmProblem), 256) * 3;
   b += gp_align_up(count * cond_finish_item_bytes(), 256);
+  // grouped covariance builds: Kuu + Kuf items, and z (x2) / x feature items
+  b += 2 * gp_align_up(count * sizeof(CovItem), 256) + 3 * gp_align_up(count * sizeof(FeatItem), 256);
   // blocked Cholesky + inverse (up to CB_MAX_PANELS 128-column panels): per panel 2 pointer arrays, 1 size array,
   // 4 GEMM problem arrays
   b += CB_MAX_PANELS * (2 * gp_align_up(count * sizeof(double*), 256) + gp_align_up(count * sizeof(int), 256) +
@@ -55,7 +57,7 @@ size_t cond_batch_desc_bytes(int count) {
   return b;
 }
 
-gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten) {
+gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitter) {
   const int G = (int)cb.tasks.size();
   const int N = cb.N;
   const int64_t ldN = ldN_of(N);
@@ -104,6 +106,47 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten) {
     const int rb = gemm_rowblocks(t.M, 1);
     cond_finish_fill(fin + g * cond_finish_item_bytes(), t.s1, rb, t.s2, t.q_sqrt ? rb : 0, t.dot, rb, t.kern,
                      t.fmean, t.fvar);
+  }
+  // Grouped covariance builds: the latent GPs are sorted into kernel families (type, padded partial count); each
+  // family's Kuu (and Kuf) matrices are built by ONE launch (48 + 36 launches per step at P = 12 otherwise, which
+  // left the device waiting for the host at the start of every step).
+  {
+    cb.groups.clear();
+    std::vector<int> order;
+    for (int g = 0; g < G; g++) {
+      const CondTask& t = cb.tasks[g];
+      const int key_m = gp_kern_has_partials(t.kern.type) ? t.kern.m : 0;
+      int gi = -1;
+      for (size_t q = 0; q < cb.groups.size(); q++)
+        if (cb.groups[q].type == t.kern.type && cb.groups[q].m == key_m) gi = (int)q;
+      if (gi < 0) { CondBatch::Group ng; ng.type = t.kern.type; ng.m = key_m; cb.groups.push_back(ng); gi = (int)cb.groups.size() - 1; }
+      cb.groups[gi].members.push_back(g);
+    }
+    cb.off_cov_uu = region(G * sizeof(CovItem));
+    cb.off_cov_uf = region(G * sizeof(CovItem));
+    cb.off_feat_zuu = region(G * sizeof(FeatItem));
+    cb.off_feat_zuf = region(G * sizeof(FeatItem));
+    cb.off_feat_x = region(G * sizeof(FeatItem));
+    CovItem* uu = (CovItem*)(cb.h_desc.data() + cb.off_cov_uu);
+    CovItem* uf = (CovItem*)(cb.h_desc.data() + cb.off_cov_uf);
+    FeatItem* fzuu = (FeatItem*)(cb.h_desc.data() + cb.off_feat_zuu);
+    FeatItem* fzuf = (FeatItem*)(cb.h_desc.data() + cb.off_feat_zuf);
+    FeatItem* fx = (FeatItem*)(cb.h_desc.data() + cb.off_feat_x);
+    int pos = 0;
+    for (auto& gr : cb.groups) {
+      gr.first = pos; gr.maxM = 0;
+      for (int g : gr.members) {
+        const CondTask& t = cb.tasks[g];
+        if (t.M > gr.maxM) gr.maxM = t.M;
+        cov_item_fill(&uu[pos], t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat_uu);
+        cov_item_fill(&uf[pos], t.kern, t.z, t.M, nullptr, -1, t.Kuf, ldN, 0, 0.0, t.feat);
+        fzuu[pos] = FeatItem{t.kern, t.z, t.feat_uu, t.M, 0};
+        fzuf[pos] = FeatItem{t.kern, t.z, t.feat, t.M, 0};
+        const int mp = sm_mpad(t.kern.m);
+        fx[pos] = FeatItem{t.kern, nullptr, t.feat ? t.feat + gp_align_up((size_t)2 * mp * t.M, 32) : nullptr, -1, 0};
+        pos++;
+      }
+    }
   }
   // Blocked factorisation of the Kuu batch (M > 256): 128-column panels; the diagonal blocks go to the one-workgroup
   // kernels (batched over the GPs), the O(M^3) panel solve / trailing update / block-row inverse to the batched GEMMs.
@@ -199,7 +242,6 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   const int G = (int)cb.tasks.size();
   if (G == 0 || N <= 0) return GP_OK;
   if (!cb.uploaded || cb.N != N) return gp_fail(h, GP_ERR_BAD_ARG, "conditional batch descriptors not uploaded");
-  const int64_t ldN = ldN_of(N);
   // 1-2. Kuu + jitter I, its Cholesky factor and inverse — skipped when the caller vouches that L and W already hold
   //    the factor of the current parameters (repeated predictions at new inputs, pdgp.py:17-44 predict_windowed).
   //    The factorisation is latency-bound on ~G CUs, so it runs on the handle's helper stream while the main stream
@@ -207,28 +249,42 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   // The host feeds both queues alternately (a Kuu build for the helper stream, a Kuf build for the main stream):
   // issuing all of one stream's launches first left the other queue waiting for the host for ~0.6 ms.
   const bool forked = !reuse_factor && (N >= 4096) && gp_aux_fork(h);
-  hipStream_t aux = h->stream, mainq = forked ? h->main_stream_saved : h->stream;
+  // one launch per kernel family for the Kuu builds (helper stream when forked) ...
+  auto build_kuu = [&]() -> gp_status {
+    for (const auto& gr : cb.groups) {
+      const int cnt = (int)gr.members.size();
+      if (gp_kern_is_mercer(gr.type))
+        GP_CHECK(launch_sm_features_items(h, (const FeatItem*)(cb.d_desc + cb.off_feat_zuu) + gr.first, cnt, gr.maxM,
+                                          sm_mpad(gr.m), nullptr, 0));
+      GP_CHECK(launch_kernel_build_items(h, gr.type, gr.m, (const CovItem*)(cb.d_desc + cb.off_cov_uu) + gr.first, cnt,
+                                         gr.maxM, gr.maxM, nullptr, 0));
+    }
+    return GP_OK;
+  };
+  // ... and for the Kuf strips (main stream): every item shares the frames x
+  auto build_kuf = [&]() -> gp_status {
+    for (const auto& gr : cb.groups) {
+      const int cnt = (int)gr.members.size();
+      if (gp_kern_is_mercer(gr.type)) {
+        const int mp = sm_mpad(gr.m);
+        GP_CHECK(launch_sm_features_items(h, (const FeatItem*)(cb.d_desc + cb.off_feat_zuf) + gr.first, cnt, gr.maxM, mp,
+                                          nullptr, 0));
+        GP_CHECK(launch_sm_features_items(h, (const FeatItem*)(cb.d_desc + cb.off_feat_x) + gr.first, cnt, N, mp, x, N));
+      }
+      GP_CHECK(launch_kernel_build_items(h, gr.type, gr.m, (const CovItem*)(cb.d_desc + cb.off_cov_uf) + gr.first, cnt,
+                                         gr.maxM, N, x, N));
+    }
+    return GP_OK;
+  };
   gp_status st = GP_OK;
-  for (int g = 0; g < G && st == GP_OK; g++) {
-    const CondTask& t = cb.tasks[g];
-    if (!reuse_factor) {
-      h->stream = aux;
-      st = launch_kernel_build(h, t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat_uu);
-    }
-    if (forked && st == GP_OK) {       // 3. Kuf (main queue), interleaved
-      h->stream = mainq;
-      st = launch_kernel_build(h, t.kern, t.z, t.M, x, N, t.Kuf, ldN, 0, 0.0, t.feat);
-    }
+  if (!reuse_factor) {
+    st = build_kuu();
+    if (st == GP_OK) st = cond_batch_factorize(h, cb);
   }
-  h->stream = aux;
-  if (!reuse_factor && st == GP_OK) st = cond_batch_factorize(h, cb);
   if (forked) { gp_status s2 = gp_aux_end(h); if (st == GP_OK) st = s2; }
   GP_CHECK(st);
-  // 3. Kuf (when it was not interleaved above)
-  for (int g = 0; g < G && !forked; g++) {
-    const CondTask& t = cb.tasks[g];
-    GP_CHECK(launch_kernel_build(h, t.kern, t.z, t.M, x, N, t.Kuf, ldN, 0, 0.0, t.feat));
-  }
+  // 3. Kuf
+  GP_CHECK(build_kuf());
   GP_CHECK(gp_aux_join(h));
   // 4. A = W Kuf (+ column reductions)
   {

@@ -210,7 +210,7 @@ static gp_status pdgp_bind(gp_pdgp_plan p, const double* params, const double* x
     t.fvar = fvar + (size_t)g * n;
   }
   p->cb.N = n;
-  GP_CHECK(cond_batch_upload(h, p->cb, p->whiten != 0));
+  GP_CHECK(cond_batch_upload(h, p->cb, p->whiten != 0, p->jitter));
   // KL items
   p->h_misc.assign(p->misc_bytes, 0);
   p->off_kl_items = 0;
