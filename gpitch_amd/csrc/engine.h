@@ -30,7 +30,8 @@ gp_status launch_addvec_batched(gp_handle h, const GemmProblem* d_probs, int bat
 gp_status launch_tril_add_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM);
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
                                 const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
-                                const double* feat, double* partials, int* nparts, double* gz_partials);
+                                const double* feat, double* partials, int* nparts, double* gz_partials,
+                                const double* kvals = nullptr, int64_t ldk = 0);
 gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, int nparts, const double* gv_sum,
                               double* g_theta, const double* gz_partials, int ncolblocks, int n1, double* g_z);
 int hyper_num_sums(int m);
