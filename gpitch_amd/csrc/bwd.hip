@@ -14,6 +14,7 @@
 // analytic kernel derivatives, evaluated on the fly.
 #include "pdgp_plan.h"
 #include <string.h>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // small batched vector / matrix kernels (problem fields reused; see each kernel)
@@ -129,6 +130,11 @@ gp_status launch_matvec_batched(gp_handle h, const GemmProblem* d, int batch, in
 #define HY_ROWS 32
 
 int hyper_num_sums(int m) { return 2 + 2 * m; }
+size_t hyper_kuf_records(int N, int M) {
+  const size_t generic = ((size_t)(N + HY_THREADS - 1) / HY_THREADS + 1) * ((size_t)(M + HY_ROWS - 1) / HY_ROWS + 1);
+  const size_t mfma = (size_t)(N + 63) / 64 + 1;       // hyper_sm_mfma_kernel: one record per 64 columns
+  return generic > mfma ? generic : mfma;
+}
 
 // MPAD = spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded, so the
 // inner loop carries no guards); SM = Mercer Matern-1/2 SM kernel; GZ = also produce the inducing-input gradient.
@@ -427,6 +433,150 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_sm_kuf_kernel(DevKern k, con
   }
 }
 
+// Matrix-core form of the same Kuf-side contraction.  With c_ij = w_ij var phi(r_ij) and d_ij = c_ij (z_i - x_j), the
+// per-partial sums are two small GEMMs over the inducing rows,
+//     PE[f][j] = sum_i Zf[i][f] c_ij ,   PD[f][j] = sum_i Zf[i][f] d_ij        (Zf = [cos | sin] row features, 2m wide)
+// followed by a dot with the column features.  The float64 MFMA has the same peak as the float64 VALU, so this is
+// not about flops: it takes the 4 x 2m multiply-adds per entry and — more to the point — the broadcast LDS reads of
+// the row features off the vector pipe (each A fragment is read once per 64 entries).  One workgroup owns 64
+// columns (16 per wave) and walks ALL rows, so it leaves a single partial record.
+#define HYM_ROWS 32        // rows staged in LDS per chunk
+template <int MPAD>
+__global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const double* __restrict__ x1, int n1,
+                                                            const double* __restrict__ x2, int n2,
+                                                            const double* __restrict__ G, int64_t ldg,
+                                                            const double* __restrict__ alpha,
+                                                            const double* __restrict__ gm,
+                                                            const double* __restrict__ Kuf, int64_t ldk,
+                                                            const double* __restrict__ f1,
+                                                            const double* __restrict__ f2,
+                                                            double* __restrict__ partials) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int NF = 2 * MPAD;                 // features per row: cos block, then sin block
+  constexpr int NT = (NF + 15) / 16;           // 16-row MFMA tiles of the feature dimension
+  constexpr int FS = NT * 16 + 1;              // LDS row stride (odd: the 4 rows of a k-step hit different banks)
+  __shared__ double zf[HYM_ROWS * FS];         // row features of the current chunk (zero-padded to NT * 16)
+  __shared__ double rowx[HYM_ROWS], rowa[HYM_ROWS], rowal[HYM_ROWS];
+  __shared__ double etab[GP_EXP_TAB];
+  __shared__ double red[4][2 + 2 * 32];
+  gp_exp_tab_init(etab);
+  const double* th = k.theta;
+  const double var = th[0], ls = th[1];
+  const int m = k.m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kq = lane >> 4;
+  const int j = (blockIdx.x * 4 + wave) * 16 + lc;       // this lane's column
+  const bool live = (j < n2);
+  const int jc = live ? j : n2 - 1;
+  const double xb = x2[jc];
+  const double bsc = xb / ls, bb = __dmul_rn(bsc, bsc);
+  const double gmj = live ? gm[jc] : 0.0;
+  const double inv_ls = 1.0 / ls;
+  const bool m12 = (k.type == GP_KERN_MERCER_MATERN12SM);
+  d4 accE[NT], accD[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) { accE[t] = d4{0.0, 0.0, 0.0, 0.0}; accD[t] = d4{0.0, 0.0, 0.0, 0.0}; }
+  double acc_v = 0.0, acc_l = 0.0;
+  // The global operands of a chunk (this lane's 8 entries of G and Kuf) are fetched one chunk AHEAD: a dependent load
+  // per k-step left every wave waiting out a full HBM round trip eight times per chunk (the kernel ran at the same
+  // speed whether the partial sums were done on the VALU or on the matrix cores: it was latency-bound).
+  constexpr int KS = HYM_ROWS / 4;
+  double gw[KS], kvv[KS], gw_n[KS], kv_n[KS];
+  auto fetch = [&](int r0, double* g, double* kk) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int i = r0 + ks * 4 + kq;
+      const bool on = live && (i < n1);
+      g[ks] = on ? G[(int64_t)i * ldg + j] : 0.0;
+      kk[ks] = on ? Kuf[(int64_t)i * ldk + j] : 0.0;
+    }
+  };
+  fetch(0, gw, kvv);
+  for (int r0 = 0; r0 < n1; r0 += HYM_ROWS) {
+    __syncthreads();     // the previous chunk's fragments have been read
+    for (int t = tid; t < HYM_ROWS * NT * 16; t += 256) {
+      const int ii = t / (NT * 16), f = t % (NT * 16);
+      zf[ii * FS + f] = (r0 + ii < n1 && f < NF) ? f1[(size_t)f * n1 + r0 + ii] : 0.0;
+    }
+    if (tid < HYM_ROWS) {
+      const bool ok = (r0 + tid < n1);
+      const double xv = ok ? x1[r0 + tid] : 0.0;
+      rowx[tid] = xv; rowa[tid] = xv / ls; rowal[tid] = ok ? alpha[r0 + tid] : 0.0;
+    }
+    fetch(r0 + HYM_ROWS, gw_n, kv_n);      // next chunk (all-false predicates past the last row)
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int li = ks * 4 + kq;             // row of this lane's B entry inside the chunk
+      const int i = r0 + li;
+      const bool on = live && (i < n1);
+      const double w = on ? fma(rowal[li], gmj, gw[ks]) : 0.0;
+      const double kv = on ? kvv[ks] : 0.0;
+      const double a = rowa[li], aa = __dmul_rn(a, a);
+      const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, bsc), aa), bb);
+      const double r = gp_sqrt_pos(__dadd_rn(r2, 1e-12));
+      double E, nratio;   // phi(r) and -phi'(r)/phi(r)
+      if (m12) { E = gp_exp_neg(-r, etab); nratio = 1.0; }
+      else {
+        const double s5 = 2.23606797749979, poly = 1.0 + s5 * r + (5.0 / 3.0) * r * r;
+        E = poly * gp_exp_neg(-s5 * r, etab);
+        nratio = (5.0 / 3.0) * r * (1.0 + s5 * r) / poly;
+      }
+      const double wvE = w * var * E, wd = wvE * (rowx[li] - xb);
+      const double wk = w * kv;
+      acc_v += wk;
+      acc_l = fma(wk * nratio, r2 * inv_ls / r, acc_l);
+      // A fragment of tile t: A[f = 16 t + lc][k = kq] = zf[row ks*4 + kq][16 t + lc]
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const double af = zf[li * FS + t * 16 + lc];
+        accE[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, wvE, accE[t], 0, 0, 0);
+        accD[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, wd, accD[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) { gw[ks] = gw_n[ks]; kvv[ks] = kv_n[ks]; }
+  }
+  // accumulator element r of tile t: feature f = 16 t + kq + 4 r, column j (this lane's).  Dot with the column
+  // features: SE[f] = sum_j f2[f][j] PE[f][j];  SD[f] = sum_j f2[partner(f)][j] PD[f][j], partner = the sin (cos)
+  // feature of the same partial.  Then  d/d e_q ~ SE[q] + SE[MPAD + q],  d/d f_q ~ SD[MPAD + q] - SD[q].
+  const int ns = 2 + 2 * m;
+  auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+  for (int t = lane; t < ns; t += 64) red[wave][t] = 0.0;
+  const double rv = wred(acc_v / var), rl = wred(acc_l);
+  if (lane == 0) { red[wave][0] = rv; red[wave][1] = rl; }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int f = 16 * t + kq + 4 * r;
+      double se = 0.0, sd = 0.0;
+      if (f < NF && live) {
+        const int fp = (f < MPAD) ? f + MPAD : f - MPAD;
+        se = f2[(size_t)f * n2 + jc] * accE[t][r];
+        sd = f2[(size_t)fp * n2 + jc] * accD[t][r];
+      }
+      // reduce over the 16 columns of this lane group (lanes sharing kq)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); sd += __shfl_xor(sd, o, 64); }
+      if (lc == 0 && f < NF) {
+        const int q = (f < MPAD) ? f : f - MPAD;
+        if (q < m) {
+          // each (wave, feature) pair is written by exactly one lane group; cos and sin halves land in the same slots
+          atomicAdd(&red[wave][2 + q], se / th[2 + q]);
+          atomicAdd(&red[wave][2 + m + q], -6.283185307179586 * ((f < MPAD) ? -sd : sd));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < ns) {
+    const double s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    partials[(int64_t)blockIdx.x * ns + tid] = s;
+  }
+}
+
 // Broadcast-form kernels Matern12sm (matern12_spectral_mixture.py:38-56) and Matern32sm (kernels.py:204-258):
 //   d = x1_i - x2_j + 1e-12,  r = |d|,  K = var * phi(r; ls) * sum_q e_q cos(2 pi f_q r),
 //   phi = exp(-r / ls)  or  (1 + r1) exp(-r1), r1 = sqrt(3) r / ls.
@@ -582,6 +732,25 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
   size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
   if (sm && kvals && !gz_partials && !symmetric && alpha && gm) {
     // Kuf side with the covariance strip still in memory: the separable form (hyper_sm_kuf_kernel)
+    if (getenv("GP_HYPER_VALU") == nullptr) {
+      dim3 gridm((n2 + 63) / 64);
+#define HY_MFMA(MP) hipLaunchKernelGGL((hyper_sm_mfma_kernel<MP>), gridm, dim3(256), 0, h->stream, k, x1, n1, x2, n2, G, ldg, \
+                                       alpha, gm, kvals, ldk, f1, f2, partials)
+      switch (mp) {
+        case 4: HY_MFMA(4); break;
+        case 8: HY_MFMA(8); break;
+        case 12: HY_MFMA(12); break;
+        case 16: HY_MFMA(16); break;
+        case 20: HY_MFMA(20); break;
+        case 24: HY_MFMA(24); break;
+        case 28: HY_MFMA(28); break;
+        default: HY_MFMA(32); break;
+      }
+#undef HY_MFMA
+      GP_HIP_CHECK(h, hipGetLastError());
+      if (nparts) *nparts = gridm.x;
+      return GP_OK;
+    }
     const size_t sh2 = ((size_t)HY_ROWS * 2 * (mp / HYK_QG) + 4 * (size_t)redw) * sizeof(double);
     dim3 grid2((n2 + HY_THREADS * HYK_CPT - 1) / (HY_THREADS * HYK_CPT), grid.y, HYK_QG);
 #define HY_KUF(MP) hipLaunchKernelGGL((hyper_sm_kuf_kernel<MP>), grid2, dim3(HY_THREADS), sh2, h->stream, k, x1, n1, x2, n2, G, \

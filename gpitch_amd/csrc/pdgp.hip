@@ -16,7 +16,7 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
     add(M); add(M); add(M); add((size_t)65 * M);
     const size_t ns = hyper_num_sums(p->gps[g].m);
     const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
-    add(ns * colblocks * rowblocks);
+    add(ns * hyper_kuf_records(p->maxN, (int)M));
     add(ns * ((M + 255) / 256 + 1) * rowblocks);
     add(colblocks * M + ((M + 255) / 256 + 1) * M);
   }
@@ -155,7 +155,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       b.upart = ar.take<double>((size_t)p->nsplit * M);
       const size_t ns = hyper_num_sums(p->gps[g].m);
       const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
-      b.hyp_part = ar.take<double>(ns * colblocks * rowblocks);
+      b.hyp_part = ar.take<double>(ns * hyper_kuf_records(p->maxN, (int)M));
       b.hyp_part_uu = ar.take<double>(ns * ((M + 255) / 256 + 1) * rowblocks);
       b.gz_part = ar.take<double>(colblocks * M + ((M + 255) / 256 + 1) * M);
     }
