@@ -14,7 +14,6 @@
 // analytic kernel derivatives, evaluated on the fly.
 #include "pdgp_plan.h"
 #include <string.h>
-#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // small batched vector / matrix kernels (problem fields reused; see each kernel)
@@ -290,151 +289,11 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
 
 
 // Kuf side of a Mercer spectral-mixture kernel when the covariance values K themselves are still in memory (the
-// forward pass's Kuf strip) and no inducing-input gradient is wanted.  Two identities cut the per-(entry, partial)
-// work from 7 to 4 float64 operations:
-//   sum_q e_q cos(w_q d) = K / (var phi(r))                      (no per-partial cosine sum for the variance /
-//                                                                 lengthscale terms: they are sums of w K ...)
-//   sum_i c_i (zc_iq fxc_q + zs_iq fxs_q) = fxc_q sum_i c_i zc_iq + fxs_q sum_i c_i zs_iq
-//                                                                (the column features leave the row loop)
-// Same grid, partial-record layout and scaling conventions as hyper_contract_kernel.
-// The row features come from LDS as wave-uniform (broadcast) reads, and a broadcast read still moves 64 lanes x 8 B
-// through the LDS return path: with one column per thread the kernel was LDS-bandwidth-bound (cutting its VALU work by
-// 46 % changed nothing).  So each thread carries CPT = 2 adjacent columns, and the partials are dealt to QG = 2
-// workgroup groups (blockIdx.z) to keep the 4 x CPT x MPAD/QG accumulators in registers: 4x less LDS traffic per entry.
-#define HYK_CPT 2
-#define HYK_QG 2
-template <int MPAD>
-__global__ void __launch_bounds__(HY_THREADS) hyper_sm_kuf_kernel(DevKern k, const double* __restrict__ x1, int n1,
-                                                                  const double* __restrict__ x2, int n2,
-                                                                  const double* __restrict__ G, int64_t ldg,
-                                                                  const double* __restrict__ alpha,
-                                                                  const double* __restrict__ gm,
-                                                                  const double* __restrict__ Kuf, int64_t ldk,
-                                                                  const double* __restrict__ f1,
-                                                                  const double* __restrict__ f2,
-                                                                  double* __restrict__ partials) {
-  constexpr int MQ = MPAD / HYK_QG;   // partials per workgroup group (MPAD is a multiple of 4)
-  const int q0 = blockIdx.z * MQ;
-  extern __shared__ double smem[];  // [HY_ROWS][2*MQ] row features of this group | reduction scratch
-  const double* th = k.theta;
-  const double var = th[0], ls = th[1];
-  const int m = k.m;
-  const int j0 = (blockIdx.x * HY_THREADS + threadIdx.x) * HYK_CPT;
-  const int i0 = blockIdx.y * HY_ROWS;
-  const int iend = min(i0 + HY_ROWS, n1);
-  double* fzs = smem;
-  double* red = smem + HY_ROWS * 2 * MQ;
-  __shared__ double etab[GP_EXP_TAB];
-  gp_exp_tab_init(etab);
-  __shared__ double row_a[HY_ROWS];
-  if (threadIdx.x < HY_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / ls : 0.0;
-  for (int t = threadIdx.x; t < HY_ROWS * 2 * MQ; t += HY_THREADS) {
-    int q = t / HY_ROWS, ii = t % HY_ROWS;
-    const int src = (q < MQ) ? (q0 + q) : (MPAD + q0 + q - MQ);     // cosine rows, then sine rows of the table
-    fzs[ii * 2 * MQ + q] = (i0 + ii < n1) ? f1[(size_t)src * n1 + i0 + ii] : 0.0;
-  }
-  __syncthreads();
-  bool live[HYK_CPT];
-  int jc[HYK_CPT];
-  double xb[HYK_CPT], b[HYK_CPT], bb[HYK_CPT], gmj[HYK_CPT];
-#pragma unroll
-  for (int c = 0; c < HYK_CPT; c++) {
-    live[c] = (j0 + c < n2);
-    jc[c] = live[c] ? j0 + c : n2 - 1;
-    xb[c] = x2[jc[c]]; b[c] = xb[c] / ls; bb[c] = __dmul_rn(b[c], b[c]);
-    gmj[c] = live[c] ? gm[jc[c]] : 0.0;
-  }
-  const bool vec = live[HYK_CPT - 1] && ((ldg & 1) == 0) && ((ldk & 1) == 0) && ((((uintptr_t)G) & 15) == 0) &&
-                   ((((uintptr_t)Kuf) & 15) == 0);
-  double Pc[HYK_CPT][MQ], Ps[HYK_CPT][MQ], Rc[HYK_CPT][MQ], Rs[HYK_CPT][MQ];
-#pragma unroll
-  for (int c = 0; c < HYK_CPT; c++)
-#pragma unroll
-    for (int q = 0; q < MQ; q++) { Pc[c][q] = 0.0; Ps[c][q] = 0.0; Rc[c][q] = 0.0; Rs[c][q] = 0.0; }
-  double acc_v = 0.0, acc_l = 0.0;
-  const double inv_ls = 1.0 / ls;
-  const bool m12 = (k.type == GP_KERN_MERCER_MATERN12SM);
-  const bool lead = (blockIdx.z == 0);   // the variance / lengthscale sums do not depend on the partial group
-  for (int i = i0; i < iend; i++) {
-    const double xa = x1[i], al = alpha[i];
-    double gw[HYK_CPT], kv[HYK_CPT];
-    if (vec) {
-      const double2 g2 = *reinterpret_cast<const double2*>(&G[(int64_t)i * ldg + j0]);
-      const double2 k2 = *reinterpret_cast<const double2*>(&Kuf[(int64_t)i * ldk + j0]);
-      gw[0] = g2.x; gw[1] = g2.y; kv[0] = k2.x; kv[1] = k2.y;
-    } else {
-#pragma unroll
-      for (int c = 0; c < HYK_CPT; c++) {
-        gw[c] = live[c] ? G[(int64_t)i * ldg + jc[c]] : 0.0;
-        kv[c] = live[c] ? Kuf[(int64_t)i * ldk + jc[c]] : 0.0;
-      }
-    }
-    const double a = row_a[i - i0], aa = __dmul_rn(a, a);
-    double wvE[HYK_CPT], wd[HYK_CPT];
-#pragma unroll
-    for (int c = 0; c < HYK_CPT; c++) {
-      const double w = live[c] ? fma(al, gmj[c], gw[c]) : 0.0;
-      const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b[c]), aa), bb[c]);
-      const double r = gp_sqrt_pos(__dadd_rn(r2, 1e-12));
-      double E, nratio;   // phi(r) and -phi'(r)/phi(r)
-      if (m12) { E = gp_exp_neg(-r, etab); nratio = 1.0; }
-      else {
-        const double s5 = 2.23606797749979, poly = 1.0 + s5 * r + (5.0 / 3.0) * r * r;
-        E = poly * gp_exp_neg(-s5 * r, etab);
-        nratio = (5.0 / 3.0) * r * (1.0 + s5 * r) / poly;
-      }
-      wvE[c] = w * var * E; wd[c] = wvE[c] * (xa - xb[c]);
-      if (lead) {
-        const double wk = w * kv[c];
-        acc_v += wk;                                             // = w * phi * S * var, divided by var at the end
-        acc_l = fma(wk * nratio, r2 * inv_ls / r, acc_l);       // -w var phi' S * r2 / (r ls)
-      }
-    }
-    const double* fz = &fzs[(i - i0) * 2 * MQ];
-#pragma unroll
-    for (int q = 0; q < MQ; q++) {
-      const double zc = fz[q], zs = fz[q + MQ];
-#pragma unroll
-      for (int c = 0; c < HYK_CPT; c++) {
-        Pc[c][q] = fma(wvE[c], zc, Pc[c][q]);
-        Ps[c][q] = fma(wvE[c], zs, Ps[c][q]);
-        Rc[c][q] = fma(wd[c], zc, Rc[c][q]);
-        Rs[c][q] = fma(wd[c], zs, Rs[c][q]);
-      }
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ns = 2 + 2 * m;
-  auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
-  for (int t = lane; t < ns; t += 64) red[wave * ns + t] = 0.0;   // the other group's slots of this record stay zero
-  double rv = wred(acc_v / var), rl = wred(acc_l);
-  if (lane == 0) { red[wave * ns + 0] = rv; red[wave * ns + 1] = rl; }
-#pragma unroll
-  for (int q = 0; q < MQ; q++) {
-    double se = 0.0, sf = 0.0;
-#pragma unroll
-    for (int c = 0; c < HYK_CPT; c++) {
-      const double fxc = f2[(size_t)(q0 + q) * n2 + jc[c]], fxs = f2[(size_t)(q0 + q + MPAD) * n2 + jc[c]];
-      se += fma(fxc, Pc[c][q], fxs * Ps[c][q]);              // sum w var phi e_q cos
-      sf += fma(fxc, Rs[c][q], -fxs * Rc[c][q]);             // sum w var phi d e_q sin
-    }
-    const double re = wred(se), rf = wred(sf);
-    if (lane == 0 && q0 + q < m) {
-      red[wave * ns + 2 + q0 + q] = re / th[2 + q0 + q];
-      red[wave * ns + 2 + m + q0 + q] = -6.283185307179586 * rf;
-    }
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < ns) {
-    const int t = threadIdx.x;
-    const double s = (red[0 * ns + t] + red[1 * ns + t]) + (red[2 * ns + t] + red[3 * ns + t]);
-    const int64_t rec = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    partials[rec * ns + t] = s;
-  }
-}
-
-// Matrix-core form of the same Kuf-side contraction.  With c_ij = w_ij var phi(r_ij) and d_ij = c_ij (z_i - x_j), the
-// per-partial sums are two small GEMMs over the inducing rows,
+// forward pass's Kuf strip) and no inducing-input gradient is wanted.  Two identities remove the per-entry cosine
+// sums:   sum_q e_q cos(w_q d) = K / (var phi(r))   (the variance / lengthscale terms become sums of w K ...), and
+//         sum_i c_i (zc_iq fxc_q + zs_iq fxs_q) = fxc_q sum_i c_i zc_iq + fxs_q sum_i c_i zs_iq
+// (the column features leave the row loop).  With c_ij = w_ij var phi(r_ij) and d_ij = c_ij (z_i - x_j), the
+// per-partial sums are then two small GEMMs over the inducing rows,
 //     PE[f][j] = sum_i Zf[i][f] c_ij ,   PD[f][j] = sum_i Zf[i][f] d_ij        (Zf = [cos | sin] row features, 2m wide)
 // followed by a dot with the column features.  The float64 MFMA has the same peak as the float64 VALU, so this is
 // not about flops: it takes the 4 x 2m multiply-adds per entry and — more to the point — the broadcast LDS reads of
@@ -731,43 +590,23 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
   const int redw = ns > HY_ROWS ? ns : HY_ROWS;
   size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
   if (sm && kvals && !gz_partials && !symmetric && alpha && gm) {
-    // Kuf side with the covariance strip still in memory: the separable form (hyper_sm_kuf_kernel)
-    if (getenv("GP_HYPER_VALU") == nullptr) {
-      dim3 gridm((n2 + 63) / 64);
+    // Kuf side with the covariance strip still in memory: the matrix-core form (hyper_sm_mfma_kernel)
+    dim3 gridm((n2 + 63) / 64);
 #define HY_MFMA(MP) hipLaunchKernelGGL((hyper_sm_mfma_kernel<MP>), gridm, dim3(256), 0, h->stream, k, x1, n1, x2, n2, G, ldg, \
-                                       alpha, gm, kvals, ldk, f1, f2, partials)
-      switch (mp) {
-        case 4: HY_MFMA(4); break;
-        case 8: HY_MFMA(8); break;
-        case 12: HY_MFMA(12); break;
-        case 16: HY_MFMA(16); break;
-        case 20: HY_MFMA(20); break;
-        case 24: HY_MFMA(24); break;
-        case 28: HY_MFMA(28); break;
-        default: HY_MFMA(32); break;
-      }
-#undef HY_MFMA
-      GP_HIP_CHECK(h, hipGetLastError());
-      if (nparts) *nparts = gridm.x;
-      return GP_OK;
-    }
-    const size_t sh2 = ((size_t)HY_ROWS * 2 * (mp / HYK_QG) + 4 * (size_t)redw) * sizeof(double);
-    dim3 grid2((n2 + HY_THREADS * HYK_CPT - 1) / (HY_THREADS * HYK_CPT), grid.y, HYK_QG);
-#define HY_KUF(MP) hipLaunchKernelGGL((hyper_sm_kuf_kernel<MP>), grid2, dim3(HY_THREADS), sh2, h->stream, k, x1, n1, x2, n2, G, \
-                                      ldg, alpha, gm, kvals, ldk, f1, f2, partials)
+                                     alpha, gm, kvals, ldk, f1, f2, partials)
     switch (mp) {
-      case 4: HY_KUF(4); break;
-      case 8: HY_KUF(8); break;
-      case 12: HY_KUF(12); break;
-      case 16: HY_KUF(16); break;
-      case 20: HY_KUF(20); break;
-      case 24: HY_KUF(24); break;
-      case 28: HY_KUF(28); break;
-      default: HY_KUF(32); break;
+      case 4: HY_MFMA(4); break;
+      case 8: HY_MFMA(8); break;
+      case 12: HY_MFMA(12); break;
+      case 16: HY_MFMA(16); break;
+      case 20: HY_MFMA(20); break;
+      case 24: HY_MFMA(24); break;
+      case 28: HY_MFMA(28); break;
+      default: HY_MFMA(32); break;
     }
-#undef HY_KUF
+#undef HY_MFMA
     GP_HIP_CHECK(h, hipGetLastError());
-    if (nparts) *nparts = grid2.x * grid2.y * grid2.z;
+    if (nparts) *nparts = gridm.x;
     return GP_OK;
   }
 #define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials

@@ -293,6 +293,76 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
   return GP_OK;
 }
 
+// Matrix-core form of the Mercer Kuf strip.  K[i][j] = var phi(r_ij) * sum_f Zf[i][f] Xf[j][f] with 2m features per
+// point: the feature dot product is a (rows x 2m) x (2m x cols) GEMM.  The float64 MFMA peak equals the float64 VALU
+// peak, so this is not about flops: in the VALU kernel every row feature reaches the lanes as a broadcast LDS read
+// (64 lanes x 8 B through the LDS return path per value) and that path co-limits it; here a feature fragment is read
+// once per 16 x 16 outputs and the vector pipe keeps only the envelope (sqrt + exp).  One workgroup owns 64 columns
+// (16 per wave) and walks all rows; Kuf strips only (no diagonal, no accumulation); blockIdx.y = item.
+#define CVM_ROWS 32
+template <int MPAD, int ENV>
+__global__ void __launch_bounds__(256) cov_mercer_mfma_kernel(const CovItem* __restrict__ items,
+                                                              const double* __restrict__ x2s, int n2s) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int NF = 2 * MPAD;          // features per point (a multiple of 8)
+  constexpr int FS = NF + 1;            // odd LDS stride
+  const CovItem it = items[blockIdx.y];
+  const double* __restrict__ x1 = it.x1;
+  const int n1 = it.n1;
+  const double* __restrict__ x2 = (it.n2 >= 0) ? it.x2 : x2s;
+  const int n2 = (it.n2 >= 0) ? it.n2 : n2s;
+  double* __restrict__ out = it.out;
+  const int64_t ld = it.ld;
+  __shared__ double xf[64 * FS];            // column features of this workgroup's 64 columns
+  __shared__ double zf[CVM_ROWS * FS];      // row features of the current 32-row chunk
+  __shared__ double rowa[CVM_ROWS];
+  __shared__ double etab[GP_EXP_TAB];
+  gp_exp_tab_init(etab);
+  const double* th = it.k.theta;
+  const double var = th[0], ls = th[1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kq = lane >> 4;
+  const int jb = blockIdx.x * 64;
+  if (jb >= n2) return;
+  for (int t = tid; t < 64 * NF; t += 256) {
+    const int f = t / 64, c = t % 64;      // consecutive threads read consecutive points of one feature row
+    xf[c * FS + f] = (jb + c < n2) ? it.f2[(size_t)f * n2 + jb + c] : 0.0;
+  }
+  const int j = jb + wave * 16 + lc;
+  const bool live = (j < n2);
+  const double bsc = x2[live ? j : n2 - 1] / ls, bb = __dmul_rn(bsc, bsc);
+  for (int r0 = 0; r0 < n1; r0 += CVM_ROWS) {
+    __syncthreads();
+    for (int t = tid; t < CVM_ROWS * NF; t += 256) {
+      const int f = t / CVM_ROWS, ii = t % CVM_ROWS;
+      zf[ii * FS + f] = (r0 + ii < n1) ? it.f1[(size_t)f * n1 + r0 + ii] : 0.0;
+    }
+    if (tid < CVM_ROWS) rowa[tid] = (r0 + tid < n1) ? x1[r0 + tid] / ls : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < CVM_ROWS / 16; rt++) {
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < NF / 4; s++) {
+        const double af = zf[(rt * 16 + lc) * FS + 4 * s + kq];            // A[i = lc][k = kq]
+        const double bf = xf[(wave * 16 + lc) * FS + 4 * s + kq];           // B[k = kq][j = lc]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+      }
+      // element r of acc: row 16 rt + kq + 4 r, column lc
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int li = rt * 16 + kq + 4 * r, i = r0 + li;
+        const double a = rowa[li], aa = __dmul_rn(a, a);
+        const double rr = gp_sqrt_pos(__dadd_rn(__dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, bsc), aa), bb), 1e-12));
+        double env;
+        if (ENV == 0) env = gp_exp_neg(-rr, etab);
+        else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
+        if (live && i < n1) out[(size_t)i * ld + j] = var * env * acc[r];
+      }
+    }
+  }
+}
+
 // ---- grouped launches: all matrices of one kernel family (same type, same padded partial count) in one launch ----
 void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const double* x2, int n2, double* out, int64_t ld,
                    int accumulate, double diag_add, double* feat_ws) {
@@ -326,6 +396,30 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
   DevKern k0{type, m, nullptr};
   if (gp_kern_is_mercer(type)) {
     if (m < 1 || m > 32) return gp_fail(h, GP_ERR_UNSUPPORTED, "num_partials must be in [1, 32]");
+    if (x2_shared && big) {
+      // Kuf strips (shared frames, nothing accumulated, no diagonal): matrix-core form
+      dim3 gm((max_n2 + 63) / 64, count);
+#define COV_MFMA(MP)                                                                                                   \
+      do {                                                                                                             \
+        if (type == GP_KERN_MERCER_MATERN12SM)                                                                         \
+          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared); \
+        else                                                                                                           \
+          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 2>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared); \
+      } while (0)
+      switch (sm_mpad(m)) {
+        case 4: COV_MFMA(4); break;
+        case 8: COV_MFMA(8); break;
+        case 12: COV_MFMA(12); break;
+        case 16: COV_MFMA(16); break;
+        case 20: COV_MFMA(20); break;
+        case 24: COV_MFMA(24); break;
+        case 28: COV_MFMA(28); break;
+        default: COV_MFMA(32); break;
+      }
+#undef COV_MFMA
+      GP_HIP_CHECK(h, hipGetLastError());
+      return GP_OK;
+    }
     dim3 grid((max_n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
 #define COV_MERCER_ITEMS(MP) launch_mercer<MP>(h, grid, k0, nullptr, 0, x2_shared, n2_shared, nullptr, 0, 0, 0.0, nullptr, nullptr, 0, d_items)
     switch (sm_mpad(m)) {
