@@ -790,21 +790,25 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     GP_CHECK(launch_gemm_batched(h, D(S_QW_L), G, maxM, maxM, f));
     GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl2, G));   // accumulates -dKL/dq' into (g', G')
   }
-  // H = A diag(2 gv) A^T  (symmetric, split-K over the frames)
-  GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
-  // (u = A gm and grad q_mu += u are fused into the split-K product above)
+  const int nK = p->nK;   // latent GPs whose kernel hyper-parameters / inducing inputs are trainable
   // sum_n gv  (kdiag term)
   hipLaunchKernelGGL(batched_sum_kernel, dim3(G), dim3(256), 0, h->stream, p->gFvar, (int64_t)n, n, p->bw[0].gvsum);
   GP_HIP_CHECK(h, hipGetLastError());
-  // grad q_sqrt += tril(H Lq)
-  f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
-  GP_CHECK(launch_gemm_batched(h, D(S_HLQ), G, maxM, maxM, f));
-  const int nK = p->nK;   // latent GPs whose kernel hyper-parameters / inducing inputs are trainable
-  if (nK > 0) {
-    // E = Lq Lq^T - I
-    f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
-    GP_CHECK(launch_gemm_batched(h, D(S_E), nK, maxM, maxM, f));
-    GP_CHECK(launch_sub_identity_batched(h, D(S_E), nK, maxM));
+  // Everything that hangs off H = A diag(2 gv) A^T — grad q_sqrt, Wbar, the whole Kuu side — is independent of the
+  // Kuf_bar product, which needs only R = W^T (Lq Lq^T - I) and alpha = W^T q_mu.  With early_fork the H chain
+  // (the split-K product included) goes to the helper stream and the main stream starts Kuf_bar right away.
+  const bool early_fork = white && nK > 0 && n >= 4096 && p->overlap >= 2;
+  auto h_chain_head = [&]() -> gp_status {
+    GemmFlags f;
+    // H = A diag(2 gv) A^T  (symmetric, split-K over the frames); u = A gm and grad q_mu += u are fused into it
+    GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
+    // grad q_sqrt += tril(H Lq)
+    f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
+    GP_CHECK(launch_gemm_batched(h, D(S_HLQ), G, maxM, maxM, f));
+    return GP_OK;
+  };
+  auto wbar_chain = [&]() -> gp_status {
+    GemmFlags f;
     // T1 = E H
     f = GemmFlags();
     GP_CHECK(launch_gemm_batched(h, D(S_EH), nK, maxM, maxM, f));
@@ -818,6 +822,15 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.beta = 1.0;
       GP_CHECK(launch_gemm_batched(h, D(S_WB_L), nK, maxM, maxM, f));
     }
+    return GP_OK;
+  };
+  if (!early_fork) GP_CHECK(h_chain_head());
+  if (nK > 0) {
+    // E = Lq Lq^T - I
+    f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
+    GP_CHECK(launch_gemm_batched(h, D(S_E), nK, maxM, maxM, f));
+    GP_CHECK(launch_sub_identity_batched(h, D(S_E), nK, maxM));
+    if (!early_fork) GP_CHECK(wbar_chain());
     // R = W^T E ; alpha = W^T mu
     f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
     GP_CHECK(launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f));
@@ -825,7 +838,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     // From here two independent chains remain: the Kuf side (the big Kuf_bar product and its contraction with
     // dK/dtheta over all frames) and the Kuu side (the Cholesky adjoint, six M x M products, and its contraction
     // over M x M).  The Kuu side is ~1.4 ms of small launches: it runs on the helper stream underneath Kuf_bar.
-    const bool forked = (n >= 4096) && gp_aux_fork(h);
+    const bool forked = (n >= 4096) && p->overlap >= 1 && gp_aux_fork(h);
     gp_status st = GP_OK;
     std::vector<int> np_uu(p->G, 0);
     auto kuu_side = [&]() -> gp_status {
@@ -854,8 +867,9 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       }
       return GP_OK;
     };
-    if (forked) {            // helper stream: Kuu side
-      st = kuu_side();
+    if (forked) {            // helper stream: [H chain when forked early,] Kuu side
+      if (early_fork) { st = h_chain_head(); if (st == GP_OK) st = wbar_chain(); }
+      if (st == GP_OK) st = kuu_side();
       gp_status s2 = gp_aux_end(h);
       if (st == GP_OK) st = s2;
       GP_CHECK(st);
@@ -863,7 +877,10 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     // Kuf_bar (dense part) = R (A diag(2 gv))
     f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
     GP_CHECK(launch_gemm_batched(h, D(S_G), nK, maxM, n, f));
-    if (!forked) GP_CHECK(kuu_side());
+    if (!forked) {
+      if (early_fork) { GP_CHECK(h_chain_head()); GP_CHECK(wbar_chain()); }   // (no helper stream to be had)
+      GP_CHECK(kuu_side());
+    }
     if (!white) {
       GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));
       f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;

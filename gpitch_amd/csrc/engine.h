@@ -66,6 +66,7 @@ struct CondBatch {
   // offsets of the descriptor arrays inside d_desc
   size_t off_chol_ptrs = 0, off_w_ptrs = 0, off_Ms = 0, off_lds = 0, off_f1 = 0, off_f1u = 0, off_f2 = 0, off_finish = 0;
   bool uploaded = false;
+  bool overlap = true;    // run the Kuu factorisation on the handle's helper stream next to the Kuf builds
   // grouped covariance builds (one launch per kernel family)
   struct Group { int type = 0, m = 0, first = 0, maxM = 0; std::vector<int> members; };
   std::vector<Group> groups;

@@ -248,7 +248,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   //    builds the Kuf strips (HBM / VALU-bound on all CUs); they meet again before A = W Kuf.
   // The host feeds both queues alternately (a Kuu build for the helper stream, a Kuf build for the main stream):
   // issuing all of one stream's launches first left the other queue waiting for the host for ~0.6 ms.
-  const bool forked = !reuse_factor && (N >= 4096) && gp_aux_fork(h);
+  const bool forked = !reuse_factor && (N >= 4096) && cb.overlap && gp_aux_fork(h);
   // one launch per kernel family for the Kuu builds (helper stream when forked) ...
   auto build_kuu = [&]() -> gp_status {
     for (const auto& gr : cb.groups) {

@@ -78,6 +78,12 @@ gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, 
   }
   return GP_OK;
 }
+gp_status gp_pdgp_set_overlap(gp_pdgp_plan p, int32_t level) {
+  if (!p || level < 0 || level > 2) return GP_ERR_BAD_ARG;
+  p->overlap = level;
+  p->cb.overlap = (level >= 1);
+  return GP_OK;
+}
 int64_t gp_pdgp_num_params(gp_pdgp_plan p) { return p ? p->nparams : 0; }
 
 gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t* off_z, int64_t* off_qmu,

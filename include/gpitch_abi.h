@@ -168,6 +168,15 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes);
  * Skipped entries of the gradient vector are left at zero.  Default: everything needed. */
 gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, int32_t need_z);
 
+/* How much of a step may run on the handle's internal helper stream (same results, different schedule):
+ *   0  everything on the handle's stream, in order;
+ *   1  forward: Kuu builds + Cholesky / inverse next to the Kuf builds; backward: the Kuu-side chain (Cholesky
+ *      adjoint and its contraction) underneath the Kuf_bar product;
+ *   2  (default) additionally the H = A diag(2 gv) A^T chain next to Kuf_bar — the two largest backward products then
+ *      share the device, so each one's own launch takes longer while the step gets shorter.
+ * Batches below 4096 frames always run on one stream. */
+gp_status gp_pdgp_set_overlap(gp_pdgp_plan p, int32_t level);
+
 /* Pdgp.build_likelihood (pdgp.py:133-170) on the batch (x, y) of n frames:
  *   elbo = (num_data / n) * sum_n varexp_n - KL.   elbo_dev points to TWO device doubles: [0] the ELBO, [1] the
  * summed KL term (Pdgp.build_prior_kl, pdgp.py:113-131).  When

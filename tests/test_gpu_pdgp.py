@@ -463,3 +463,29 @@ def test_blocked_kuu_factorisation_with_partial_last_panel(gp_handle):
     from oracle import gpflow05 as orc
     rm, rv = orc.conditional(xs, prob["za"][0], prob["kern_act"][0], prob["q_mu_act"][0], prob["q_sqrt_act"][0], whiten=True)
     np.testing.assert_allclose(ma[0], rm, rtol=0, atol=1e-6 * np.abs(rm).max())
+
+
+def test_overlap_levels_give_identical_results(gp_handle):
+    """gp_pdgp_set_overlap changes only the schedule (helper-stream fork / join points); the ELBO and every gradient
+    entry must come out bit for bit the same at every level (batches of >= 4096 frames are the ones that fork)."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(4096, 48, 2, num_partials=3, seed=13)
+    ref = None
+    for level in (0, 1, 2, 1, 0):
+        m = pdgp_from_problem(prob, handle=gp_handle)
+        m.za.fixed = True
+        m.zc.fixed = True
+        m._pack()
+        gp_handle.check(gp_handle.lib.gp_pdgp_set_overlap(m._plan, level))
+        vals = []
+        for _ in range(2):                      # the second evaluation (a fresh frame permutation, identically seeded in
+            f = m._elbo(True)                   # every model) reuses descriptors and streams
+            vals.append((f, m._grad.cpu().numpy().copy()))
+        if ref is None:
+            ref = vals
+        else:
+            for a, b in zip(vals, ref):
+                assert a[0] == b[0], level
+                assert np.array_equal(a[1], b[1]), level
+    with pytest.raises(Exception):
+        gp_handle.check(gp_handle.lib.gp_pdgp_set_overlap(m._plan, 3))
