@@ -40,6 +40,17 @@ bool gp_aux_fork(gp_handle h) {
   return true;
 }
 
+bool gp_aux_resume(gp_handle h) {
+  if (!h->aux_pending || h->aux_active || !h->aux_stream) return false;
+  if (!h->ev_mid && hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming) != hipSuccess) { h->ev_mid = nullptr; return false; }
+  if (hipEventRecord(h->ev_mid, h->stream) != hipSuccess) return false;
+  if (hipStreamWaitEvent(h->aux_stream, h->ev_mid, 0) != hipSuccess) return false;
+  h->main_stream_saved = h->stream;
+  h->stream = h->aux_stream;
+  h->aux_active = true;
+  return true;
+}
+
 gp_status gp_aux_end(gp_handle h) {
   if (!h->aux_active) return GP_OK;
   hipError_t e = hipEventRecord(h->ev_join, h->aux_stream);
@@ -104,6 +115,7 @@ gp_status gp_destroy(gp_handle h) {
   for (auto& r : h->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->d_status) (void)hipFree(h->d_status);

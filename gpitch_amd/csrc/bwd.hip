@@ -886,21 +886,47 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;
       GP_CHECK(launch_gemm_batched(h, D(S_GQ_L), G, maxM, maxM, f));
     }
-    // Kuf side of the hyper-parameter and inducing-input gradients
-    for (int g : p->kgps) {
+    // Kuf side of the hyper-parameter and inducing-input gradients.  The stationary kernels' contractions are short
+    // and latency-bound: with a fork pending they go to the helper stream (which is idle by now) while the main stream
+    // does the spectral-mixture ones; their finish kernels follow the join.
+    std::vector<int> np_uf(p->G, 0);
+    auto kuf_contract = [&](int g) -> gp_status {
       const PdgpGP& q = p->gps[g];
       const CondTask& t = p->cb.tasks[g];
       const BwdBufs& bb = p->bw[g];
       const double* z = params + q.off_z;
       const double* gm = p->gFmu + (size_t)g * n;
-      int np_uf = 0;
+      double* gz_uf = q.need_z ? bb.gz_part : nullptr;
+      return launch_hyper_contract(h, t.kern, z, q.M, x, n, bb.G, ldN, bb.alpha, gm, 0, t.feat, bb.hyp_part, &np_uf[g], gz_uf,
+                                   t.Kuf, ldN);
+    };
+    auto kuf_finish = [&](int g) -> gp_status {
+      const PdgpGP& q = p->gps[g];
+      const CondTask& t = p->cb.tasks[g];
+      const BwdBufs& bb = p->bw[g];
       const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS;
       double* gz_uf = q.need_z ? bb.gz_part : nullptr;
-      GP_CHECK(launch_hyper_contract(h, t.kern, z, q.M, x, n, bb.G, ldN, bb.alpha, gm, 0, t.feat, bb.hyp_part, &np_uf, gz_uf, t.Kuf, ldN));
-      GP_CHECK(launch_hyper_finish(h, t.kern, bb.hyp_part, np_uf, bb.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
-                                   grad + q.off_z));
+      return launch_hyper_finish(h, t.kern, bb.hyp_part, np_uf[g], bb.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
+                                 grad + q.off_z);
+    };
+    const bool split = forked && p->overlap >= 2 && gp_aux_resume(h);
+    if (split) {
+      gp_status st2 = GP_OK;
+      for (int g : p->kgps)
+        if (st2 == GP_OK && !gp_kern_has_partials(p->gps[g].ktype)) st2 = kuf_contract(g);
+      gp_status s3 = gp_aux_end(h);
+      if (st2 == GP_OK) st2 = s3;
+      GP_CHECK(st2);
+    }
+    for (int g : p->kgps) {
+      if (split && !gp_kern_has_partials(p->gps[g].ktype)) continue;
+      GP_CHECK(kuf_contract(g));
+      GP_CHECK(kuf_finish(g));
     }
     GP_CHECK(gp_aux_join(h));
+    if (split)
+      for (int g : p->kgps)
+        if (!gp_kern_has_partials(p->gps[g].ktype)) GP_CHECK(kuf_finish(g));
     for (int g : p->kgps) {   // the Kuu-side sums join the same gradient entries: after the join, on the main stream
       const PdgpGP& q = p->gps[g];
       const CondTask& t = p->cb.tasks[g];

@@ -24,7 +24,7 @@ struct gp_handle_s {
   GpLogisticTable logistic = {}; int num_logistic = 0;
   // helper stream for work that can overlap the main stream (the latency-bound Kuu factorisation runs on ~24 CUs
   // while the Kuf builds stream over the rest): created on first use, joined through events
-  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
   hipStream_t main_stream_saved = nullptr; bool aux_active = false, aux_pending = false;
   // timers
   bool timers_on = false;
@@ -109,6 +109,9 @@ static inline __host__ __device__ bool gp_kern_kdiag_energy(int t) { return gp_k
 // launchers (which enqueue on h->stream) target the helper stream; gp_aux_join makes the main stream wait for it.
 // gp_aux_fork returns false (and changes nothing) when no helper stream can be had: the work then stays in line.
 bool gp_aux_fork(gp_handle h);
+// after gp_aux_end and before gp_aux_join: hand the helper stream more work that depends on what the main stream has
+// enqueued so far (returns false when there is no pending fork)
+bool gp_aux_resume(gp_handle h);
 gp_status gp_aux_end(gp_handle h);
 gp_status gp_aux_join(gp_handle h);
 
