@@ -772,6 +772,34 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
   return GP_OK;
 }
 
+// R = W^T (Lq Lq^T - I) and alpha = W^T q_mu depend on the parameters and on W only: when the helper stream exists they
+// are enqueued on it during the FORWARD pass, right behind the Kuu factorisation it has just run (no wait on the main
+// stream, which is busy with the forward GEMM strips), and the backward pass finds them ready.
+gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n) {
+  gp_handle h = p->h;
+  p->era_ready = false;
+  if (!(p->whiten && p->nK > 0 && n >= 4096 && p->overlap >= 2 && h->aux_stream && !h->aux_active)) return GP_OK;
+  if (!h->ev_era && hipEventCreateWithFlags(&h->ev_era, hipEventDisableTiming) != hipSuccess) { h->ev_era = nullptr; return GP_OK; }
+  auto D = [&](int slot) { return (const GemmProblem*)(p->d_misc + p->off_bwd[slot]); };
+  const int nK = p->nK, maxM = p->maxM;
+  hipStream_t mainq = h->stream;
+  h->stream = h->aux_stream;
+  gp_status st = GP_OK;
+  GemmFlags f;
+  f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
+  st = launch_gemm_batched(h, D(S_E), nK, maxM, maxM, f);
+  if (st == GP_OK) st = launch_sub_identity_batched(h, D(S_E), nK, maxM);
+  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
+  if (st == GP_OK) st = launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f);
+  if (st == GP_OK) st = launch_matvec_batched(h, D(S_ALPHA), nK, maxM, 1);
+  hipError_t e = hipEventRecord(h->ev_era, h->aux_stream);
+  h->stream = mainq;
+  GP_CHECK(st);
+  if (e != hipSuccess) return gp_fail(h, GP_ERR_HIP, "hipEventRecord on the helper stream failed");
+  p->era_ready = true;
+  return GP_OK;
+}
+
 gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad) {
   gp_handle h = p->h;
   const int G = p->G, maxM = p->maxM;
@@ -826,15 +854,23 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   };
   if (!early_fork) GP_CHECK(h_chain_head());
   if (nK > 0) {
-    // E = Lq Lq^T - I
-    f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
-    GP_CHECK(launch_gemm_batched(h, D(S_E), nK, maxM, maxM, f));
-    GP_CHECK(launch_sub_identity_batched(h, D(S_E), nK, maxM));
+    const bool pre = p->era_ready;   // E, R, alpha were computed on the helper stream during the forward pass
+    p->era_ready = false;
+    if (pre) {
+      GP_HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_era, 0));
+    } else {
+      // E = Lq Lq^T - I
+      f = GemmFlags(); f.triA = TRI_LOWER; f.transB = 1; f.triB = TRI_UPPER;
+      GP_CHECK(launch_gemm_batched(h, D(S_E), nK, maxM, maxM, f));
+      GP_CHECK(launch_sub_identity_batched(h, D(S_E), nK, maxM));
+    }
     if (!early_fork) GP_CHECK(wbar_chain());
-    // R = W^T E ; alpha = W^T mu
-    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
-    GP_CHECK(launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f));
-    GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), nK, maxM, 1));
+    if (!pre) {
+      // R = W^T E ; alpha = W^T mu
+      f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
+      GP_CHECK(launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f));
+      GP_CHECK(launch_matvec_batched(h, D(S_ALPHA), nK, maxM, 1));
+    }
     // From here two independent chains remain: the Kuf side (the big Kuf_bar product and its contraction with
     // dK/dtheta over all frames) and the Kuu side (the Cholesky adjoint, six M x M products, and its contraction
     // over M x M).  The Kuu side is ~1.4 ms of small launches: it runs on the helper stream underneath Kuf_bar.

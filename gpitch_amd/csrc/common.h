@@ -24,7 +24,7 @@ struct gp_handle_s {
   GpLogisticTable logistic = {}; int num_logistic = 0;
   // helper stream for work that can overlap the main stream (the latency-bound Kuu factorisation runs on ~24 CUs
   // while the Kuf builds stream over the rest): created on first use, joined through events
-  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_era = nullptr;
   hipStream_t main_stream_saved = nullptr; bool aux_active = false, aux_pending = false;
   // timers
   bool timers_on = false;

@@ -194,6 +194,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
 }  // extern "C"
 
 gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad);  // bwd.hip
+gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n);
 gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad);
 
 // (re)bind the parameter vector / batch to the device descriptors
@@ -254,6 +255,7 @@ static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double
   GP_CHECK(pdgp_bind(p, params, x, n, grad, p->fmean, p->fvar));
   if (grad) GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
   GP_CHECK(cond_batch_run(h, p->cb, x, n, p->whiten != 0, p->jitter));
+  if (grad) GP_CHECK(pdgp_prefetch_backward(p, n));
   if (xchg) {
     GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, 1.0, nullptr, nullptr, nullptr,
                             nullptr, nullptr, xchg, nullptr));

@@ -72,6 +72,7 @@ struct gp_pdgp_plan_s {
   GemmProblem dummy_prob;      // sink for descriptor slots a GP does not need (pdgp_upload_bwd)
   int overlap = 2;             // gp_pdgp_set_overlap: 0 one stream, 1 Kuu factorisation / Kuu-side backward on the helper
                                // stream, 2 also the H = A D A^T chain next to Kuf_bar
+  bool era_ready = false;      // pdgp_prefetch_backward ran for the current evaluation
   bool factor_valid = false;   // L / W hold the factorisation of the parameters last passed to gp_pdgp_predict
   // two-stage (pitch-sharded) evaluation: what gp_pdgp_elbo_begin staged for gp_pdgp_elbo_end
   int staged_n = 0; double* staged_grad = nullptr; const double* staged_params = nullptr;
