@@ -138,6 +138,7 @@ def main():
 
     import gpitch_amd
     from gpitch_amd import _lib
+    from gpitch_amd import dist as gp_dist
     prob, model = build_model(args, rank)
     model._pack()
     h = model._handle
@@ -154,7 +155,7 @@ def main():
         if dist is not None and args.shard == "window":
             # scalar ELBO of the whole job (north_star: all-reduce of the scalar ELBO)
             elbo_sum.copy_(model._elbo_dev[:1])
-            gpitch_amd.dist.allreduce_sum_(elbo_sum)
+            gp_dist.allreduce_sum_(elbo_sum)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,42 @@
+"""bench.py end to end on the GPU box: the single-process line and a 2-rank rehearsal of both multi-GPU modes
+(gloo backend, both ranks on the one GPU here; the driver's scaling runs use RCCL with one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--N", "4096", "--M", "64", "--P", "2", "--partials", "3", "--steps", "2", "--warmup", "1", "--no-cpu"]
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_process_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["metric"] == "ELBO-steps/sec" and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["value"] > 0
+    assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"]
+    assert d["config"]["workload"].startswith("pdgp ELBO step")
+
+
+@pytest.mark.parametrize("shard,scaling", [("window", "weak"), ("pitch", "strong")])
+def test_bench_two_rank_rehearsal(shard, scaling):
+    port = 29700 + (os.getpid() % 200) + (0 if shard == "window" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shard", shard] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("window-per-gpu" if shard == "window" else "pitch-sharded")
