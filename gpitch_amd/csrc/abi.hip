@@ -127,6 +127,9 @@ gp_status gp_destroy(gp_handle h) {
 
 gp_status gp_sync(gp_handle h) {
   if (!h) return GP_ERR_BAD_ARG;
+  // the helper stream is normally joined into the handle's stream before an entry point returns; the one exception is
+  // work prefetched for a backward pass that was never asked for (gp_pdgp_elbo_begin without _end)
+  if (h->aux_stream) GP_HIP_CHECK(h, hipStreamSynchronize(h->aux_stream));
   GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
   return GP_OK;
 }

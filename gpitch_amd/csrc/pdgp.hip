@@ -67,7 +67,11 @@ gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* o
   return GP_OK;
 }
 
-gp_status gp_pdgp_destroy(gp_pdgp_plan p) { delete p; return GP_OK; }
+gp_status gp_pdgp_destroy(gp_pdgp_plan p) {
+  if (p && p->h && p->h->aux_stream) (void)hipStreamSynchronize(p->h->aux_stream);   // nothing of this plan still in flight
+  delete p;
+  return GP_OK;
+}
 
 gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, int32_t need_z) {
   if (!p || g < 0 || g >= p->G) return GP_ERR_BAD_ARG;
