@@ -336,6 +336,16 @@ gp_status gp_gauss_kl_matrix(gp_handle h, const double* q_mu, const double* q_sq
                        "gp_gauss_kl_matrix: workspace too small (gp_gauss_kl_workspace_bytes)");
 }
 
+gp_status gp_overlap_merge(gp_handle h, const double* windows, int32_t num_windows, int32_t ws, int64_t ld, int32_t n,
+                           int32_t square, double* out) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!windows || !out || num_windows < 2 || ws < 3 || (ws & 1) == 0 || ld < ws)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_overlap_merge: need >= 2 windows of odd length ws >= 3, ld >= ws");
+  const int ll = (ws - 1) / 2;
+  if (n != ll * (num_windows + 1) + 1) return gp_fail(h, GP_ERR_BAD_ARG, "gp_overlap_merge: n must be (ws-1)/2 * (num_windows+1) + 1");
+  return launch_overlap_merge(h, windows, num_windows, ws, ld, n, square, out);
+}
+
 gp_status gp_transform_register_logistic(gp_handle h, double a, double b, uint8_t* code_out) {
   if (!h) return GP_ERR_BAD_ARG;
   if (!code_out || !(b > a)) return gp_fail(h, GP_ERR_BAD_ARG, "gp_transform_register_logistic: need b > a");

@@ -228,6 +228,7 @@ gp_status launch_sm_features_items(gp_handle h, const FeatItem* d_items, int cou
                                    const double* x_shared, int n_shared);
 gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem* d_items, int count, int max_n1,
                                     int max_n2, const double* x2_shared, int n2_shared);
+gp_status launch_overlap_merge(gp_handle h, const double* y, int nw, int ws, int64_t ldy, int n, int square, double* out);
 // lik.hip
 // whitened KL: each item writes GP_KL_BLOCKS partial sums to out[0..GP_KL_BLOCKS)
 #define GP_KL_BLOCKS 16

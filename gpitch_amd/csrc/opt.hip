@@ -84,3 +84,39 @@ gp_status launch_adam(gp_handle h, double* fs, double* params, const double* gra
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hann overlap-add of per-window predictions (gpitch/window_overlap.py:19-59, merged_mean / merged_variance): windows
+// of odd length ws, hop ll = (ws - 1) / 2, n = ll (nw + 1) + 1 output frames.  Written as a gather: every output frame
+// takes its (at most two) contributions, reproducing the reference's slice assignments, including which iteration
+// wins on the shared boundary frames.  win = scipy.signal.hann(ws) (symmetric), flat over the first half of the first
+// window and the last half of the last one; squared for variances.
+__global__ void __launch_bounds__(256) overlap_merge_kernel(const double* __restrict__ y, int nw, int ws, int64_t ldy,
+                                                            int n, int square, double* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int ll = (ws - 1) / 2;
+  auto wv = [&](int k, int j) -> double {      // weighted sample j of window k
+    double w = 0.5 - 0.5 * cos(6.283185307179586 * (double)j / (double)(ws - 1));
+    if (k == 0 && j < ll) w = 1.0;
+    if (k == nw - 1 && j >= ws - ll) w = 1.0;
+    if (square) w = w * w;
+    return y[(int64_t)k * ldy + j] * w;
+  };
+  double v;
+  if (t < ll) v = wv(0, t);
+  else if (t >= n - ll) v = wv(nw - 1, t - (nw - 1) * ll);
+  else {
+    int i = t / ll - 1;
+    if (i > nw - 2) i = nw - 2;
+    const int j = t - (i + 1) * ll;
+    v = wv(i, ll + j) + wv(i + 1, j);
+  }
+  out[t] = v;
+}
+
+gp_status launch_overlap_merge(gp_handle h, const double* y, int nw, int ws, int64_t ldy, int n, int square, double* out) {
+  hipLaunchKernelGGL(overlap_merge_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, y, nw, ws, ldy, n, square, out);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}

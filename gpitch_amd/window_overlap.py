@@ -56,6 +56,22 @@ def merged_variance(y, ws, n):
     return _merge(y, ws, n, True)
 
 
+def merged_on_device(windows, ws, n, square=False, handle=None):
+    """merged_mean (square=False) / merged_variance (square=True) on the GPU: `windows` is a (num_windows, ws) device
+    tensor (e.g. the stacked per-window predictions of windows.fit_windows) or anything np.asarray accepts; returns a
+    device tensor of n frames.  Same arithmetic as _merge above (gp_overlap_merge, csrc/opt.hip)."""
+    from . import _lib
+    h = handle or _lib.default_handle()
+    t = h.torch
+    if not t.is_tensor(windows):
+        windows = h.to_device(np.asarray([np.asarray(wi, dtype=np.float64).reshape(-1) for wi in windows]))
+    windows = windows.contiguous()
+    nw = windows.shape[0]
+    out = h.empty(n)
+    h.check(h.lib.gp_overlap_merge(h.h, windows.data_ptr(), nw, ws, windows.shape[1], n, int(bool(square)), out.data_ptr()))
+    return out
+
+
 def merged_x(x, ws):
     """window_overlap.py:60-73"""
     l = (ws - 1) // 2

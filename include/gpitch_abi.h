@@ -213,6 +213,13 @@ gp_status gp_pdgp_predict(gp_pdgp_plan p, const double* params, const double* xn
 gp_status gp_pdgp_predict_reuse(gp_pdgp_plan p, const double* params, const double* xnew, int32_t n,
                                 double* fmean, double* fvar, double* mean_source);
 
+/* ---- overlap-add of per-window predictions (gpitch/window_overlap.py:19-59: merged_mean / merged_variance) ----------
+ * windows: num_windows x ws (row-major, leading dimension ld) device array of per-window means (square = 0) or
+ * variances (square = 1: squared Hann weights); ws odd, 50 % overlap (hop (ws-1)/2); out: n = (ws-1)/2 *
+ * (num_windows + 1) + 1 frames.  First / last half-windows are kept flat exactly as the reference does. */
+gp_status gp_overlap_merge(gp_handle h, const double* windows, int32_t num_windows, int32_t ws, int64_t ld, int32_t n,
+                           int32_t square, double* out);
+
 /* ---- optimiser on the free state (GPflow Model.optimize with tf.train.AdamOptimizer;
  *      demo-modgp.py:44-45; transforms: GPflow Log1pe 'positive') -----------------------------------
  * tcode[i]: 0 identity, 1 positive (y = log(1+e^x) + 1e-6), 2 fixed (identity, no update),

@@ -232,3 +232,21 @@ def test_logistic_transform_and_adam_step(gp_handle):
     np.testing.assert_allclose(dx.cpu().numpy(), x1, rtol=1e-12, atol=1e-14)
     y1 = np.array([tr[w].forward(np.array([xi]))[0] for w, xi in zip(which, x1)])
     np.testing.assert_allclose(dy.cpu().numpy(), y1, rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("ws,nw", [(2001, 5), (31, 2), (101, 17)])
+def test_overlap_merge_on_device_matches_host(gp_handle, ws, nw):
+    """gp_overlap_merge = window_overlap.merged_mean / merged_variance (window_overlap.py:19-59), boundary frames and
+    flat half-windows included."""
+    from gpitch_amd.window_overlap import merged_mean, merged_variance, merged_on_device
+    rng = np.random.RandomState(ws + nw)
+    ll = (ws - 1) // 2
+    n = ll * (nw + 1) + 1
+    ys = [rng.randn(ws, 1) for _ in range(nw)]
+    for square, host in ((False, merged_mean), (True, merged_variance)):
+        ref = host([y.copy() for y in ys], ws, n).reshape(-1)
+        got = merged_on_device(ys, ws, n, square=square, handle=gp_handle).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-14)
+    bad = gp_handle.empty(nw, ws)
+    with pytest.raises(Exception):
+        gp_handle.check(gp_handle.lib.gp_overlap_merge(gp_handle.h, bad.data_ptr(), nw, ws, ws, n + 1, 0, bad.data_ptr()))
