@@ -686,6 +686,56 @@ gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, in
   return GP_OK;
 }
 
+// One launch for all latent GPs: block (s, item) adds the Kuf-side and the Kuu-side partial sums (and the Kdiag term)
+// of entry s of that GP's theta gradient; the remaining blocks do the same for its inducing-input gradient.
+struct HyperFinishItem {
+  DevKern k;
+  const double* p_uf; const double* p_uu; const double* gv_sum;
+  double* g_theta; const double* gz_uf; const double* gz_uu; double* g_z;
+  int np_uf, np_uu, cb_uf, cb_uu, n1, pad;
+};
+
+size_t hyper_finish_item_bytes() { return sizeof(HyperFinishItem); }
+
+__global__ void __launch_bounds__(256) hyper_finish_items_kernel(const HyperFinishItem* __restrict__ items) {
+  const HyperFinishItem it = items[blockIdx.y];
+  const int ns = 2 + 2 * it.k.m;
+  const int s = blockIdx.x;
+  if (s < ns) {
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int c = threadIdx.x; c < it.np_uf; c += 256) a += it.p_uf[(int64_t)c * ns + s];
+    for (int c = threadIdx.x; c < it.np_uu; c += 256) a += it.p_uu[(int64_t)c * ns + s];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      double v = red[0];
+      const double gs = it.gv_sum[0];      // d kdiag / d theta contribution: kdiag = var (stationary) or var * sum(e)
+      const bool smk = gp_kern_kdiag_energy(it.k.type);
+      if (s == 0) {
+        double se = 1.0;
+        if (smk) { se = 0.0; for (int q = 0; q < it.k.m; q++) se += it.k.theta[2 + q]; }
+        v += gs * se;
+      } else if (smk && s >= 2 && s < 2 + it.k.m) {
+        v += gs * it.k.theta[0];
+      }
+      it.g_theta[s] += v;
+    }
+  } else if (it.g_z) {
+    const int i = (blockIdx.x - ns) * 256 + threadIdx.x;
+    if (i < it.n1) {
+      double a = 0.0;
+      for (int c = 0; c < it.cb_uf; c++) a += it.gz_uf[(int64_t)c * it.n1 + i];
+      for (int c = 0; c < it.cb_uu; c++) a += it.gz_uu[(int64_t)c * it.n1 + i];
+      it.g_z[i] += a;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // orchestration
 // slots below S_E are batched over all latent GPs, slots from S_E on over the GPs whose kernel gradients are needed.
@@ -704,6 +754,8 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
   size_t base = pdgp_kl_region_bytes(G);
   for (int s = 0; s < S_COUNT; s++) p->off_bwd[s] = base + s * slot_bytes;
   p->off_kl2 = base + 24 * slot_bytes;
+  p->off_fin_items = p->off_kl2 + pdgp_kl_region_bytes(G);
+  p->h_fin_items.clear();       // the descriptor block is rewritten: force a fresh upload of the finish items
   const bool white = p->whiten != 0;
   const int64_t ldN = ldN_b(n);
   size_t slab_off = 0;
@@ -936,15 +988,6 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       return launch_hyper_contract(h, t.kern, z, q.M, x, n, bb.G, ldN, bb.alpha, gm, 0, t.feat, bb.hyp_part, &np_uf[g], gz_uf,
                                    t.Kuf, ldN);
     };
-    auto kuf_finish = [&](int g) -> gp_status {
-      const PdgpGP& q = p->gps[g];
-      const CondTask& t = p->cb.tasks[g];
-      const BwdBufs& bb = p->bw[g];
-      const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS;
-      double* gz_uf = q.need_z ? bb.gz_part : nullptr;
-      return launch_hyper_finish(h, t.kern, bb.hyp_part, np_uf[g], bb.gvsum, grad + q.off_theta, gz_uf, cb_uf, q.M,
-                                 grad + q.off_z);
-    };
     const bool split = forked && p->overlap >= 2 && gp_aux_resume(h);
     if (split) {
       gp_status st2 = GP_OK;
@@ -957,20 +1000,39 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     for (int g : p->kgps) {
       if (split && !gp_kern_has_partials(p->gps[g].ktype)) continue;
       GP_CHECK(kuf_contract(g));
-      GP_CHECK(kuf_finish(g));
     }
     GP_CHECK(gp_aux_join(h));
-    if (split)
-      for (int g : p->kgps)
-        if (!gp_kern_has_partials(p->gps[g].ktype)) GP_CHECK(kuf_finish(g));
-    for (int g : p->kgps) {   // the Kuu-side sums join the same gradient entries: after the join, on the main stream
-      const PdgpGP& q = p->gps[g];
-      const CondTask& t = p->cb.tasks[g];
-      const BwdBufs& bb = p->bw[g];
-      const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS, cb_uu = (q.M + HY_THREADS - 1) / HY_THREADS;
-      double* gz_uu = q.need_z ? bb.gz_part + (size_t)cb_uf * q.M : nullptr;
-      GP_CHECK(launch_hyper_finish(h, t.kern, bb.hyp_part_uu, np_uu[g], nullptr, grad + q.off_theta, gz_uu, cb_uu, q.M,
-                                   grad + q.off_z));
+    // all partial sums (Kuf side, Kuu side) are in: ONE finish launch adds them into the gradient vector (48 tiny
+    // launches at the end of every step otherwise).  The item array is re-uploaded only when it changes.
+    {
+      std::vector<HyperFinishItem> items;
+      int maxblocks = 0;
+      for (int g : p->kgps) {
+        const PdgpGP& q = p->gps[g];
+        const CondTask& t = p->cb.tasks[g];
+        const BwdBufs& bb = p->bw[g];
+        const int cb_uf = (n + HY_THREADS - 1) / HY_THREADS, cb_uu = (q.M + HY_THREADS - 1) / HY_THREADS;
+        HyperFinishItem it;
+        memset(&it, 0, sizeof(it));
+        it.k = t.kern; it.p_uf = bb.hyp_part; it.np_uf = np_uf[g]; it.p_uu = bb.hyp_part_uu; it.np_uu = np_uu[g];
+        it.gv_sum = bb.gvsum; it.g_theta = grad + q.off_theta; it.n1 = q.M;
+        if (q.need_z) {
+          it.gz_uf = bb.gz_part; it.cb_uf = cb_uf; it.gz_uu = bb.gz_part + (size_t)cb_uf * q.M; it.cb_uu = cb_uu;
+          it.g_z = grad + q.off_z;
+        }
+        const int blocks = 2 + 2 * t.kern.m + (q.need_z ? (q.M + 255) / 256 : 0);
+        if (blocks > maxblocks) maxblocks = blocks;
+        items.push_back(it);
+      }
+      const size_t bytes = items.size() * sizeof(HyperFinishItem);
+      char* d_items = p->d_misc + p->off_fin_items;
+      if (p->h_fin_items.size() != bytes || memcmp(p->h_fin_items.data(), items.data(), bytes) != 0) {
+        p->h_fin_items.assign((const char*)items.data(), (const char*)items.data() + bytes);
+        GP_HIP_CHECK(h, hipMemcpyAsync(d_items, p->h_fin_items.data(), bytes, hipMemcpyHostToDevice, h->stream));
+      }
+      hipLaunchKernelGGL(hyper_finish_items_kernel, dim3(maxblocks, (unsigned)items.size()), dim3(256), 0, h->stream,
+                         (const HyperFinishItem*)d_items);
+      GP_HIP_CHECK(h, hipGetLastError());
     }
   } else if (!white) {
     GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));

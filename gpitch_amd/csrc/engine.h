@@ -35,6 +35,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
 gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, int nparts, const double* gv_sum,
                               double* g_theta, const double* gz_partials, int ncolblocks, int n1, double* g_z);
 int hyper_num_sums(int m);
+size_t hyper_finish_item_bytes();
 // partial records the Kuf-side contraction of an M x N strip may write (the largest over its kernel variants)
 size_t hyper_kuf_records(int N, int M);
 

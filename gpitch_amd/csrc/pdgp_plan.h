@@ -60,6 +60,7 @@ struct gp_pdgp_plan_s {
   std::vector<char> h_misc;
   size_t off_kl_items = 0;
   size_t off_bwd[24] = {0};
+  size_t off_fin_items = 0; std::vector<char> h_fin_items;   // batched hyper-gradient finish (bwd.hip)
   size_t off_kl2 = 0;         // unwhitened backward: KL items of the equivalent whitened state
   double* qw_block = nullptr; size_t qw_doubles = 0;   // [q' | grad q'] of all GPs, contiguous (one memset)
   double* kl_dummy = nullptr;
