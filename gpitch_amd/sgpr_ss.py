@@ -122,6 +122,7 @@ class SGPRSS(Parameterized):
         self._dev("_Yd", self.Y._array[fr])
         self._dev("_Zd", self.Z._array)
         object.__setattr__(self, "_n_local", fr.stop - fr.start)
+        object.__setattr__(self, "_obj_state", None)      # Param values / .fixed flags may have changed
 
     def _bound(self, grad=None):
         """one evaluation of the bound (and gradient into the device vector `grad`) on this model's frames; the
@@ -209,14 +210,54 @@ class SGPRSS(Parameterized):
             ps.extend(k.theta_params())
         return ps
 
+    def _objective_setup(self):
+        """vectorised view of the free state for _objective (rebuilt by optimize(): .fixed flags, transforms and the
+        values of the fixed Params are read once per optimisation, not once per evaluation)"""
+        from .param import Identity, Log1pe, Logistic
+        ps = self._param_list()
+        free_idx = np.array([i for i, p in enumerate(ps) if not p.fixed], dtype=np.int64)
+        kind = np.zeros(free_idx.size, dtype=np.int64)      # 0 identity, 1 positive, 2 logistic, 3 anything else
+        lo = np.zeros(free_idx.size)
+        span = np.ones(free_idx.size)
+        other = {}
+        for j, i in enumerate(free_idx):
+            tr = ps[i].transform
+            if isinstance(tr, Identity):
+                kind[j] = 0
+            elif isinstance(tr, Log1pe):
+                kind[j] = 1
+                lo[j] = tr._lower
+            elif isinstance(tr, Logistic):
+                kind[j] = 2
+                lo[j], span[j] = tr.a, tr.b - tr.a
+            else:
+                kind[j] = 3
+                other[j] = tr
+        st = {"ps": ps, "free_idx": free_idx, "kind": kind, "lo": lo, "span": span, "other": other,
+              "vals0": np.array([p.value[0] for p in ps])}
+        object.__setattr__(self, "_obj_state", st)
+        return st
+
+    @staticmethod
+    def _free_to_params(st, x):
+        """forward transforms and their derivatives for the whole free vector at once"""
+        x = np.asarray(x, dtype=np.float64)
+        kind, lo, span = st["kind"], st["lo"], st["span"]
+        sig = 1. / (1. + np.exp(-x))
+        y = np.where(kind == 1, np.logaddexp(0., x) + lo, np.where(kind == 2, lo + span * sig, x))
+        dy = np.where(kind == 1, sig, np.where(kind == 2, span * sig * (1. - sig), 1.))
+        for j, tr in st["other"].items():
+            y[j] = tr.forward(np.array([x[j]]))[0]
+            dy[j] = tr.dforward(np.array([x[j]]))[0]
+        return y, dy
+
     def _objective(self, x_free):
         """(-(bound), -d bound / d free-state) — GPflow Model._objective"""
         h = self._handle
-        ps = self._param_list()
-        free_idx = [i for i, p in enumerate(ps) if not p.fixed]
-        vals = np.array([p.value[0] for p in ps])
-        for j, i in enumerate(free_idx):
-            vals[i] = ps[i].transform.forward(np.array([x_free[j]]))[0]
+        st = self.__dict__.get("_obj_state") or self._objective_setup()
+        y, dy = self._free_to_params(st, x_free)
+        vals = st["vals0"].copy()
+        vals[st["free_idx"]] = y
         self._dev("_params", vals)
         grad = self.__dict__.get("_grad_dev")
         if grad is None or grad.numel() != self._nparams:
@@ -224,23 +265,21 @@ class SGPRSS(Parameterized):
             object.__setattr__(self, "_grad_dev", grad)
         value = self._bound(grad)
         g = grad.cpu().numpy()
-        gf = np.empty(len(free_idx))
-        for j, i in enumerate(free_idx):
-            dydx = float(ps[i].transform.dforward(np.array([x_free[j]]))[0])
-            gf[j] = g[i] * dydx
-        return -value, -gf
+        return -value, -(g[st["free_idx"]] * dy)
 
     def optimize(self, method='L-BFGS-B', tol=None, callback=None, maxiter=1000, disp=False, **kw):
         from scipy.optimize import minimize
         self._compile()
         self._pack()
-        ps = self._param_list()
-        free_idx = [i for i, p in enumerate(ps) if not p.fixed]
+        st = self._objective_setup()
+        ps, free_idx = st["ps"], st["free_idx"]
         x0 = np.array([ps[i].transform.backward(ps[i].value)[0] for i in free_idx])
         res = minimize(self._objective, x0, jac=True, method=method, tol=tol, callback=callback,
                        options=dict(maxiter=maxiter, disp=disp))
+        y, _ = self._free_to_params(st, res.x)
         for j, i in enumerate(free_idx):
-            ps[i].value = ps[i].transform.forward(np.array([res.x[j]]))
+            ps[i].value = y[j:j + 1]
+        object.__setattr__(self, "_obj_state", None)
         return res
 
     def _destroy(self):
