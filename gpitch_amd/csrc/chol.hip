@@ -31,27 +31,50 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// sqrt(x) and 1/sqrt(x) of a pivot from one v_rsq_f64 and fused corrections (both within 1.5 ulp): the pivot
+// chain of the in-register factorisation is serial, so the library's sqrt + division (each with scaling and class
+// handling) is what bounds it.  Valid for finite x > 0 (no intermediate leaves the double range); the caller
+// rejects everything else as a bad pivot.
+__device__ __forceinline__ void pivot_sqrt_recip(double x, double& s, double& rinv) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  double r = h + h;
+  r = fma(fma(-g, r, 1.0), r, r);
+  s = g; rinv = r;
+}
+
 // Factor the 32 x 32 diagonal block at (k0, k0) entirely in the registers of ONE wavefront (lane i holds row i;
 // pivots / columns are broadcast with v_readlane), write L_kk to global and its inverse to Dinv (LDS).
 __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t ld, int M, int k0, int lane,
                                                 double (*Dinv)[CH_NB + 1], int* __restrict__ status, int b, int pbase) {
   const int nb = min(CH_NB, M - k0);
   double row[CH_NB];
+  double rinv[CH_NB];   // 1 / L_jj, wave-uniform (lives in SGPRs)
   const int i = lane & 31;
+  // unconditional loads from clamped (always valid) addresses, then select: no divergent branches
+  const double* arow = A + (int64_t)(k0 + min(i, nb - 1)) * ld + k0;
 #pragma unroll
-  for (int c = 0; c < CH_NB; c++)
-    row[c] = (i < nb && c <= i) ? A[(int64_t)(k0 + i) * ld + k0 + c] : (i == c ? 1.0 : 0.0);
+  for (int c = 0; c < CH_NB; c++) {
+    const double v = arow[min(c, nb - 1)];
+    row[c] = (i < nb && c <= i) ? v : (i == c ? 1.0 : 0.0);
+  }
+  int bad = -1;        // first non-positive / non-finite pivot (wave-uniform), reported once after the loop
 #pragma unroll
   for (int j = 0; j < CH_NB; j++) {
     double djj = lane_bcast(row[j], j);
-    if (!(djj > 0.0)) {  // non-positive or NaN pivot: report the first one, keep going finite
-      if (lane == 0 && j < nb) {
-        if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = pbase + k0 + j; status[2] = b; }
-      }
-      djj = 1.0;
-    }
-    double s = __dsqrt_rn(djj);
-    double lij = (i > j) ? row[j] / s : (i == j ? s : 0.0);
+    const bool ok = (djj > 0.0) && (djj <= 1.7976931348623157e308);
+    bad = (!ok && bad < 0 && j < nb) ? j : bad;
+    djj = ok ? djj : 1.0;                       // keep going finite
+    double s, ri;
+    pivot_sqrt_recip(djj, s, ri);
+    rinv[j] = lane_bcast(ri, 0);
+    double lij = (i > j) ? row[j] * ri : (i == j ? s : 0.0);
     row[j] = lij;
 #pragma unroll
     for (int c = j + 1; c < CH_NB; c++) {
@@ -59,20 +82,33 @@ __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t 
       row[c] = fma(-lij, lcj, row[c]);  // meaningful for i >= c only
     }
   }
+  if (bad >= 0 && lane == 0) {
+    if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = pbase + k0 + bad; status[2] = b; }
+  }
   if (lane < 32) {
 #pragma unroll
     for (int c = 0; c < CH_NB; c++)
       if (i < nb && c <= i) A[(int64_t)(k0 + i) * ld + k0 + c] = row[c];
   }
-  // inverse of the diagonal factor, column c in lane c: x[r] = (L_kk^-1)[r][c]
+  // inverse of the diagonal factor, column c in lane c: x[r] = (L_kk^-1)[r][c], by forward substitution taken
+  // column by column (x[t] final -> 31 - t independent updates).  L_rt is lane r of row[t], the very value the
+  // factor loop broadcast: laundering row[] keeps the compiler from holding all 496 of them live in SGPRs
+  // (it spilled them lane by lane into VGPRs) instead of simply reading the lane again.
+#pragma unroll
+  for (int c = 0; c < CH_NB; c++) asm volatile("" : "+v"(row[c]));
   double x[CH_NB];
 #pragma unroll
-  for (int r = 0; r < CH_NB; r++) {
-    double acc = (i == r) ? 1.0 : 0.0;
+  for (int r = 0; r < CH_NB; r++) x[r] = (i == r) ? 1.0 : 0.0;
 #pragma unroll
-    for (int t = 0; t < r; t++) acc = fma(-lane_bcast(row[t], r), x[t], acc);
-    x[r] = acc / lane_bcast(row[r], r);
+  for (int t = 0; t < CH_NB; t++) {
+    x[t] *= rinv[t];
+#pragma unroll
+    for (int r = t + 1; r < CH_NB; r++) x[r] = fma(-lane_bcast(row[t], r), x[t], x[r]);
   }
+  // pin x[] here: otherwise the substitution is sunk into the lane-conditional stores below while its
+  // (convergent) lane broadcasts stay outside, all 496 of them live at once and spilled
+#pragma unroll
+  for (int r = 0; r < CH_NB; r++) asm volatile("" : "+v"(x[r]));
   if (lane < 32) {
 #pragma unroll
     for (int r = 0; r < CH_NB; r++) Dinv[r][i] = x[r];
@@ -234,17 +270,25 @@ __global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* c
     const int nb = min(CH_NB, M - d0);
     const int i = lane & 31;
     double lrow[CH_NB];  // lane i: row i of the diagonal block of L (identity-padded)
+    const double* lsrc = L + (int64_t)(d0 + min(i, nb - 1)) * ld + d0;   // clamped: loads are unconditional
 #pragma unroll
-    for (int c = 0; c < CH_NB; c++)
-      lrow[c] = (i < nb && c <= i) ? L[(int64_t)(d0 + i) * ld + d0 + c] : (i == c ? 1.0 : 0.0);
-    double x[CH_NB];  // lane c: column c of the inverse, x[t] = X[t][c]
-#pragma unroll
-    for (int r = 0; r < CH_NB; r++) {
-      double acc = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-      for (int t = 0; t < r; t++) acc = fma(-lane_bcast(lrow[t], r), x[t], acc);
-      x[r] = acc / lane_bcast(lrow[r], r);
+    for (int c = 0; c < CH_NB; c++) {
+      const double v = lsrc[min(c, nb - 1)];
+      lrow[c] = (i < nb && c <= i) ? v : (i == c ? 1.0 : 0.0);
     }
+    // one division per lane up front (lane i: 1 / L_ii), so the serial substitution below only multiplies
+    const double rec = 1.0 / ((i < nb) ? lsrc[min(i, nb - 1)] : 1.0);
+    double x[CH_NB];  // lane c: column c of the inverse, x[t] = X[t][c]; substitution column by column
+#pragma unroll
+    for (int r = 0; r < CH_NB; r++) x[r] = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < CH_NB; t++) {
+      x[t] *= lane_bcast(rec, t);
+#pragma unroll
+      for (int r = t + 1; r < CH_NB; r++) x[r] = fma(-lane_bcast(lrow[t], r), x[t], x[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < CH_NB; r++) asm volatile("" : "+v"(x[r]));   // as in chol_diag_block: no sinking into the stores
     if (lane < 32 && i < nb) {
 #pragma unroll
       for (int r = 0; r < CH_NB; r++)
