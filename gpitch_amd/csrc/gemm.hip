@@ -30,7 +30,10 @@ typedef double __attribute__((address_space(1))) * gptr;
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef const dbl2 __attribute__((address_space(1))) * gcptr2;
 
-#define GEMM_THREADS 256
+// Threads per workgroup: 4 wavefronts (1 x 4 on the 128-tiles, each 128 x 32; 2 x 2 on the 64-tiles), except the
+// Lq^T A strip product (TAG 2), which measures 5 % faster with 8 (2 x 4, each 64 x 32, <= 128 VGPRs: four
+// wavefronts per SIMD); the other roles lose more to the extra LDS reads and staging than they gain.
+constexpr int gemm_threads(int BM, int TAG) { return (BM == 128 && TAG == 2) ? 512 : 256; }
 #define GEMM_BK 16
 
 struct GemmDevFlags {
@@ -65,12 +68,14 @@ template <> struct RoleCfg<3> { static constexpr int triA = TRI_NONE, triB = TRI
 template <> struct RoleCfg<4> { static constexpr int triA = TRI_NONE, triB = TRI_NONE, scale = -1; };  // scale: runtime (v1 may be absent)
 
 template <int BM, int BN, bool TA, bool TB, int TAG>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmProblem* __restrict__ probs,
+__global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) / 128) gemm_f64_kernel(const GemmProblem* __restrict__ probs,
                                                                     GemmDevFlags f) {
   using S = GemmSmem<BM, BN, TA, TB>;
   // wave layout: 128-tiles use 1 x 4 (each wave owns all 128 rows of a 32-column slice, so triangular
-  // skipping inside the diagonal block is identical for every wave: no barrier imbalance); 64-tiles 2 x 2.
-  constexpr int WAVES_M = (BM == 128) ? 1 : 2, WAVES_N = 4 / WAVES_M;
+  // skipping inside the diagonal block is identical for every wave: no barrier imbalance), or 2 x 4 with 8
+  // wavefronts; 64-tiles 2 x 2.
+  constexpr int GEMM_THREADS = gemm_threads(BM, TAG);
+  constexpr int WAVES_M = (BM == 128) ? GEMM_THREADS / 256 : 2, WAVES_N = (GEMM_THREADS / 64) / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int EA = BM * GEMM_BK / GEMM_THREADS;  // elements per thread, A tile
@@ -147,7 +152,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(const GemmPro
   // first row-tile each of this wave's column tiles needs (wave-uniform scalars; 0 = everything)
   int cmin[TN];
 #pragma unroll
-  for (int b = 0; b < TN; b++) cmin[b] = diag_sym ? __builtin_amdgcn_readfirstlane(ctile[b]) : 0;
+  for (int b = 0; b < TN; b++)
+    cmin[b] = diag_sym ? max(0, __builtin_amdgcn_readfirstlane(ctile[b]) - __builtin_amdgcn_readfirstlane(wr) * TM) : 0;
 
   // ---- global -> register staging ---------------------------------------------------------------
   // Row-contiguous tiles (op(A) transposed / op(B) plain) are dealt to threads in 16-byte pairs so that
@@ -528,7 +534,7 @@ static gp_status launch_one(gp_handle h, const GemmProblem* d_probs, int batch, 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
     attr_set.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, TA, TB, TAG>), grid, dim3(GEMM_THREADS), S::BYTES, h->stream, d_probs, df);
+  hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, TA, TB, TAG>), grid, dim3(gemm_threads(BM, TAG)), S::BYTES, h->stream, d_probs, df);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
