@@ -205,8 +205,10 @@ static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb) {
                                       (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G);
   }
   const int* lds = (const int*)(cb.d_desc + cb.off_lds);
-  for (int g = 0; g < G; g++)   // zero above the block diagonal of W (the diagonal blocks are written whole)
-    GP_HIP_CHECK(h, hipMemsetAsync(cb.tasks[g].W, 0, (size_t)cb.tasks[g].M * cb.tasks[g].M * sizeof(double), h->stream));
+  // zero above the block diagonal of every W in one launch (the diagonal blocks are written whole, the blocks
+  // below by the block-row inverse)
+  GP_CHECK(launch_zero_upper_blocks_batched(h, (double* const*)(cb.d_desc + cb.off_w_ptrs),
+                                            (const int*)(cb.d_desc + cb.off_Ms), lds, G, cb.maxM, CB_NB));
   for (int k = 0; k < cb.nblk; k++) {
     double* const* mats = (double* const*)(cb.d_desc + cb.off_blk_mats[k]);
     double* const* ws = (double* const*)(cb.d_desc + cb.off_blk_w[k]);
