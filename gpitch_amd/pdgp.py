@@ -197,15 +197,34 @@ class Pdgp(Parameterized):
 
     def _batch(self):
         """fresh minibatch (x and y generators are seeded identically so rows stay paired: pdgp.py:76-77)"""
-        h = self._handle
         idx = self.x.next_indices()
         idy = self.y.next_indices()
         assert np.array_equal(idx, idy)
-        if self.minibatch_size == self.num_data and np.array_equal(np.sort(idx), np.arange(self.num_data)):
-            ti = h.torch.as_tensor(idx, device=h.device)
-        else:
-            ti = h.torch.as_tensor(idx, device=h.device)
+        ti = self._upload_indices(idx)
         return self._x_dev.index_select(0, ti).contiguous(), self._y_dev.index_select(0, ti).contiguous(), idx.size
+
+    def _upload_indices(self, idx):
+        """The step's index vector goes up through a small ring of pinned host buffers with a non-blocking copy: a
+        plain `as_tensor(idx, device=...)` is a synchronous copy from pageable memory, i.e. one host-device sync per
+        step, after which the device sits idle until the host has issued the next step's first launches."""
+        h = self._handle
+        torch = h.torch
+        if h.device.type != "cuda":
+            return torch.as_tensor(idx, device=h.device)
+        n = int(idx.size)
+        ring = getattr(self, "_idx_ring", None)
+        if ring is None or ring[0][0].numel() < n:
+            cap = max(n, int(self.minibatch_size))
+            ring = [(torch.empty(cap, dtype=torch.int64).pin_memory(),
+                     torch.empty(cap, dtype=torch.int64, device=h.device), torch.cuda.Event()) for _ in range(3)]
+            self._idx_ring, self._idx_pos = ring, 0
+        pinned, dev, ev = ring[self._idx_pos % len(ring)]
+        self._idx_pos += 1
+        ev.synchronize()                     # the copy that last read this pinned buffer has run
+        pinned[:n].numpy()[...] = idx
+        dev[:n].copy_(pinned[:n], non_blocking=True)
+        ev.record()
+        return dev[:n]
 
     def _elbo(self, want_grad, sync=True):
         h = self._handle
