@@ -115,14 +115,9 @@ __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t 
   }
 }
 
-__global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,
-                                                          const int* __restrict__ lds_, int* __restrict__ status,
-                                                          double* single_mat, int single_M, int single_ld, int panel_rows_cap,
-                                                          int pivot_base) {
-  const int b = blockIdx.x;
-  double* A = mats ? mats[b] : single_mat;
-  const int M = mats ? Ms[b] : single_M;
-  const int64_t ld = mats ? lds_[b] : single_ld;
+// Cholesky of one matrix by one workgroup (body shared by chol_kernel and chol_inverse_kernel)
+__device__ __forceinline__ void chol_body(double* __restrict__ A, const int M, const int64_t ld, int* __restrict__ status,
+                                          const int b, const int panel_rows_cap, const int pivot_base) {
   extern __shared__ __attribute__((aligned(16))) double chol_smem[];
   // [ D: 2 x 32 x 33 (inverse of the current / next diagonal factor) | P: panel X, (M-32) x 33 when it fits ]
   double (*D)[CH_NB][CH_NB + 1] = reinterpret_cast<double (*)[CH_NB][CH_NB + 1]>(chol_smem);
@@ -242,17 +237,17 @@ __global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restr
   }
 }
 
-// W = L^-1 (lower), one workgroup per matrix.
-__global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* const* __restrict__ Ls,
-                                                                 double* const* __restrict__ Ws,
-                                                                 const int* __restrict__ Ms,
-                                                                 const int* __restrict__ lds_, const double* single_L,
-                                                                 double* single_W, int single_M, int single_ld) {
+__global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,
+                                                          const int* __restrict__ lds_, int* __restrict__ status,
+                                                          double* single_mat, int single_M, int single_ld, int panel_rows_cap,
+                                                          int pivot_base) {
   const int b = blockIdx.x;
-  const double* L = Ls ? Ls[b] : single_L;
-  double* W = Ws ? Ws[b] : single_W;
-  const int M = Ls ? Ms[b] : single_M;
-  const int64_t ld = Ls ? lds_[b] : single_ld;
+  chol_body(mats ? mats[b] : single_mat, mats ? Ms[b] : single_M, mats ? (int64_t)lds_[b] : (int64_t)single_ld, status, b,
+            panel_rows_cap, pivot_base);
+}
+
+// W = L^-1 (lower) of one matrix by one workgroup (body shared by tri_inverse_kernel and chol_inverse_kernel).
+__device__ __forceinline__ void tri_inverse_body(const double* L, double* W, const int M, const int64_t ld) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int T = (M + CH_NB - 1) / CH_NB;
 
@@ -364,6 +359,33 @@ __global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* c
 
 // dynamic LDS: the two 32 x 33 inverse blocks plus, when it fits in 150 KiB, the whole panel below the first
 // diagonal block ((maxM - 32) rows x 33 doubles).  *cap = rows the panel buffer can hold (0 = operands from global).
+__global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* const* __restrict__ Ls,
+                                                                 double* const* __restrict__ Ws,
+                                                                 const int* __restrict__ Ms,
+                                                                 const int* __restrict__ lds_, const double* single_L,
+                                                                 double* single_W, int single_M, int single_ld) {
+  const int b = blockIdx.x;
+  tri_inverse_body(Ls ? Ls[b] : single_L, Ws ? Ws[b] : single_W, Ls ? Ms[b] : single_M,
+                   Ls ? (int64_t)lds_[b] : (int64_t)single_ld);
+}
+
+// Factor and invert in ONE launch: the workgroup of a matrix stays resident from the first pivot to the last block of
+// W.  Used when device-filling kernels (the Kuf strip builds) run beside the factorisation: a 512-thread,
+// 256-VGPR workgroup needs an empty CU, which a second launch would not get until those kernels have drained.
+__global__ void __launch_bounds__(CH_THREADS) chol_inverse_kernel(double* const* __restrict__ mats,
+                                                                  double* const* __restrict__ Ws,
+                                                                  const int* __restrict__ Ms, const int* __restrict__ lds_,
+                                                                  int* __restrict__ status, int panel_rows_cap) {
+  const int b = blockIdx.x;
+  double* A = mats[b];
+  const int M = Ms[b];
+  const int64_t ld = lds_[b];
+  chol_body(A, M, ld, status, b, panel_rows_cap, 0);
+  __threadfence();
+  __syncthreads();
+  tri_inverse_body(A, Ws[b], M, ld);
+}
+
 static size_t chol_smem_bytes(int maxM, int* cap) {
   const size_t dbytes = (size_t)2 * CH_NB * (CH_NB + 1) * sizeof(double);
   const int rows = maxM > CH_NB ? maxM - CH_NB : 0;
@@ -391,6 +413,23 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
   GP_CHECK(chol_set_attr(h));
   hipLaunchKernelGGL(chol_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_M, d_ld, h->d_status,
                      (double*)nullptr, 0, 0, cap, pivot_base);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+gp_status launch_cholesky_inverse_batched(gp_handle h, double* const* d_mats, double* const* d_W, const int* d_M,
+                                          const int* d_ld, int batch, int maxM) {
+  if (batch <= 0) return GP_OK;
+  GpTimerScope ts(h, GP_TIMER_CHOL);
+  int cap = 0;
+  size_t sh = chol_smem_bytes(maxM, &cap);
+  static std::atomic<bool> done{false};
+  if (!done.load(std::memory_order_acquire)) {
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    done.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(chol_inverse_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_W, d_M, d_ld, h->d_status,
+                     cap);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }

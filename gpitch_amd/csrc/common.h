@@ -24,7 +24,7 @@ struct gp_handle_s {
   GpLogisticTable logistic = {}; int num_logistic = 0;
   // helper stream for work that can overlap the main stream (the latency-bound Kuu factorisation runs on ~24 CUs
   // while the Kuf builds stream over the rest): created on first use, joined through events
-  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_era = nullptr;
+  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_era = nullptr, ev_kuu = nullptr;
   hipStream_t main_stream_saved = nullptr; bool aux_active = false, aux_pending = false;
   // timers
   bool timers_on = false;
@@ -169,6 +169,9 @@ gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld, int 
 size_t cholesky_large_workspace_bytes(int N);
 gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_t ld, void* ws, size_t ws_bytes);
 gp_status launch_tri_inverse_single(gp_handle h, const double* L, double* Linv, int M, int64_t ld);
+// Cholesky factor (in place) and its inverse in one launch, one resident workgroup per matrix
+gp_status launch_cholesky_inverse_batched(gp_handle h, double* const* d_mats, double* const* d_W, const int* d_M,
+                                          const int* d_ld, int batch, int maxM);
 gp_status launch_zero_upper_blocks_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
                                            int maxM, int nb);
 gp_status check_not_pd(gp_handle h);  // syncs; turns the device flag into GP_ERR_NOT_PD

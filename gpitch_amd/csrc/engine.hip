@@ -193,16 +193,18 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   return GP_OK;
 }
 
-// Kuu_g -> L_g (lower, in place) and W_g = L_g^-1 for the whole batch
-static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb) {
+// Kuu_g -> L_g (lower, in place) and W_g = L_g^-1 for the whole batch.
+// `resident`: device-filling kernels will run beside the factorisation (the Kuf strip builds of a long batch).  The
+// panel-blocked path is the faster one on an otherwise idle device, but each of its ~25 launches asks again for
+// whole CUs (512 threads x 256 VGPRs per workgroup) and gets them only when those kernels have drained; one launch
+// whose workgroups factor AND invert, started before them, keeps its CUs until it is done.
+static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb, bool resident) {
   const int G = (int)cb.tasks.size();
-  if (!cb.blocked) {
-    GP_CHECK(launch_cholesky_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
-                                     (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
-                                     cb.maxM));
-    return launch_tri_inverse_batched(h, (const double* const*)(cb.d_desc + cb.off_chol_ptrs),
-                                      (double* const*)(cb.d_desc + cb.off_w_ptrs),
-                                      (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G);
+  if (!cb.blocked || (resident && cb.maxM <= 512)) {
+    return launch_cholesky_inverse_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                           (double* const*)(cb.d_desc + cb.off_w_ptrs),
+                                           (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
+                                           cb.maxM);
   }
   const int* lds = (const int*)(cb.d_desc + cb.off_lds);
   // zero above the block diagonal of every W in one launch (the diagonal blocks are written whole, the blocks
@@ -250,6 +252,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   //    builds the Kuf strips (HBM / VALU-bound on all CUs); they meet again before A = W Kuf.
   // The host feeds both queues alternately (a Kuu build for the helper stream, a Kuf build for the main stream):
   // issuing all of one stream's launches first left the other queue waiting for the host for ~0.6 ms.
+  const bool resident = (N >= 4096);   // long batch: the strip builds fill the device (independent of the overlap level)
   const bool forked = !reuse_factor && (N >= 4096) && cb.overlap && gp_aux_fork(h);
   // one launch per kernel family for the Kuu builds (helper stream when forked) ...
   auto build_kuu = [&]() -> gp_status {
@@ -281,7 +284,14 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   gp_status st = GP_OK;
   if (!reuse_factor) {
     st = build_kuu();
-    if (st == GP_OK) st = cond_batch_factorize(h, cb);
+    // The Kuf builds (main stream) start only once the Kuu builds are through, i.e. together with the factorisation
+    // launch: its workgroups must be on their CUs before the strip builds fill the device.
+    if (forked && resident && st == GP_OK) {
+      if (!h->ev_kuu && hipEventCreateWithFlags(&h->ev_kuu, hipEventDisableTiming) != hipSuccess) h->ev_kuu = nullptr;
+      if (h->ev_kuu && hipEventRecord(h->ev_kuu, h->stream) == hipSuccess)
+        (void)hipStreamWaitEvent(h->main_stream_saved, h->ev_kuu, 0);
+    }
+    if (st == GP_OK) st = cond_batch_factorize(h, cb, resident);
   }
   if (forked) { gp_status s2 = gp_aux_end(h); if (st == GP_OK) st = s2; }
   GP_CHECK(st);
