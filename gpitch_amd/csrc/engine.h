@@ -75,6 +75,7 @@ struct CondBatch {
   // blocked Kuu factorisation (engine.hip: cond_batch_factorize)
   bool blocked = false; int nblk = 0;
   size_t off_blk_mats[8] = {0}, off_blk_w[8] = {0}, off_blk_M[8] = {0}, off_blk_gemm[8][4] = {{0}};
+  size_t off_diag_mats = 0, off_diag_w = 0, off_diag_M = 0, off_diag_ld = 0;   // all panels' diagonal blocks, one batch
 };
 
 size_t cond_task_workspace_doubles(int M, int N, int num_partials, bool whiten);

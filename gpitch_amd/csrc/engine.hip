@@ -54,6 +54,9 @@ size_t cond_batch_desc_bytes(int count) {
   // 4 GEMM problem arrays
   b += CB_MAX_PANELS * (2 * gp_align_up(count * sizeof(double*), 256) + gp_align_up(count * sizeof(int), 256) +
                         4 * gp_align_up(count * sizeof(GemmProblem), 256));
+  // ... and the diagonal blocks of all panels as one batch (2 pointer arrays, sizes, leading dimensions)
+  b += 2 * gp_align_up((size_t)CB_MAX_PANELS * count * sizeof(double*), 256) +
+       2 * gp_align_up((size_t)CB_MAX_PANELS * count * sizeof(int), 256);
   return b;
 }
 
@@ -186,6 +189,25 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
           r.A = t.W + dk; r.lda = ld; r.B = t.Tblk; r.ldb = ld; r.C = t.W + (int64_t)c0 * ld; r.ldc = ld; r.M = nb; r.N = c0; r.K = nb; }
       }
     }
+    // every panel's diagonal block of every GP as ONE batch (inverted in one launch after a whole-matrix factorisation)
+    cb.off_diag_mats = region((size_t)cb.nblk * G * sizeof(double*));
+    cb.off_diag_w = region((size_t)cb.nblk * G * sizeof(double*));
+    cb.off_diag_M = region((size_t)cb.nblk * G * sizeof(int));
+    cb.off_diag_ld = region((size_t)cb.nblk * G * sizeof(int));
+    {
+      double** dm = (double**)(cb.h_desc.data() + cb.off_diag_mats);
+      double** dw = (double**)(cb.h_desc.data() + cb.off_diag_w);
+      int* dM = (int*)(cb.h_desc.data() + cb.off_diag_M);
+      int* dl = (int*)(cb.h_desc.data() + cb.off_diag_ld);
+      for (int k = 0; k < cb.nblk; k++)
+        for (int g = 0; g < G; g++) {
+          const CondTask& t = cb.tasks[g];
+          const int c0 = k * CB_NB;
+          const int nb = (c0 >= t.M) ? 0 : ((t.M - c0 < CB_NB) ? t.M - c0 : CB_NB);
+          const int64_t dk = (nb > 0) ? (int64_t)c0 * t.M + c0 : 0;
+          dm[k * G + g] = t.L + dk; dw[k * G + g] = t.W + dk; dM[k * G + g] = nb; dl[k * G + g] = t.M;
+        }
+    }
     if (off > need) return gp_fail(h, GP_ERR_WORKSPACE, "descriptor workspace too small (blocked factorisation)");
   }
   GP_HIP_CHECK(h, hipMemcpyAsync(cb.d_desc, cb.h_desc.data(), need, hipMemcpyHostToDevice, h->stream));
@@ -193,18 +215,48 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   return GP_OK;
 }
 
+// blocks of W below the block diagonal, block row by block row: W[k, :c0] = -W_kk (L[k, :c0] W[:c0, :c0])
+static gp_status cond_batch_block_row_inverse(gp_handle h, CondBatch& cb) {
+  const int G = (int)cb.tasks.size();
+  for (int k = 1; k < cb.nblk; k++) {
+    const int c0 = k * CB_NB;
+    GemmFlags f;
+    f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][2]), G, CB_NB, c0, f));
+    f = GemmFlags();
+    f.triA = TRI_LOWER; f.alpha = -1.0;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][3]), G, CB_NB, c0, f));
+  }
+  return GP_OK;
+}
+
 // Kuu_g -> L_g (lower, in place) and W_g = L_g^-1 for the whole batch.
 // `resident`: device-filling kernels will run beside the factorisation (the Kuf strip builds of a long batch).  The
 // panel-blocked path is the faster one on an otherwise idle device, but each of its ~25 launches asks again for
-// whole CUs (512 threads x 256 VGPRs per workgroup) and gets them only when those kernels have drained; one launch
-// whose workgroups factor AND invert, started before them, keeps its CUs until it is done.
+// whole CUs (512 threads x 256 VGPRs per workgroup) and gets them only when those kernels have drained.  So the
+// factor comes from ONE launch, one workgroup per matrix, started before the strip builds and resident beside them;
+// the inverse (by then the builds are ending) goes the blocked way: all diagonal 128-blocks in one launch, the
+// blocks below them as batched GEMMs.
 static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb, bool resident) {
   const int G = (int)cb.tasks.size();
-  if (!cb.blocked || (resident && cb.maxM <= 512)) {
+  if (!cb.blocked) {
     return launch_cholesky_inverse_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
                                            (double* const*)(cb.d_desc + cb.off_w_ptrs),
                                            (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
                                            cb.maxM);
+  }
+  if (resident && cb.maxM <= 512) {
+    GP_CHECK(launch_cholesky_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
+                                     (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
+                                     cb.maxM));
+    GP_CHECK(launch_zero_upper_blocks_batched(h, (double* const*)(cb.d_desc + cb.off_w_ptrs),
+                                              (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G,
+                                              cb.maxM, CB_NB));
+    GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)(cb.d_desc + cb.off_diag_mats),
+                                        (double* const*)(cb.d_desc + cb.off_diag_w),
+                                        (const int*)(cb.d_desc + cb.off_diag_M), (const int*)(cb.d_desc + cb.off_diag_ld),
+                                        cb.nblk * G));
+    return cond_batch_block_row_inverse(h, cb);
   }
   const int* lds = (const int*)(cb.d_desc + cb.off_lds);
   // zero above the block diagonal of every W in one launch (the diagonal blocks are written whole, the blocks
@@ -229,16 +281,7 @@ static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb, bool resident)
   }
   GP_CHECK(launch_zero_upper_blocks_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
                                             (const int*)(cb.d_desc + cb.off_Ms), lds, G, cb.maxM, CB_NB));
-  for (int k = 1; k < cb.nblk; k++) {
-    const int c0 = k * CB_NB;
-    GemmFlags f;
-    f.triB = TRI_LOWER;
-    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][2]), G, CB_NB, c0, f));
-    f = GemmFlags();
-    f.triA = TRI_LOWER; f.alpha = -1.0;
-    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_blk_gemm[k][3]), G, CB_NB, c0, f));
-  }
-  return GP_OK;
+  return cond_batch_block_row_inverse(h, cb);
 }
 
 gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter,
