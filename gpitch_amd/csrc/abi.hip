@@ -247,7 +247,7 @@ gp_status gp_mpd_varexp(gp_handle h, const double* Fmu, const double* Fvar, cons
   if (!Fmu || !Fvar || !y || !noise_var || N < 0 || P < 1 || nlin < 0 || nlin > 2)
     return gp_fail(h, GP_ERR_BAD_ARG, "gp_mpd_varexp: bad argument");
   if (N == 0) { if (sum_host) *sum_host = 0.0; return GP_OK; }
-  int blocks = (N + 255) / 256;
+  int blocks = mpd_lik_blocks(N);
   double* partial = nullptr;
   if (sum_host) GP_HIP_CHECK(h, hipMallocAsync((void**)&partial, (2 * (size_t)blocks + 2) * sizeof(double), h->stream));
   int nb = 0;

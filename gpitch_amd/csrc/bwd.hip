@@ -827,9 +827,12 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
 // R = W^T (Lq Lq^T - I) and alpha = W^T q_mu depend on the parameters and on W only: when the helper stream exists they
 // are enqueued on it during the FORWARD pass, right behind the Kuu factorisation it has just run (no wait on the main
 // stream, which is busy with the forward GEMM strips), and the backward pass finds them ready.
-gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n) {
+// The whitened KL terms (parameters only) ride along: on the main stream they were one of five tiny kernels between
+// the last forward strip product and the first backward one, with the device idle around them.
+gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n, bool* kl_done) {
   gp_handle h = p->h;
   p->era_ready = false;
+  if (kl_done) *kl_done = false;
   if (!(p->whiten && p->nK > 0 && n >= 4096 && p->overlap >= 2 && h->aux_stream && !h->aux_active)) return GP_OK;
   if (!h->ev_era && hipEventCreateWithFlags(&h->ev_era, hipEventDisableTiming) != hipSuccess) { h->ev_era = nullptr; return GP_OK; }
   auto D = [&](int slot) { return (const GemmProblem*)(p->d_misc + p->off_bwd[slot]); };
@@ -844,6 +847,10 @@ gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n) {
   f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
   if (st == GP_OK) st = launch_gemm_batched(h, D(S_R), nK, maxM, maxM, f);
   if (st == GP_OK) st = launch_matvec_batched(h, D(S_ALPHA), nK, maxM, 1);
+  if (st == GP_OK && kl_done) {
+    st = launch_kl_white(h, p->d_misc + p->off_kl_items, p->G);
+    *kl_done = (st == GP_OK);
+  }
   hipError_t e = hipEventRecord(h->ev_era, h->aux_stream);
   h->stream = mainq;
   GP_CHECK(st);

@@ -235,6 +235,7 @@ gp_status launch_overlap_merge(gp_handle h, const double* y, int nw, int ws, int
 // lik.hip
 // whitened KL: each item writes GP_KL_BLOCKS partial sums to out[0..GP_KL_BLOCKS)
 #define GP_KL_BLOCKS 16
+int mpd_lik_blocks(int N);   // block partials (2 doubles each) one launch over N frames leaves
 gp_status launch_mpd_lik(gp_handle h, const double* Fmu, const double* Fvar, int64_t f_rs, int64_t f_cs,
                          const double* y, int N, int P, int nlin, const double* noise_var, double scale,
                          double* per_frame, double* partial_sums, int* num_partials_out,

@@ -6,7 +6,7 @@
 //           log_lik_exp                      gpitch/likelihoods.py:47-68
 //           gauss_kl (whitened)              gpitch/pdgp.py:120-121 (GPflow 0.5 kullback_leiblers)
 //           nonlinearities                   gpitch/methods.py:216-233
-// HBM-bound: one thread per audio frame, frame-contiguous reads of the 4P conditional moments,
+// Sixteen lanes per audio frame (one source each), reads of the 4P conditional moments,
 // block partial sums written to a scratch vector and finished in a fixed order (reproducible ELBO).
 #include "common.h"
 
@@ -69,8 +69,17 @@ __device__ __forceinline__ Quad gh_quad(int nlin, double mg, double vg, bool wan
   return q;
 }
 
-// One thread per frame.  Fmu/Fvar element (n, c) at [n * rs + c * cs]; columns [g_0..g_{P-1}, f_0..f_{P-1}].
+// Sixteen lanes per frame, one source (pitch) per lane (sources beyond 16 go round again): the 20-point
+// quadrature of a source — all the exp() work — is per (frame, source), while a frame's sums over its sources are
+// a handful of multiply-adds.  Each lane parks its a_i = E1_i m_f_i, E2_i and v_f_i + m_f_i^2 in LDS, then EVERY
+// lane of the frame replays the reference's sequential accumulation over i = 0..P-1 (same order, same fused
+// operations as a one-thread-per-frame loop), so the result does not depend on how sources are dealt to lanes.
+// Fmu/Fvar element (n, c) at [n * rs + c * cs]; columns [g_0..g_{P-1}, f_0..f_{P-1}].
 // partial[2*blk] = sum varexp * scale ; partial[2*blk+1] = sum d(varexp*scale)/d noise_var
+#define LIK_LANES 16
+#define LIK_FRAMES (LIK_THREADS / LIK_LANES)
+int mpd_lik_blocks(int N) { return (N + LIK_FRAMES - 1) / LIK_FRAMES; }
+
 __global__ void __launch_bounds__(LIK_THREADS) mpd_lik_kernel(const double* __restrict__ Fmu, const double* __restrict__ Fvar,
                                                               int64_t rs, int64_t cs, const double* __restrict__ y, int N,
                                                               int P, int nlin, const double* __restrict__ noise_var,
@@ -83,27 +92,47 @@ __global__ void __launch_bounds__(LIK_THREADS) mpd_lik_kernel(const double* __re
   //                  to psum[0..N), psum[N..2N), psum[2N..3N) and stop;
   //   gsum != NULL : the same three vectors summed over all ranks; the cross term becomes C = A^2 - D
   //                  (likelihoods.py:56-65 builds the same quantity as an explicit pair sum).
-  const int n = blockIdx.x * LIK_THREADS + threadIdx.x;
+  extern __shared__ double lik_sm[];                       // [LIK_FRAMES][3][P]: a_i | E2_i | v_f_i + m_f_i^2
+  const int fl = threadIdx.x / LIK_LANES, l = threadIdx.x % LIK_LANES;
+  const int n = blockIdx.x * LIK_FRAMES + fl;
+  double* sa = lik_sm + (size_t)fl * 3 * P;
+  double* se = sa + P;
+  double* sc = se + P;
+  const bool live = (n < N);
+  const bool need_pass1 = (!gsum || psum);
+  const bool need_grad = (gFmu != nullptr) && !psum;
   const double s2 = noise_var[0];
+  Quad q0 = {0, 0, 0, 0, 0, 0};      // this lane's first source, kept for the gradient pass
+  bool cached = false;
+  if (live && need_pass1) {
+    for (int i = l; i < P; i += LIK_LANES) {
+      const double mg = Fmu[n * rs + i * cs], vg = Fvar[n * rs + i * cs];
+      const double mf = Fmu[n * rs + (i + P) * cs], vf = Fvar[n * rs + (i + P) * cs];
+      const bool keep = need_grad && (i == l);
+      Quad q = gh_quad(nlin, mg, vg, keep);
+      if (keep) { q0 = q; cached = true; }
+      sa[i] = q.E1 * mf;
+      se[i] = q.E2;
+      sc[i] = vf + mf * mf;
+    }
+  }
+  __syncthreads();
   double ve = 0.0, dnoise = 0.0;
-  if (n < N) {
+  if (live) {
     const double Y = y[n];
-    // pass 1: A, B, C (C as the reference's pair sum 2*sum_{i<j} a_i a_j, accumulated with a running prefix)
+    // A, B, C (C as the reference's pair sum 2*sum_{i<j} a_i a_j, accumulated with a running prefix)
     double A = 0.0, B = 0.0, Cpair = 0.0, D = 0.0;
-    if (!gsum || psum) {
+    if (need_pass1) {
       for (int i = 0; i < P; i++) {
-        const double mg = Fmu[n * rs + i * cs], vg = Fvar[n * rs + i * cs];
-        const double mf = Fmu[n * rs + (i + P) * cs], vf = Fvar[n * rs + (i + P) * cs];
-        Quad q = gh_quad(nlin, mg, vg, false);
-        const double a = q.E1 * mf;
+        const double a = sa[i];
         Cpair = fma(a, A, Cpair);  // a_i * sum_{j<i} a_j
         D = fma(a, a, D);
         A += a;
-        B = fma(q.E2, vf + mf * mf, B);
+        B = fma(se[i], sc[i], B);
       }
     }
     double C = 2.0 * Cpair;
-    if (psum) {
+    if (psum && l == 0) {
       psum[n] = A; psum[(int64_t)N + n] = B; psum[2 * (int64_t)N + n] = D;
     }
     if (gsum) {
@@ -113,15 +142,15 @@ __global__ void __launch_bounds__(LIK_THREADS) mpd_lik_kernel(const double* __re
     const double resid = Y * Y - 2.0 * Y * A + B + C;
     const double LOG2PI = 1.8378770664093453;
     const double v = -0.5 * ((1.0 / s2) * resid + LOG2PI + log(s2));
-    if (per_frame) per_frame[n] = v;
-    ve = v * scale;
-    if (gFmu && !psum) {
-      dnoise = scale * (0.5 * resid / (s2 * s2) - 0.5 / s2);
+    if (per_frame && l == 0) per_frame[n] = v;
+    if (l == 0) ve = v * scale;
+    if (need_grad) {
+      if (l == 0) dnoise = scale * (0.5 * resid / (s2 * s2) - 0.5 / s2);
       const double qf = -0.5 * scale / s2;
-      for (int i = 0; i < P; i++) {
+      for (int i = l; i < P; i += LIK_LANES) {
         const double mg = Fmu[n * rs + i * cs], vg = Fvar[n * rs + i * cs];
         const double mf = Fmu[n * rs + (i + P) * cs], vf = Fvar[n * rs + (i + P) * cs];
-        Quad q = gh_quad(nlin, mg, vg, true);
+        const Quad q = (cached && i == l) ? q0 : gh_quad(nlin, mg, vg, true);
         const double a = q.E1 * mf;
         const double da = qf * (-2.0 * Y + 2.0 * (A - a));  // d/d a_i
         const double dE1 = da * mf;
@@ -154,8 +183,10 @@ gp_status launch_mpd_lik(gp_handle h, const double* Fmu, const double* Fvar, int
                          double* gFvar, double* psum, const double* gsum) {
   if (N <= 0) { if (num_partials_out) *num_partials_out = 0; return GP_OK; }
   GpTimerScope ts(h, GP_TIMER_LIK);
-  int blocks = (N + LIK_THREADS - 1) / LIK_THREADS;
-  hipLaunchKernelGGL(mpd_lik_kernel, dim3(blocks), dim3(LIK_THREADS), 0, h->stream, Fmu, Fvar, f_rs, f_cs, y, N, P,
+  const int blocks = mpd_lik_blocks(N);
+  const size_t sh = (size_t)LIK_FRAMES * 3 * P * sizeof(double);
+  if (sh > 48 * 1024) return gp_fail(h, GP_ERR_UNSUPPORTED, "too many sources for the likelihood kernel's LDS staging");
+  hipLaunchKernelGGL(mpd_lik_kernel, dim3(blocks), dim3(LIK_THREADS), sh, h->stream, Fmu, Fvar, f_rs, f_cs, y, N, P,
                      nlin, noise_var, scale, per_frame, partial_sums, gFmu, gFvar, psum, gsum);
   GP_HIP_CHECK(h, hipGetLastError());
   if (num_partials_out) *num_partials_out = blocks;

@@ -112,7 +112,7 @@ size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   auto addd = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   for (int i = 0; i < 4; i++) addd((size_t)p->G * p->maxN);
   addd((size_t)p->G * GP_KL_BLOCKS);
-  addd(2 * ((size_t)(p->maxN + 255) / 256) + 8);
+  addd(2 * (size_t)mpd_lik_blocks(p->maxN) + 8);
   if (!p->whiten)
     for (int g = 0; g < p->G; g++) addd((size_t)gemm_rowblocks(p->gps[g].M, 0) * p->gps[g].M);
   {
@@ -142,7 +142,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
   p->gFmu = ar.take<double>((size_t)p->G * p->maxN);
   p->gFvar = ar.take<double>((size_t)p->G * p->maxN);
   p->kl = ar.take<double>((size_t)p->G * GP_KL_BLOCKS);
-  p->lik_partials = ar.take<double>(2 * ((size_t)(p->maxN + 255) / 256) + 8);
+  p->lik_partials = ar.take<double>(2 * (size_t)mpd_lik_blocks(p->maxN) + 8);
   for (int g = 0; g < p->G; g++) {
     CondTask& t = p->cb.tasks[g];
     t.M = p->gps[g].M;
@@ -199,7 +199,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
 }  // extern "C"
 
 gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad);  // bwd.hip
-gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n);
+gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n, bool* kl_done);
 gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad);
 
 // (re)bind the parameter vector / batch to the device descriptors
@@ -260,13 +260,15 @@ static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double
   GP_CHECK(pdgp_bind(p, params, x, n, grad, p->fmean, p->fvar));
   if (grad) GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
   GP_CHECK(cond_batch_run(h, p->cb, x, n, p->whiten != 0, p->jitter));
-  if (grad) GP_CHECK(pdgp_prefetch_backward(p, n));
+  bool kl_done = false;   // the whitened KL kernel went to the helper stream with the backward prefetch
+  if (grad) GP_CHECK(pdgp_prefetch_backward(p, n, &kl_done));
+  if (kl_done) GP_HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_era, 0));   // behind the forward strips: no stall
   if (xchg) {
     GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, 1.0, nullptr, nullptr, nullptr,
                             nullptr, nullptr, xchg, nullptr));
   }
   if (p->whiten) {
-    GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl_items, p->G));
+    if (!kl_done) GP_CHECK(launch_kl_white(h, p->d_misc + p->off_kl_items, p->G));
   } else {
     // gauss_kl(q_mu, q_sqrt, K = Kuu + jitter I) (pdgp.py:123-129): L and W of the conditional are reused
     // (one value per GP: the other partial-sum slots of the whitened layout stay zero)
