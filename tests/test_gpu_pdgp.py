@@ -436,12 +436,14 @@ def test_predictions_reuse_factorisation_and_memoise(gp_handle):
                                             fv.data_ptr(), None))
 
 
-def test_blocked_kuu_factorisation_with_partial_last_panel(gp_handle):
+@pytest.mark.parametrize("N", [900, 4200])
+def test_blocked_kuu_factorisation_with_partial_last_panel(gp_handle, N):
     """M > 256 switches the Kuu batch to the panel-blocked Cholesky + inverse (engine.hip: cond_batch_factorize);
-    M = 300 leaves a 44-column last panel.  ELBO and gradients against the oracle (cond(Kuu) ~ 1e9 here, so the
-    comparison carries cond * eps on both sides)."""
+    M = 300 leaves a 44-column last panel.  N = 900: every panel through the batched GEMMs; N = 4200 (a long batch,
+    the Kuf builds fill the device): whole-matrix factor in one resident launch, then the blocked inverse.  ELBO and
+    gradients against the oracle (cond(Kuu) ~ 1e9 here, so the comparison carries cond * eps on both sides)."""
     from gpitch_amd.synth import make_problem
-    prob = make_problem(900, 300, 1, num_partials=3, seed=6)
+    prob = make_problem(N, 300, 1, num_partials=3, seed=6)
     model = pdgp_from_problem(prob, handle=gp_handle)
     model._pack()
     f = model._elbo(True)
@@ -465,11 +467,13 @@ def test_blocked_kuu_factorisation_with_partial_last_panel(gp_handle):
     np.testing.assert_allclose(ma[0], rm, rtol=0, atol=1e-6 * np.abs(rm).max())
 
 
-def test_overlap_levels_give_identical_results(gp_handle):
+@pytest.mark.parametrize("N,M,P", [(4096, 48, 2), (4200, 300, 1)])
+def test_overlap_levels_give_identical_results(gp_handle, N, M, P):
     """gp_pdgp_set_overlap changes only the schedule (helper-stream fork / join points); the ELBO and every gradient
-    entry must come out bit for bit the same at every level (batches of >= 4096 frames are the ones that fork)."""
+    entry must come out bit for bit the same at every level (batches of >= 4096 frames are the ones that fork;
+    M = 300 takes the resident-factor + blocked-inverse route, chosen by N and M alone)."""
     from gpitch_amd.synth import make_problem
-    prob = make_problem(4096, 48, 2, num_partials=3, seed=13)
+    prob = make_problem(N, M, P, num_partials=3, seed=13)
     ref = None
     for level in (0, 1, 2, 1, 0):
         m = pdgp_from_problem(prob, handle=gp_handle)
