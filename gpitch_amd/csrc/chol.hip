@@ -375,15 +375,18 @@ __global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* c
 __global__ void __launch_bounds__(CH_THREADS) chol_inverse_kernel(double* const* __restrict__ mats,
                                                                   double* const* __restrict__ Ws,
                                                                   const int* __restrict__ Ms, const int* __restrict__ lds_,
-                                                                  int* __restrict__ status, int panel_rows_cap) {
+                                                                  int* __restrict__ status, int panel_rows_cap,
+                                                                  double* single_mat, double* single_W, int single_M,
+                                                                  int single_ld) {
   const int b = blockIdx.x;
-  double* A = mats[b];
-  const int M = Ms[b];
-  const int64_t ld = lds_[b];
+  double* A = mats ? mats[b] : single_mat;
+  double* W = mats ? Ws[b] : single_W;
+  const int M = mats ? Ms[b] : single_M;
+  const int64_t ld = mats ? (int64_t)lds_[b] : (int64_t)single_ld;
   chol_body(A, M, ld, status, b, panel_rows_cap, 0);
   __threadfence();
   __syncthreads();
-  tri_inverse_body(A, Ws[b], M, ld);
+  tri_inverse_body(A, W, M, ld);
 }
 
 static size_t chol_smem_bytes(int maxM, int* cap) {
@@ -417,19 +420,37 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
   return GP_OK;
 }
 
+static gp_status chol_inverse_set_attr(gp_handle h) {
+  static std::atomic<bool> done{false};
+  if (!done.load(std::memory_order_acquire)) {
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    done.store(true, std::memory_order_release);
+  }
+  return GP_OK;
+}
+
 gp_status launch_cholesky_inverse_batched(gp_handle h, double* const* d_mats, double* const* d_W, const int* d_M,
                                           const int* d_ld, int batch, int maxM) {
   if (batch <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_CHOL);
   int cap = 0;
   size_t sh = chol_smem_bytes(maxM, &cap);
-  static std::atomic<bool> done{false};
-  if (!done.load(std::memory_order_acquire)) {
-    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    done.store(true, std::memory_order_release);
-  }
+  GP_CHECK(chol_inverse_set_attr(h));
   hipLaunchKernelGGL(chol_inverse_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_W, d_M, d_ld, h->d_status,
-                     cap);
+                     cap, (double*)nullptr, (double*)nullptr, 0, 0);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// one matrix: A -> L in place, W = L^-1, one launch (the window-sized SGPR problems are chains of dependent launches)
+gp_status launch_cholesky_inverse_single(gp_handle h, double* A, double* W, int M, int64_t ld) {
+  if (M <= 0) return GP_OK;
+  GpTimerScope ts(h, GP_TIMER_CHOL);
+  int cap = 0;
+  size_t sh = chol_smem_bytes(M, &cap);
+  GP_CHECK(chol_inverse_set_attr(h));
+  hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(CH_THREADS), sh, h->stream, (double* const*)nullptr,
+                     (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, h->d_status, cap, A, W, M, (int)ld);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }

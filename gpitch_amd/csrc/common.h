@@ -172,6 +172,7 @@ gp_status launch_tri_inverse_single(gp_handle h, const double* L, double* Linv, 
 // Cholesky factor (in place) and its inverse in one launch, one resident workgroup per matrix
 gp_status launch_cholesky_inverse_batched(gp_handle h, double* const* d_mats, double* const* d_W, const int* d_M,
                                           const int* d_ld, int batch, int maxM);
+gp_status launch_cholesky_inverse_single(gp_handle h, double* A, double* W, int M, int64_t ld);
 gp_status launch_zero_upper_blocks_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
                                            int maxM, int nb);
 gp_status check_not_pd(gp_handle h);  // syncs; turns the device flag into GP_ERR_NOT_PD

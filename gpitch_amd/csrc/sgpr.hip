@@ -299,8 +299,7 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
     DevKern k = sg_kern(p, params, i);
     GP_CHECK(launch_kernel_build(h, k, Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, p->feat));
   }
-  GP_CHECK(launch_cholesky_single(h, p->L, M, M));
-  GP_CHECK(launch_tri_inverse_single(h, p->L, p->W, M, M));
+  GP_CHECK(launch_cholesky_inverse_single(h, p->L, p->W, M, M));
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
     GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat));
@@ -320,8 +319,7 @@ static gp_status sgpr_global(gp_sgpr_plan p, const double* params, int Ntotal, c
   gp_handle h = p->h;
   const int M = p->M;
   hipLaunchKernelGGL(sgpr_B_kernel, dim3(64), dim3(256), 0, h->stream, p->H, p->LB, M, params);
-  GP_CHECK(launch_cholesky_single(h, p->LB, M, M));
-  GP_CHECK(launch_tri_inverse_single(h, p->LB, p->WB, M, M));
+  GP_CHECK(launch_cholesky_inverse_single(h, p->LB, p->WB, M, M));
   hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->WB, p->LB, p->u, p->c, M, Ntotal, params,
                      p->P, desc->toff, desc->ktype, desc->km, p->reg, p->scal);
   GP_HIP_CHECK(h, hipGetLastError());
