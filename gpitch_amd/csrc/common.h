@@ -155,7 +155,7 @@ static inline DevKern dev_kern(const gp_kernel_desc* k) { return DevKern{k->type
 
 // cov.hip
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
-                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws);
+                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws, int feat_ready = 0);
 size_t kernel_build_feat_ws_doubles(int m, int n1, int n2);
 int sm_mpad(int m);  // spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded)
 gp_status launch_kernel_diag(gp_handle h, DevKern k, int n, double* out, int accumulate);

@@ -240,7 +240,8 @@ static void launch_mercer(gp_handle h, dim3 grid, DevKern k, const double* x1, i
 }
 
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
-                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws) {
+                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws, int feat_ready) {
+  // feat_ready: the feature tables in feat_ws (layout of launch_sm_features: x1 block, then x2 block) are current
   if (n1 <= 0 || n2 <= 0) return GP_OK;
   if (x2 == nullptr) { x2 = x1; n2 = n1; }
   const int vec_ok = ((ld % 2) == 0) && ((((uintptr_t)out) & 15) == 0);
@@ -254,8 +255,9 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
     double* f1 = feat_ws;
     double* f2 = (x2 == x1) ? f1 : feat_ws + gp_align_up((size_t)2 * mp * n1, 32);
     dim3 g1((n1 + 255) / 256, mp);
-    hipLaunchKernelGGL(sm_features_kernel, g1, dim3(256), 0, h->stream, k, x1, n1, f1, mp, (const FeatItem*)nullptr);
-    if (x2 != x1) {
+    if (!feat_ready)
+      hipLaunchKernelGGL(sm_features_kernel, g1, dim3(256), 0, h->stream, k, x1, n1, f1, mp, (const FeatItem*)nullptr);
+    if (x2 != x1 && !feat_ready) {
       dim3 g2((n2 + 255) / 256, mp);
       hipLaunchKernelGGL(sm_features_kernel, g2, dim3(256), 0, h->stream, k, x2, n2, f2, mp, (const FeatItem*)nullptr);
     }

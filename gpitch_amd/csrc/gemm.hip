@@ -578,6 +578,9 @@ int gemm_nt_nsplit(int M, int Nlong, int batch) {
   tiles = tiles * (tiles + 1) / 2 * (batch > 0 ? batch : 1);
   int want = (2048 + tiles - 1) / tiles;
   int maxs = (Nlong + 511) / 512;
+  // a window-sized problem (one tile, a few thousand frames) would be 4 workgroups of 32 K-tiles each: latency, not
+  // throughput — slices down to 128 deep then
+  if ((int64_t)tiles * maxs < 256) maxs = (Nlong + 127) / 128;
   int s = want < maxs ? want : maxs;
   if (s < 2) s = 2;
   if (s > 64) s = 64;

@@ -163,6 +163,12 @@ __global__ void __launch_bounds__(256) predict_finish_kernel(const double* __res
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
+// Each kernel of the sum keeps its own (Z | X) feature table for a whole bound + gradient evaluation: built once in
+// the forward pass, read by the Kuu build, the Kuf build and both hyper-gradient contractions.
+static size_t sgpr_feat_stride(const gp_sgpr_plan_s* p) {
+  return gp_align_up(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, p->M, p->maxN), 32);
+}
+
 static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
@@ -170,7 +176,7 @@ static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   const int rb = gemm_rowblocks(p->M, 1);
   for (int i = 0; i < 5; i++) add(M * M);           // L, W, H, LB, WB
   add(M * ld); add(M * ld);                          // Kuf, A
-  add(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, p->M, p->maxN));
+  add(sgpr_feat_stride(p) * p->P);                   // one feature table per kernel of the sum
   add((size_t)rb * p->maxN); add((size_t)rb * p->maxN); add((size_t)rb * p->maxN);
   add(M); add(M); add(64);
   add((size_t)p->nsplit * M * M);
@@ -227,7 +233,7 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   p->L = ar.take<double>(M * M); p->W = ar.take<double>(M * M); p->H = ar.take<double>(M * M);
   p->LB = ar.take<double>(M * M); p->WB = ar.take<double>(M * M);
   p->Kuf = ar.take<double>(M * ld); p->A = ar.take<double>(M * ld);
-  p->feat = ar.take<double>(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, p->M, p->maxN));
+  p->feat = ar.take<double>(sgpr_feat_stride(p) * p->P);
   p->s1 = ar.take<double>((size_t)rb * p->maxN); p->s2 = ar.take<double>((size_t)rb * p->maxN);
   p->dot = ar.take<double>((size_t)rb * p->maxN);
   p->u = ar.take<double>(M); p->c = ar.take<double>(M); p->scal = ar.take<double>(64);
@@ -297,12 +303,14 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   // Kuu, Kuf: GPflow Add kernel = sum over kern_list (sgpr_ss.py:42-43)
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
-    GP_CHECK(launch_kernel_build(h, k, Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, p->feat));
+    double* feat = p->feat + (size_t)i * sgpr_feat_stride(p);
+    GP_CHECK(launch_sm_features(h, k, Z, M, X, N, feat));
+    GP_CHECK(launch_kernel_build(h, k, Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, feat, 1));
   }
   GP_CHECK(launch_cholesky_inverse_single(h, p->L, p->W, M, M));
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
-    GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat));
+    GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat + (size_t)i * sgpr_feat_stride(p), 1));
   }
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ;
     GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
@@ -469,17 +477,13 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
   // every kernel of the sum sees the same Kuf_bar / Kuu_bar (K = sum_p K_p)
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
-    // the feature tables hold the LAST kernel built: rebuild this kernel's (Z and X) before contracting
-    if (gp_kern_is_mercer(k.type)) {
-      // cheap: two feature passes; the covariance values themselves are not needed again
-      GP_CHECK(launch_sm_features(h, k, Z, M, X, N, p->feat));
-    }
+    double* feat = p->feat + (size_t)i * sgpr_feat_stride(p);   // this kernel's (Z | X) features, from the forward pass
     int np_uf = 0, np_uu = 0;
-    GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, p->feat, p->hyp, &np_uf, nullptr));
+    GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, feat, p->hyp, &np_uf, nullptr));
     GP_CHECK(launch_hyper_finish(h, k, p->hyp, np_uf, include_replicated ? p->scal + 4 : nullptr, grad + p->off_theta[i],
                                  nullptr, 0, M, nullptr));
     if (include_replicated) {
-      GP_CHECK(launch_hyper_contract(h, k, Z, M, Z, M, p->E2, M, nullptr, nullptr, 1, p->feat, p->hyp_uu, &np_uu, nullptr));
+      GP_CHECK(launch_hyper_contract(h, k, Z, M, Z, M, p->E2, M, nullptr, nullptr, 1, feat, p->hyp_uu, &np_uu, nullptr));
       GP_CHECK(launch_hyper_finish(h, k, p->hyp_uu, np_uu, nullptr, grad + p->off_theta[i], nullptr, 0, M, nullptr));
     }
   }
