@@ -67,13 +67,14 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
                                                                 int accumulate, double diag_add,
                                                                 const double* __restrict__ f1,
                                                                 const double* __restrict__ f2, int vec_ok,
-                                                                const CovItem* __restrict__ items) {
+                                                                const CovItem* __restrict__ items, int wg_rows) {
+  // wg_rows: rows handled per workgroup (<= COV_ROWS; fewer for small matrices, which otherwise occupy a handful of CUs)
   if (items) {
     const CovItem it = items[blockIdx.z];
     k = it.k; x1 = it.x1; n1 = it.n1; out = it.out; ld = it.ld;
     if (it.n2 >= 0) { x2 = it.x2; n2 = it.n2; }         // n2 < 0: every item shares the launch's x2 / n2 (the frames)
     accumulate = it.accumulate; diag_add = it.diag_add; f1 = it.f1; f2 = it.f2; vec_ok = it.vec_ok;
-    if ((int)(blockIdx.y * COV_ROWS) >= n1) return;     // the grid is sized for the largest item
+    if ((int)(blockIdx.y * wg_rows) >= n1) return;       // the grid is sized for the largest item
   }
   extern __shared__ double smem[];  // MODE 1: z-features for this block's rows [COV_ROWS][2m]
   __shared__ double row_a[COV_ROWS];  // x1[i] / lengthscale (the exact quotient, computed once per row, not per entry)
@@ -84,19 +85,19 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   const double ls = th[1];
   const int m = k.m;
   const int j0 = (blockIdx.x * COV_THREADS + threadIdx.x) * CPT;
-  const int i0 = blockIdx.y * COV_ROWS;
-  const int iend = min(i0 + COV_ROWS, n1);
+  const int i0 = blockIdx.y * wg_rows;
+  const int iend = min(i0 + wg_rows, n1);
   // K(x, x) + diag_add I: only the workgroups whose column range meets their row range carry the diagonal test
   const int jb0 = blockIdx.x * COV_THREADS * CPT;
-  const bool self_cov = (x2 == x1) && (diag_add != 0.0) && (jb0 < i0 + COV_ROWS) && (jb0 + COV_THREADS * CPT > i0);
+  const bool self_cov = (x2 == x1) && (diag_add != 0.0) && (jb0 < i0 + wg_rows) && (jb0 + COV_THREADS * CPT > i0);
 
-  if (threadIdx.x < COV_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / th[1] : 0.0;
+  if (threadIdx.x < COV_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / th[1] : 0.0;   // (rows beyond wg_rows unused)
   if (MODE != 1) __syncthreads();
   if (MODE == 1) {
     // stage this block's row features: smem[(i - i0) * 2*MPAD + q] = f1[q][i]
     for (int t = threadIdx.x; t < COV_ROWS * 2 * MPAD; t += COV_THREADS) {
       int q = t / COV_ROWS, ii = t % COV_ROWS;
-      smem[ii * 2 * MPAD + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
+      smem[ii * 2 * MPAD + q] = (ii < wg_rows && i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
     }
     __syncthreads();
   }
@@ -229,14 +230,23 @@ size_t kernel_build_feat_ws_doubles(int m, int n1, int n2) {
 template <int MPAD>
 static void launch_mercer(gp_handle h, dim3 grid, DevKern k, const double* x1, int n1, const double* x2, int n2,
                           double* out, int64_t ld, int accumulate, double diag_add, const double* f1, const double* f2,
-                          int vec_ok, const CovItem* items) {
+                          int vec_ok, const CovItem* items, int rows = COV_ROWS) {
   size_t sh = (size_t)COV_ROWS * 2 * MPAD * sizeof(double);
   if (k.type == GP_KERN_MERCER_MATERN12SM)
     hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 0>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
-                       ld, accumulate, diag_add, f1, f2, vec_ok, items);
+                       ld, accumulate, diag_add, f1, f2, vec_ok, items, rows);
   else
     hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 2>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
-                       ld, accumulate, diag_add, f1, f2, vec_ok, items);
+                       ld, accumulate, diag_add, f1, f2, vec_ok, items, rows);
+}
+
+// rows per workgroup: the full COV_ROWS for strips; small matrices (window-sized problems, Kuu) get more, smaller
+// workgroups — a 64 x 2001 build is otherwise 8 workgroups on a 256-CU device
+static int cov_rows_for(int n1, int n2) {
+  const int64_t e = (int64_t)n1 * n2;
+  if (e >= (1 << 20)) return COV_ROWS;
+  if (e >= (1 << 17)) return 8;
+  return 4;
 }
 
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
@@ -261,26 +271,29 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
       dim3 g2((n2 + 255) / 256, mp);
       hipLaunchKernelGGL(sm_features_kernel, g2, dim3(256), 0, h->stream, k, x2, n2, f2, mp, (const FeatItem*)nullptr);
     }
-    dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
+    const int rows = cov_rows_for(n1, n2);
+    dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + rows - 1) / rows);
     switch (mp) {
-      case 4: launch_mercer<4>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
-      case 8: launch_mercer<8>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
-      case 12: launch_mercer<12>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
-      case 16: launch_mercer<16>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
-      case 20: launch_mercer<20>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
-      case 24: launch_mercer<24>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
-      case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
-      default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr); break;
+      case 4: launch_mercer<4>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      case 8: launch_mercer<8>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      case 12: launch_mercer<12>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      case 16: launch_mercer<16>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      case 20: launch_mercer<20>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      case 24: launch_mercer<24>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
     }
   } else if (gp_kern_is_broadcast(k.type)) {
     if (k.m < 1) return gp_fail(h, GP_ERR_BAD_ARG, "num_partials must be >= 1");
-    dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + COV_ROWS - 1) / COV_ROWS);
+    const int rows = cov_rows_for(n1, n2);
+    dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + rows - 1) / rows);
     hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
-                       accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr);
+                       accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr, rows);
   } else if (k.type >= GP_KERN_MATERN12 && k.type <= GP_KERN_RBF) {
-    dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + COV_ROWS - 1) / COV_ROWS);
+    const int rows = cov_rows_for(n1, n2);
+    dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + rows - 1) / rows);
 #define COV_STAT(T) hipLaunchKernelGGL((cov_build_kernel<0, 2, 1, T>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, \
-                                      x2, n2, out, ld, accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr)
+                                      x2, n2, out, ld, accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr, rows)
     switch (k.type) {
       case GP_KERN_MATERN12: COV_STAT(GP_KERN_MATERN12); break;
       case GP_KERN_MATERN32: COV_STAT(GP_KERN_MATERN32); break;
@@ -439,12 +452,12 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
     dim3 grid((max_n2 + COV_THREADS - 1) / COV_THREADS, (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
     hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k0, (const double*)nullptr, 0,
                        x2_shared, n2_shared, (double*)nullptr, (int64_t)0, 0, 0.0, (const double*)nullptr,
-                       (const double*)nullptr, 0, d_items);
+                       (const double*)nullptr, 0, d_items, COV_ROWS);
   } else {
     dim3 grid((max_n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
 #define COV_STAT_ITEMS(T) hipLaunchKernelGGL((cov_build_kernel<0, 2, 1, T>), grid, dim3(COV_THREADS), 0, h->stream, k0, \
                                             (const double*)nullptr, 0, x2_shared, n2_shared, (double*)nullptr,             \
-                                            (int64_t)0, 0, 0.0, (const double*)nullptr, (const double*)nullptr, 0, d_items)
+                                            (int64_t)0, 0, 0.0, (const double*)nullptr, (const double*)nullptr, 0, d_items, COV_ROWS)
     switch (type) {
       case GP_KERN_MATERN12: COV_STAT_ITEMS(GP_KERN_MATERN12); break;
       case GP_KERN_MATERN32: COV_STAT_ITEMS(GP_KERN_MATERN32); break;
