@@ -129,10 +129,20 @@ gp_status launch_matvec_batched(gp_handle h, const GemmProblem* d, int batch, in
 #define HY_ROWS 32
 
 int hyper_num_sums(int m) { return 2 + 2 * m; }
+// rows of x1 per workgroup: HY_ROWS for the strips; small contractions (window-sized problems, the Kuu side) get
+// more, smaller workgroups (a 64 x 2001 contraction is otherwise 16 workgroups on a 256-CU device)
+#define HY_ROWS_SMALL 8
+static int hy_rows_for(int n1, int n2) { return ((int64_t)n1 * n2 >= (1 << 20)) ? HY_ROWS : HY_ROWS_SMALL; }
+// partial records one contraction of an M x N problem can leave (any N' <= N: the plan is sized for its largest batch)
 size_t hyper_kuf_records(int N, int M) {
   const size_t generic = ((size_t)(N + HY_THREADS - 1) / HY_THREADS + 1) * ((size_t)(M + HY_ROWS - 1) / HY_ROWS + 1);
   const size_t mfma = (size_t)(N + 63) / 64 + 1;       // hyper_sm_mfma_kernel: one record per 64 columns
-  return generic > mfma ? generic : mfma;
+  // small form: only while M * N' < 2^20
+  const int64_t nsmall = (M > 0) ? (((int64_t)1 << 20) + M - 1) / M : 0;
+  const int64_t ncap = nsmall < N ? nsmall : N;
+  const size_t small = ((size_t)(ncap + HY_THREADS - 1) / HY_THREADS + 1) * ((size_t)(M + HY_ROWS_SMALL - 1) / HY_ROWS_SMALL + 1);
+  size_t r = generic > mfma ? generic : mfma;
+  return r > small ? r : small;
 }
 
 // MPAD = spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded, so the
@@ -147,14 +157,14 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
                                                                     const double* __restrict__ f1,
                                                                     const double* __restrict__ f2,
                                                                     double* __restrict__ partials,
-                                                                    double* __restrict__ gz_part) {
+                                                                    double* __restrict__ gz_part, int wg_rows) {
   extern __shared__ double smem[];  // [HY_ROWS][2*MPAD] row features | omega[MPAD] | reduction scratch
   const double* th = k.theta;
   const double var = th[0], ls = th[1];
   const int m = k.m;
   const int j = blockIdx.x * HY_THREADS + threadIdx.x;
-  const int i0 = blockIdx.y * HY_ROWS;
-  const int iend = min(i0 + HY_ROWS, n1);
+  const int i0 = blockIdx.y * wg_rows;             // wg_rows <= HY_ROWS rows of x1 per workgroup
+  const int iend = min(i0 + wg_rows, n1);
   double* fzs = smem;
   __shared__ double etab[GP_EXP_TAB];  // 2^(j/64) for gp_exp_neg
   gp_exp_tab_init(etab);
@@ -165,7 +175,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   if (SM) {
     for (int t = threadIdx.x; t < HY_ROWS * 2 * MPAD; t += HY_THREADS) {
       int q = t / HY_ROWS, ii = t % HY_ROWS;
-      fzs[ii * 2 * MPAD + q] = (i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
+      fzs[ii * 2 * MPAD + q] = (ii < wg_rows && i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
     }
     if ((int)threadIdx.x < MPAD) omega[threadIdx.x] = ((int)threadIdx.x < m) ? 6.283185307179586 * th[2 + m + threadIdx.x] : 0.0;
   }
@@ -256,7 +266,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
   }
   if (GZ) {
     __syncthreads();
-    if (threadIdx.x < HY_ROWS && i0 + (int)threadIdx.x < n1) {
+    if ((int)threadIdx.x < wg_rows && i0 + (int)threadIdx.x < n1) {
       const int t = threadIdx.x;
       double s = (red[0 * HY_ROWS + t] + red[1 * HY_ROWS + t]) + (red[2 * HY_ROWS + t] + red[3 * HY_ROWS + t]);
       gz_part[(int64_t)blockIdx.x * n1 + i0 + t] = symmetric ? 2.0 * s : s;
@@ -447,7 +457,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
                                                                  const double* __restrict__ alpha,
                                                                  const double* __restrict__ gm, int symmetric,
                                                                  double* __restrict__ partials,
-                                                                 double* __restrict__ gz_part) {
+                                                                 double* __restrict__ gz_part, int wg_rows) {
   extern __shared__ double smem[];   // e[m] | omega[m] | reduction scratch [4][max(2+2m, HY_ROWS)]
   const double* th = k.theta;
   const double var = th[0], ls = th[1];
@@ -461,8 +471,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
   }
   __syncthreads();
   const int j = blockIdx.x * HY_THREADS + threadIdx.x;
-  const int i0 = blockIdx.y * HY_ROWS;
-  const int iend = min(i0 + HY_ROWS, n1);
+  const int i0 = blockIdx.y * wg_rows;             // wg_rows <= HY_ROWS rows of x1 per workgroup
+  const int iend = min(i0 + wg_rows, n1);
   const bool live = (j < n2);
   const int jc = live ? j : n2 - 1;
   const double xb = x2[jc];
@@ -521,7 +531,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
   }
   if (GZ) {
     __syncthreads();
-    if (threadIdx.x < HY_ROWS && i0 + (int)threadIdx.x < n1) {
+    if ((int)threadIdx.x < wg_rows && i0 + (int)threadIdx.x < n1) {
       const int t = threadIdx.x;
       double s = (red[0 * HY_ROWS + t] + red[1 * HY_ROWS + t]) + (red[2 * HY_ROWS + t] + red[3 * HY_ROWS + t]);
       gz_part[(int64_t)blockIdx.x * n1 + i0 + t] = symmetric ? 2.0 * s : s;
@@ -552,13 +562,13 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
 template <int MPAD, bool SM, int KT = -1>
 static void launch_hyper_t(gp_handle h, dim3 grid, size_t sh, DevKern k, const double* x1, int n1, const double* x2,
                            int n2, const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
-                           const double* f1, const double* f2, double* partials, double* gz) {
+                           const double* f1, const double* f2, double* partials, double* gz, int wg_rows) {
   if (gz)
     hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, true, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2,
-                       n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz);
+                       n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows);
   else
     hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, false, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1,
-                       x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz);
+                       x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows);
 }
 
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
@@ -566,17 +576,18 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
                                 const double* feat, double* partials, int* nparts, double* gz_partials,
                                 const double* kvals, int64_t ldk) {
   GpTimerScope ts(h, GP_TIMER_HYPER);
+  const int wg_rows = hy_rows_for(n1, n2);
   if (gp_kern_is_broadcast(k.type)) {
-    dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + HY_ROWS - 1) / HY_ROWS);
+    dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + wg_rows - 1) / wg_rows);
     const int ns = 2 + 2 * k.m;
     const int redw = ns > HY_ROWS ? ns : HY_ROWS;
     const size_t sh = (2 * (size_t)k.m + 4 * (size_t)redw) * sizeof(double);
     if (gz_partials)
       hipLaunchKernelGGL((hyper_m12sm_kernel<true>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                         alpha, gm, symmetric, partials, gz_partials);
+                         alpha, gm, symmetric, partials, gz_partials, wg_rows);
     else
       hipLaunchKernelGGL((hyper_m12sm_kernel<false>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                         alpha, gm, symmetric, partials, gz_partials);
+                         alpha, gm, symmetric, partials, gz_partials, wg_rows);
     GP_HIP_CHECK(h, hipGetLastError());
     if (nparts) *nparts = grid.x * grid.y;
     return GP_OK;
@@ -585,7 +596,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
   const int mp = sm ? sm_mpad(k.m) : 0;
   const double* f1 = feat;
   const double* f2 = (x2 == x1 || !feat) ? feat : feat + gp_align_up((size_t)2 * mp * n1, 32);
-  dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + HY_ROWS - 1) / HY_ROWS);
+  dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + wg_rows - 1) / wg_rows);
   const int ns = 2 + 2 * k.m;
   const int redw = ns > HY_ROWS ? ns : HY_ROWS;
   size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
@@ -609,7 +620,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     if (nparts) *nparts = gridm.x;
     return GP_OK;
   }
-#define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials
+#define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials, wg_rows
   if (!sm) switch (k.type) {
     case GP_KERN_MATERN12: launch_hyper_t<1, false, GP_KERN_MATERN12>(h, HY_ARGS); break;
     case GP_KERN_MATERN32: launch_hyper_t<1, false, GP_KERN_MATERN32>(h, HY_ARGS); break;

@@ -15,9 +15,9 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
     add(M * (size_t)ldN_of64(p->maxN));
     add(M); add(M); add(M); add((size_t)65 * M);
     const size_t ns = hyper_num_sums(p->gps[g].m);
-    const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
+    const size_t colblocks = (p->maxN + 255) / 256 + 1;
     add(ns * hyper_kuf_records(p->maxN, (int)M));
-    add(ns * ((M + 255) / 256 + 1) * rowblocks);
+    add(ns * hyper_kuf_records((int)M, (int)M));
     add(colblocks * M + ((M + 255) / 256 + 1) * M);
   }
   add(p->G + 8);
@@ -165,9 +165,9 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       b.u = ar.take<double>(M); b.Lu = ar.take<double>(M); b.alpha = ar.take<double>(M);
       b.upart = ar.take<double>((size_t)p->nsplit * M);
       const size_t ns = hyper_num_sums(p->gps[g].m);
-      const size_t colblocks = (p->maxN + 255) / 256 + 1, rowblocks = (M + 31) / 32 + 1;
+      const size_t colblocks = (p->maxN + 255) / 256 + 1;
       b.hyp_part = ar.take<double>(ns * hyper_kuf_records(p->maxN, (int)M));
-      b.hyp_part_uu = ar.take<double>(ns * ((M + 255) / 256 + 1) * rowblocks);
+      b.hyp_part_uu = ar.take<double>(ns * hyper_kuf_records((int)M, (int)M));
       b.gz_part = ar.take<double>(colblocks * M + ((M + 255) / 256 + 1) * M);
     }
     {  // sum_n gv per GP, contiguous so one launch fills all of them

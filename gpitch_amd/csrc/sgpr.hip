@@ -184,8 +184,8 @@ static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   add(M * ld); add(M); add(M); add(M); add(p->maxN);
   {
     const size_t ns = hyper_num_sums(p->maxm);
-    add(ns * ((p->maxN + 255) / 256 + 1) * ((M + 31) / 32 + 1));
-    add(ns * ((M + 255) / 256 + 1) * ((M + 31) / 32 + 1));
+    add(ns * hyper_kuf_records(p->maxN, (int)M));
+    add(ns * hyper_kuf_records((int)M, (int)M));
   }
   return d;
 }
@@ -244,8 +244,8 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   p->ones = ar.take<double>(p->maxN);
   {
     const size_t ns = hyper_num_sums(p->maxm);
-    p->hyp = ar.take<double>(ns * ((p->maxN + 255) / 256 + 1) * ((M + 31) / 32 + 1));
-    p->hyp_uu = ar.take<double>(ns * ((M + 255) / 256 + 1) * ((M + 31) / 32 + 1));
+    p->hyp = ar.take<double>(ns * hyper_kuf_records(p->maxN, (int)M));
+    p->hyp_uu = ar.take<double>(ns * hyper_kuf_records((int)M, (int)M));
   }
   if (!ar.ok) return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: arena exhausted");
   p->ws = workspace; p->ws_bytes = bytes;
