@@ -13,6 +13,9 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef GP_COV_NT_STORE
+#define GP_COV_NT_STORE 1
+#endif
 #define COV_THREADS 256
 #define COV_ROWS 32  // rows (inducing points) handled per block
 
@@ -195,7 +198,8 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
       if (CPT == 2 && vec_ok && j0 + 1 < n2) {
         double2 v = make_double2(res[0], res[CPT - 1]);
         if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
-        *reinterpret_cast<double2*>(o) = v;
+        if (GP_COV_NT_STORE && !accumulate) { __builtin_nontemporal_store(v.x, o); __builtin_nontemporal_store(v.y, o + 1); }
+        else *reinterpret_cast<double2*>(o) = v;
       } else {
   #pragma unroll
         for (int c = 0; c < CPT; c++)
