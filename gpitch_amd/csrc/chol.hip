@@ -389,6 +389,45 @@ __global__ void __launch_bounds__(CH_THREADS) chol_inverse_kernel(double* const*
   tri_inverse_body(A, W, M, ld);
 }
 
+// Matrices of at most 64 rows (the window-sized SGPR problems, small inducing sets): the whole factor + inverse runs on
+// a copy in LDS.  The bodies above take generic pointers, so they are simply handed LDS addresses (flat accesses to
+// the LDS aperture): every dependent step — pivot, panel, update, the substitution chain of the inverse — then waits
+// on an LDS round trip instead of an L2 one.
+#define CHS_M 64
+#define CHS_LD (CHS_M + 1)
+#define CHS_OFF (2 * CH_NB * (CH_NB + 1) + (CHS_M - CH_NB) * (CH_NB + 1))     // chol_body's own D | P region
+#define CHS_DOUBLES (CHS_OFF + 2 * CHS_M * CHS_LD)
+__global__ void __launch_bounds__(CH_THREADS) chol_inverse_lds_kernel(double* const* __restrict__ mats,
+                                                                      double* const* __restrict__ Ws,
+                                                                      const int* __restrict__ Ms, const int* __restrict__ lds_,
+                                                                      int* __restrict__ status, double* single_mat,
+                                                                      double* single_W, int single_M, int single_ld) {
+  extern __shared__ __attribute__((aligned(16))) double chol_smem[];
+  const int b = blockIdx.x;
+  double* A = mats ? mats[b] : single_mat;
+  double* W = mats ? Ws[b] : single_W;
+  const int M = mats ? Ms[b] : single_M;
+  const int64_t ld = mats ? (int64_t)lds_[b] : (int64_t)single_ld;
+  double* Al = chol_smem + CHS_OFF;
+  double* Wl = Al + CHS_M * CHS_LD;
+  for (int idx = threadIdx.x; idx < M * M; idx += CH_THREADS) {
+    const int i = idx / M, j = idx % M;
+    Al[i * CHS_LD + j] = A[(int64_t)i * ld + j];
+  }
+  __syncthreads();
+  chol_body(Al, M, CHS_LD, status, b, CHS_M - CH_NB, 0);
+  __threadfence_block();
+  __syncthreads();
+  tri_inverse_body(Al, Wl, M, CHS_LD);
+  __threadfence_block();
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < M * M; idx += CH_THREADS) {
+    const int i = idx / M, j = idx % M;
+    A[(int64_t)i * ld + j] = Al[i * CHS_LD + j];
+    W[(int64_t)i * ld + j] = Wl[i * CHS_LD + j];
+  }
+}
+
 static size_t chol_smem_bytes(int maxM, int* cap) {
   const size_t dbytes = (size_t)2 * CH_NB * (CH_NB + 1) * sizeof(double);
   const int rows = maxM > CH_NB ? maxM - CH_NB : 0;
@@ -423,6 +462,8 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
 static gp_status chol_inverse_set_attr(gp_handle h) {
   static std::atomic<bool> done{false};
   if (!done.load(std::memory_order_acquire)) {
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_inverse_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(CHS_DOUBLES * sizeof(double))));
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     done.store(true, std::memory_order_release);
   }
@@ -436,8 +477,12 @@ gp_status launch_cholesky_inverse_batched(gp_handle h, double* const* d_mats, do
   int cap = 0;
   size_t sh = chol_smem_bytes(maxM, &cap);
   GP_CHECK(chol_inverse_set_attr(h));
-  hipLaunchKernelGGL(chol_inverse_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_W, d_M, d_ld, h->d_status,
-                     cap, (double*)nullptr, (double*)nullptr, 0, 0);
+  if (maxM <= CHS_M)
+    hipLaunchKernelGGL(chol_inverse_lds_kernel, dim3(batch), dim3(CH_THREADS), CHS_DOUBLES * sizeof(double), h->stream, d_mats,
+                       d_W, d_M, d_ld, h->d_status, (double*)nullptr, (double*)nullptr, 0, 0);
+  else
+    hipLaunchKernelGGL(chol_inverse_kernel, dim3(batch), dim3(CH_THREADS), sh, h->stream, d_mats, d_W, d_M, d_ld, h->d_status,
+                       cap, (double*)nullptr, (double*)nullptr, 0, 0);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -449,8 +494,13 @@ gp_status launch_cholesky_inverse_single(gp_handle h, double* A, double* W, int 
   int cap = 0;
   size_t sh = chol_smem_bytes(M, &cap);
   GP_CHECK(chol_inverse_set_attr(h));
-  hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(CH_THREADS), sh, h->stream, (double* const*)nullptr,
-                     (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, h->d_status, cap, A, W, M, (int)ld);
+  if (M <= CHS_M)
+    hipLaunchKernelGGL(chol_inverse_lds_kernel, dim3(1), dim3(CH_THREADS), CHS_DOUBLES * sizeof(double), h->stream,
+                       (double* const*)nullptr, (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                       h->d_status, A, W, M, (int)ld);
+  else
+    hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(CH_THREADS), sh, h->stream, (double* const*)nullptr,
+                       (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, h->d_status, cap, A, W, M, (int)ld);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
