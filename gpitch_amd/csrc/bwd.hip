@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
       acc_l = fma(w, var * e * r2 * inv_ls, acc_l);
       if (GZ) dz = -w * var * e * d * inv_ls2;
     } else {
-      const double r = gp_sqrt_pos(__dadd_rn(r2, 1e-12));
+      double r, rinv;   // sqrt and reciprocal sqrt from one rsq: no float64 division in the row loop
+      gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), r, rinv);
       if (SM) {
         // envelope phi(r) and phi'(r): Matern-1/2 (MercerMatern12sm) or Matern-5/2 (Matern52 * MercerCosMix)
         double E, dE;
@@ -239,7 +240,6 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
           acc_f[q] = fma(wd, ss, acc_f[q]);
           if (GZ) Ssin = fma(ss, omega[q], Ssin);
         }
-        const double rinv = 1.0 / r;
         acc_v = fma(w * E, S, acc_v);
         acc_l = fma(-wvD * S, r2 * rinv * inv_ls, acc_l);
         if (GZ) dz = wvD * S * d * inv_ls2 * rinv - wvE * Ssin;
@@ -253,7 +253,6 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
           const double s5 = 2.23606797749979, e = gp_exp_neg(-s5 * r, etab);
           phi = (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e; dphi = -(5.0 / 3.0) * r * (1.0 + s5 * r) * e;
         }
-        const double rinv = 1.0 / r;
         acc_v = fma(w, phi, acc_v);
         acc_l = fma(w * var * dphi, -r2 * rinv * inv_ls, acc_l);
         if (GZ) dz = w * var * dphi * d * inv_ls2 * rinv;
@@ -383,7 +382,8 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
       const double kv = on ? kvv[ks] : 0.0;
       const double a = rowa[li], aa = __dmul_rn(a, a);
       const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, bsc), aa), bb);
-      const double r = gp_sqrt_pos(__dadd_rn(r2, 1e-12));
+      double r, rinv;     // r and 1 / r from one rsq (no float64 division in the row loop of the Matern-1/2 profile)
+      gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), r, rinv);
       double E, nratio;   // phi(r) and -phi'(r)/phi(r)
       if (m12) { E = gp_exp_neg(-r, etab); nratio = 1.0; }
       else {
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
       const double wvE = w * var * E, wd = wvE * (rowx[li] - xb);
       const double wk = w * kv;
       acc_v += wk;
-      acc_l = fma(wk * nratio, r2 * inv_ls / r, acc_l);
+      acc_l = fma(wk * nratio, (r2 * inv_ls) * rinv, acc_l);
       // A fragment of tile t: A[f = 16 t + lc][k = kq] = zf[row ks*4 + kq][16 t + lc]
 #pragma unroll
       for (int t = 0; t < NT; t++) {

@@ -75,6 +75,21 @@ __device__ __forceinline__ double gp_sqrt_pos(double x) {
   d = fma(-g, g, x);
   return fma(d, h, g);
 }
+// sqrt(x) and 1/sqrt(x) together (same argument range): the reciprocal costs one more correction step instead of a
+// float64 division (~20 instructions) wherever a kernel needs both r and something / r.
+__device__ __forceinline__ void gp_sqrt_rsqrt_pos(double x, double& s, double& rinv) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  double r = h + h;
+  r = fma(fma(-g, r, 1.0), r, r);
+  s = g; rinv = r;
+}
 // table for gp_exp_neg: tab[j] = 2^(j/64), j < 64 (filled per workgroup into LDS by gp_exp_tab_init)
 #define GP_EXP_TAB 64
 __device__ __forceinline__ void gp_exp_tab_init(double* tab) {
