@@ -202,8 +202,8 @@ gp_status gp_kuu_cholesky(gp_handle h, const gp_kernel_desc* kern, const double*
   double* feat = gp_kern_is_mercer(k.type) ? ar.take<double>(kernel_build_feat_ws_doubles(k.m, M, M)) : nullptr;
   if (!ar.ok || !Lbuf) return gp_fail(h, GP_ERR_WORKSPACE, "gp_kuu_cholesky: workspace too small");
   GP_CHECK(launch_kernel_build(h, k, z, M, nullptr, M, Lbuf, M, 0, jitter, feat));
-  GP_CHECK(launch_cholesky_single(h, Lbuf, M, M));
-  if (Linv) GP_CHECK(launch_tri_inverse_single(h, Lbuf, Linv, M, M));
+  if (Linv) GP_CHECK(launch_cholesky_inverse_single(h, Lbuf, Linv, M, M));   // one launch (on an LDS copy for M <= 64)
+  else GP_CHECK(launch_cholesky_single(h, Lbuf, M, M));
   return check_not_pd(h);
 }
 

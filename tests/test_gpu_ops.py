@@ -250,3 +250,21 @@ def test_overlap_merge_on_device_matches_host(gp_handle, ws, nw):
     bad = gp_handle.empty(nw, ws)
     with pytest.raises(Exception):
         gp_handle.check(gp_handle.lib.gp_overlap_merge(gp_handle.h, bad.data_ptr(), nw, ws, ws, n + 1, 0, bad.data_ptr()))
+
+
+@pytest.mark.parametrize("M", [40, 200])
+def test_kuu_cholesky_with_inverse_reports_not_pd(gp_handle, M):
+    """the one-launch factor + inverse (LDS copy for M <= 64, global otherwise) reports a bad pivot like the plain
+    factorisation: a kernel with a negative variance gives -K, not positive definite at the first pivot"""
+    from gpitch_amd import _lib
+    h = gp_handle
+    kern = dict(KERNELS[1])
+    kern["variance"] = -1.0
+    z = np.linspace(0, 2.0, M).reshape(-1, 1)
+    d, th = _desc(h, kern)
+    dz = h.to_device(z)
+    L, W = h.empty(M, M), h.empty(M, M)
+    ws = h.workspace(h.lib.gp_chol_workspace_bytes(M))
+    st = h.lib.gp_kuu_cholesky(h.h, C.byref(d), dz.data_ptr(), M, 1e-6, L.data_ptr(), W.data_ptr(), ws.data_ptr(), ws.numel())
+    assert st == _lib.GP_ERR_NOT_PD
+    assert h.lib.gp_last_not_pd_index(h.h) == 0
