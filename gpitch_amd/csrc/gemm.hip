@@ -35,6 +35,9 @@ typedef const dbl2 __attribute__((address_space(1))) * gcptr2;
 // wavefronts per SIMD); the other roles lose more to the extra LDS reads and staging than they gain.
 constexpr int gemm_threads(int BM, int TAG) { return (BM == 128 && TAG == 2) ? 512 : 256; }
 #define GEMM_BK 16
+#ifndef GP_MFMA_PRIO
+#define GP_MFMA_PRIO 2
+#endif
 
 struct GemmDevFlags {
   int triA, triB, triC;
@@ -348,6 +351,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
       if (triA == TRI_LOWER) full = (kt <= rowbase);
       if (triA == TRI_UPPER) full = (kt >= rowbase + 16 * TM - 16);
       if (full) {
+        __builtin_amdgcn_s_setprio(GP_MFMA_PRIO);
 #pragma unroll
         for (int ks = 0; ks < GEMM_BK / 4; ks++) {
           const int k = ks * 4 + kq;
@@ -369,6 +373,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
               if (!PERM || a >= cmin[b])   // symmetric diagonal tile: upper MFMA tiles are never read
                 acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
       } else {
 #pragma unroll
         for (int ks = 0; ks < GEMM_BK / 4; ks++) {
