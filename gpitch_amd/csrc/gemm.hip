@@ -375,6 +375,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
         }
         __builtin_amdgcn_s_setprio(0);
       } else {
+        __builtin_amdgcn_s_setprio(GP_MFMA_PRIO);
 #pragma unroll
         for (int ks = 0; ks < GEMM_BK / 4; ks++) {
           const int k = ks * 4 + kq;
@@ -403,6 +404,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
             }
           }
         }
+        __builtin_amdgcn_s_setprio(0);
       }
       if (more) store_tiles(buf ^ 1, kt + GEMM_BK);
       __syncthreads();
