@@ -1,139 +1,143 @@
-"""Inducing-point initialisers — gpitch/init_models.py:9-71 (host numpy, O(N))."""
+"""Inducing-point and kernel initialisers: the host-side producers of the (z, kern) every caller hands to the hot path.
+
+Own numpy implementations of the behaviour of gpitch/init_models.py (init_liv :9-51, init_iv :54-71,
+init_kernel_training :74-89, init_kernel_with_trained_models :92-121, get_features :154-180, init_kern :183-198),
+quirks included; pinned by tests/test_host_init.py against the oracle's restatement and against the one anchor the
+reference prints (109 inducing points on its demo recording, demos/notebooks/demo_modgp-real-audio.ipynb:88,116).
+"""
 import numpy as np
 from scipy import signal
 
 
-def _hann(n):
-    # scipy.signal.hann of the reference's era == scipy.signal.windows.hann (symmetric)
-    return signal.windows.hann(n)
+def _hann_average(sig, width):
+    """`sig` smoothed by a unit-gain symmetric Hann window of `width` taps (scipy's 'same' convolution, as the
+    reference calls it at init_models.py:19-20,24-25)."""
+    taps = signal.windows.hann(width)
+    return signal.convolve(sig, taps, mode="same") / taps.sum()
+
+
+def _turning_points(sig):
+    """indices i where the slope of `sig` changes sign between samples i and i+1 (peaks, valleys, flat edges)"""
+    slope_sign = np.sign(np.gradient(sig))
+    return np.flatnonzero(slope_sign[1:] != slope_sign[:-1])
 
 
 def init_liv(x, y, num_sources=1, win_size=9, thres=0.0025, dec=1):
-    """Initialize location of inducing variables from the extrema of the data (init_models.py:9-51).
+    """Inducing inputs at the extrema of the (Hann-smoothed) signal.
 
-    Faithful to the reference including its quirk at :38-43: `np.argsort` is applied to the *tuple*
-    returned by np.where, which yields [[0..k-1]] — so the first k extrema are returned (k = number
-    above the energy threshold), not the k above threshold."""
-    x = x.reshape(-1, )
-    y = y.reshape(-1, )
-    win1 = _hann(1600)
-    energy = signal.convolve(np.abs(y), win1, mode='same') / sum(win1)
-    energy /= np.max(energy)
-    win2 = _hann(win_size)
-    y_smooth = signal.convolve(y, win2, mode='same') / sum(win2)
-    f_sign = np.sign(np.gradient(y_smooth))
-    f_change_sign = np.diff(f_sign)
-    idx = np.where(f_change_sign)
-    x_all = x[idx].copy()
-    y_all = y[idx].copy()
-    energy_all = energy[idx].copy()
-    idx1 = np.where(energy_all > thres)
-    idx3 = np.argsort(idx1)
-    x_final = x_all[idx3].copy().reshape(-1, 1)
-    y_final = y_all[idx3].copy().reshape(-1, 1)
-    za, zc = [], []
-    for i in range(num_sources):
-        za.append(x_final[::dec].copy())
-        zc.append(x_final[::dec].copy())
-    return [za, zc], y_final[::dec]
+    Returns ([za, zc], u): per source a copy of the (k', 1) extremum locations for the activation and for the
+    component GP, and the signal values there.  The envelope threshold only sets HOW MANY extrema are kept: the
+    reference applies argsort to the tuple np.where returns (init_models.py:38-43), which enumerates 0..k-1, so the
+    result is the FIRST k turning points in time (k = number whose normalised envelope exceeds `thres`), then every
+    `dec`-th of those.  Reproduced deliberately: the published 109-point demo depends on it."""
+    t = np.asarray(x).reshape(-1)
+    s = np.asarray(y).reshape(-1)
+    envelope = _hann_average(np.abs(s), 1600)
+    envelope = envelope / envelope.max()
+    turns = _turning_points(_hann_average(s, win_size))
+    k = int(np.count_nonzero(envelope[turns] > thres))
+    keep = turns[:k][::dec]
+    loc = t[keep].reshape(-1, 1)
+    z = [[loc.copy() for _ in range(num_sources)] for _role in ("activation", "component")]
+    return z, s[keep].reshape(-1, 1)
+
+
+def _every_kth_plus_last(x, stride):
+    x = np.asarray(x)
+    return np.concatenate([x[::stride], x[-1:]], axis=0)
 
 
 def init_iv(x, num_sources, nivps_a, nivps_c, fs):
-    """Uniform inducing variables (init_models.py:54-71); Python-2 integer division made explicit."""
-    za, zc = [], []
-    dec_a = int(fs // nivps_a)
-    dec_c = int(fs // nivps_c)
-    for i in range(num_sources):
-        za.append(np.vstack([x[::dec_a].copy(), x[-1].copy()]))
-        zc.append(np.vstack([x[::dec_c].copy(), x[-1].copy()]))
+    """Uniform inducing inputs: `nivps_a` (`nivps_c`) per second for the activations (components), i.e. every
+    (fs // nivps)-th sample — the reference's Python-2 integer division — with the final sample appended (so the
+    last point can repeat the grid's last one).  (init_models.py:54-71)"""
+    za = [_every_kth_plus_last(x, int(fs // nivps_a)) for _ in range(num_sources)]
+    zc = [_every_kth_plus_last(x, int(fs // nivps_c)) for _ in range(num_sources)]
     return [za, zc]
 
 
 def init_kernel_training(y, list_files, fs, maxh=25):
-    """init_models.py:74-89: one (Matern12 activation, Matern32sm component) pair per training file, the
-    component initialised from the note's spectrum."""
+    """Per training recording: a Matern12(l=1, v=3.5) activation kernel and a Matern32sm component kernel whose
+    partial frequencies / variances are the spectral peaks of that recording (methods.init_cparam), held fixed.
+    Returns ([kern_act, kern_com], per-recording init_cparam results).  (init_models.py:74-89)"""
     from .kernels import Matern12, Matern32sm
     from .methods import find_ideal_f0, init_cparam
-    num_pitches = len(list_files)
-    if0 = find_ideal_f0(list_files)
-    iparam, kern_act, kern_com = [], [], []
-    for i in range(num_pitches):
-        iparam.append(init_cparam(y[i], fs=fs, maxh=maxh, ideal_f0=if0[i]))
-        kern_act.append(Matern12(1, lengthscales=1., variance=3.5))
-        kern_com.append(Matern32sm(1, num_partials=len(iparam[i][1]), lengthscales=1., variances=iparam[i][1],
-                                   frequencies=iparam[i][0]))
-        kern_com[i].vars_n_freqs_fixed()
-    return [kern_act, kern_com], iparam
+    pitches = find_ideal_f0(list_files)
+    spectra = [init_cparam(y[i], fs=fs, maxh=maxh, ideal_f0=pitches[i]) for i in range(len(list_files))]
+    kern_act = [Matern12(1, lengthscales=1., variance=3.5) for _ in spectra]
+    kern_com = []
+    for sp in spectra:
+        k = Matern32sm(1, num_partials=len(sp[1]), lengthscales=1., variances=sp[1], frequencies=sp[0])
+        k.vars_n_freqs_fixed()
+        kern_com.append(k)
+    return [kern_act, kern_com], spectra
+
+
+def _copy_value(p):
+    return np.array(p.value, copy=True)
 
 
 def init_kernel_with_trained_models(m, option_two=False):
-    """init_models.py:92-121: kernels of the multi-pitch model from the per-pitch trained models `m`."""
+    """Kernels of the multi-pitch model from single-pitch models `m` trained beforehand: partial frequencies and
+    variances are taken over (variances fixed, frequencies trainable), the envelope hyper-parameters either copied
+    from the trained model or, with `option_two`, set to l_act=0.5, v_act=4, l_com=1.  (init_models.py:92-121)"""
     from .kernels import Matern12, Matern32sm
     kern_act, kern_com = [], []
-    num_sources = len(m)
-    for i in range(num_sources):
-        num_p = m[i].kern_com[0].num_partials
-        kern_act.append(Matern12(1))
-        kern_com.append(Matern32sm(1, num_partials=num_p))
-        kern_act[i].fixed = True
-        kern_com[i].fixed = True
-        kern_com[i].vars_n_freqs_fixed(fix_var=True, fix_freq=False)
+    for trained in m:
+        src_act, src_com = trained.kern_act[0], trained.kern_com[0]
+        act = Matern12(1)
+        com = Matern32sm(1, num_partials=src_com.num_partials)
+        com.fixed = True
+        com.vars_n_freqs_fixed(fix_var=True, fix_freq=False)
         if option_two:
-            kern_act[i].lengthscales = 0.5
-            kern_act[i].variance = 4.0
-            kern_com[i].lengthscales = 1.0
+            act.lengthscales, act.variance, com.lengthscales = 0.5, 4.0, 1.0
         else:
-            kern_act[i].lengthscales = m[i].kern_act[0].lengthscales.value.copy()
-            kern_act[i].variance = m[i].kern_act[0].variance.value.copy()
-            kern_com[i].lengthscales = m[i].kern_com[0].lengthscales.value.copy()
-        kern_act[i].fixed = False
-        kern_com[i].lengthscales.fixed = False
-        for j in range(num_p):
-            kern_com[i].frequency[j].value = m[i].kern_com[0].frequency[j].value.copy()
-            kern_com[i].variance[j].value = m[i].kern_com[0].variance[j].value.copy()
+            act.lengthscales = _copy_value(src_act.lengthscales)
+            act.variance = _copy_value(src_act.variance)
+            com.lengthscales = _copy_value(src_com.lengthscales)
+        act.fixed = False
+        com.lengthscales.fixed = False
+        for j in range(src_com.num_partials):
+            com.frequency[j].value = _copy_value(src_com.frequency[j])
+            com.variance[j].value = _copy_value(src_com.variance[j])
+        kern_act.append(act)
+        kern_com.append(com)
     return [kern_act, kern_com]
 
 
 def get_features(f, s, f_centers, nfpc, use_centers, totalnumf):
-    """Get kernel features (parameters) from FFT of training data (init_models.py:154-180)"""
-    if use_centers:
-        var_l, freq_l = [], []
-        for i in range(f_centers.size):
-            idx = np.argmin(np.abs(f - f_centers[i]))
-            if nfpc == 1:
-                freq_l.append(f[idx: idx + 1])
-                var_l.append(s[idx: idx + 1])
-            else:
-                freq_l.append(f[idx - nfpc // 2: idx + nfpc // 2])
-                var_l.append(s[idx - nfpc // 2: idx + nfpc // 2])
-        frequency = np.asarray(freq_l).reshape(-1, 1)
-        energy = np.asarray(var_l).reshape(-1, 1)
-        energy = energy / sum(energy)
-    else:
-        num_features = totalnumf
-        idx = np.flip(np.argsort(np.log(s)), axis=0)
-        ssorted = s[idx].copy()
-        fsorted = f[idx].copy()
-        energy = ssorted[0:num_features].copy()
-        energy /= np.sum(energy)
-        frequency = fsorted[0:num_features].copy()
-    return frequency, energy
+    """(frequency, energy) features of a component kernel from a spectrum (f, s).  With `use_centers`: the `nfpc`
+    bins around the bin nearest each centre (nfpc // 2 either side; a single bin for nfpc == 1), as (n, 1) columns;
+    otherwise the `totalnumf` strongest bins.  Energies are normalised to sum 1.  (init_models.py:154-180)"""
+    f, s = np.asarray(f), np.asarray(s)
+    if not use_centers:
+        strongest = np.argsort(np.log(s))[::-1][:totalnumf]
+        energy = s[strongest].copy()
+        return f[strongest].copy(), energy / np.sum(energy)
+    centres = np.asarray(f_centers).reshape(-1)
+    nearest = np.abs(f[None, :] - centres[:, None]).argmin(axis=1)
+    lo, hi = (0, 1) if nfpc == 1 else (-(nfpc // 2), nfpc // 2)
+    # (the reference slices f[idx + lo : idx + hi]; a centre closer than nfpc // 2 bins to the start gives the same
+    # empty or wrapped slice here)
+    freq = np.asarray([f[i + lo:i + hi] for i in nearest]).reshape(-1, 1)
+    energy = np.asarray([s[i + lo:i + hi] for i in nearest]).reshape(-1, 1)
+    return freq, energy / sum(energy)
 
 
 def init_kern(num_pitches, energy, frequency):
-    """Initialize kernels for activations and components (init_models.py:183-198): Matern32 activations and
-    Matern52 * MercerCosMix components (Matern52 variance fixed, lengthscale ~ Logistic(0, 0.5); the cosine
-    mixture fixed)."""
+    """Older multi-pitch model: Matern32(l=0.25, v=3.5) activations; components Matern52 x MercerCosMix with the
+    Matern52 variance fixed at 1, its lengthscale confined to (0, 0.5) by a Logistic transform, and the cosine
+    mixture (variance 0.25, given energies / frequencies) entirely fixed.  (init_models.py:183-198)"""
     from .kernels import Matern32, Matern52, MercerCosMix
     from .param import transforms
-    k_act, k_com = [], []
-    for i in range(num_pitches):
-        k_act.append(Matern32(1, lengthscales=0.25, variance=3.5))
-        a = Matern52(1, lengthscales=0.25, variance=1.0)
-        a.variance.fixed = True
-        a.lengthscales.transform = transforms.Logistic(0., 0.5)
-        b = MercerCosMix(input_dim=1, energy=np.asarray(energy[i]).copy(), frequency=np.asarray(frequency[i]).copy(),
-                         variance=0.25, features_as_params=False)
-        b.fixed = True
-        k_com.append(a * b)
-    return [k_act, k_com]
+
+    def component(i):
+        envelope = Matern52(1, lengthscales=0.25, variance=1.0)
+        envelope.variance.fixed = True
+        envelope.lengthscales.transform = transforms.Logistic(0., 0.5)
+        mixture = MercerCosMix(input_dim=1, energy=np.array(energy[i], copy=True),
+                               frequency=np.array(frequency[i], copy=True), variance=0.25, features_as_params=False)
+        mixture.fixed = True
+        return envelope * mixture
+    return [[Matern32(1, lengthscales=0.25, variance=3.5) for _ in range(num_pitches)],
+            [component(i) for i in range(num_pitches)]]

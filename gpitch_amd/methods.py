@@ -74,98 +74,87 @@ def freq2midi(freq):
 
 
 def find_ideal_f0(string):
-    """methods.py:26-33: ideal f0 of every file name that carries an 'M<midi>' tag (MAPS naming).
-    ('M21' also matches inside 'M210'...: the reference's substring test is kept as is.)"""
-    ideal_f0 = []
-    for j in range(len(string)):
-        for i in range(21, 109):
-            if string[j].find('M' + str(i)) != -1:
-                ideal_f0.append(midi2freq(i))
-    return ideal_f0
+    """Ideal fundamental of every file name carrying an 'M<midi>' tag (MAPS naming), 21 <= midi <= 108
+    (methods.py:26-33).  Plain substring search, as in the reference: 'M21' also matches inside 'M210', and a name
+    with several tags contributes several entries."""
+    return [midi2freq(midi) for name in string for midi in range(21, 109) if ("M%d" % midi) in name]
+
+
+def _fill_flat_steps(step):
+    """First differences with every run of zeros replaced by a neighbouring non-zero slope: a leading run takes the
+    slope that follows it, a trailing run the slope before it, an interior run (a flat top or bottom) the left slope
+    for its first half and the right slope from its middle on — so a plateau yields one sign change, at its centre."""
+    n = step.size
+    pos = np.arange(n)
+    live = step != 0
+    before = np.maximum.accumulate(np.where(live, pos, -1))              # nearest non-zero step at or before i
+    after = np.minimum.accumulate(np.where(live, pos, n)[::-1])[::-1]    # nearest at or after i
+    flat = ~live
+    centre = 0.5 * ((before + 1) + (after - 1))                          # median index of the zero run i lies in
+    from_left = flat & (before >= 0) & ((after >= n) | (pos < centre))
+    from_right = flat & ~from_left
+    out = step.copy()
+    out[from_left] = step[before[from_left]]
+    out[from_right] = step[np.minimum(after[from_right], n - 1)]
+    return out
 
 
 def peak_indexes(y, thres=0.3, min_dist=1):
-    """Peak picker used by init_cparam (methods.py:115 calls `peakutils.indexes`, a third-party package that is
-    not vendored in the reference; restated here from its published algorithm, peakutils 1.x): first-difference
-    sign change, amplitude above `thres` of the data range, flat tops resolved towards their middle, then greedy
-    suppression of weaker peaks within `min_dist` samples of a stronger one."""
+    """Indices of the local maxima of `y` that rise above `thres` (a fraction of the data range) and are at least
+    `min_dist` samples from any higher one.  Behaves as `peakutils.indexes(y, thres, min_dist)` of PeakUtils 1.x
+    (MIT licence; third-party, called at methods.py:115, not part of the reference tree), written from its
+    documented algorithm: slope sign change with flat tops resolved to their middle, then greedy suppression from
+    the highest peak down."""
     y = np.asarray(y, dtype=np.float64)
-    thres = thres * (np.max(y) - np.min(y)) + np.min(y)
-    min_dist = int(min_dist)
-    dy = np.diff(y)
-    zeros, = np.where(dy == 0)
-    if len(zeros) == len(y) - 1:
+    level = thres * (y.max() - y.min()) + y.min()
+    step = np.diff(y)
+    if not np.any(step):
         return np.array([], dtype=int)
-    if len(zeros):
-        zeros_diff = np.diff(zeros)
-        zeros_diff_not_one, = np.add(np.where(zeros_diff != 1), 1)
-        zero_plateaus = np.split(zeros, zeros_diff_not_one)
-        if zero_plateaus[0][0] == 0:
-            dy[zero_plateaus[0]] = dy[zero_plateaus[0][-1] + 1]
-            zero_plateaus.pop(0)
-        if len(zero_plateaus) and zero_plateaus[-1][-1] == len(dy) - 1:
-            dy[zero_plateaus[-1]] = dy[zero_plateaus[-1][0] - 1]
-            zero_plateaus.pop(-1)
-        for plateau in zero_plateaus:
-            median = np.median(plateau)
-            dy[plateau[plateau < median]] = dy[plateau[0] - 1]
-            dy[plateau[plateau >= median]] = dy[plateau[-1] + 1]
-    peaks = np.where((np.hstack([dy, 0.]) < 0.) & (np.hstack([0., dy]) > 0.) & (np.greater(y, thres)))[0]
-    if peaks.size > 1 and min_dist > 1:
-        highest = peaks[np.argsort(y[peaks])][::-1]
-        rem = np.ones(y.size, dtype=bool)
-        rem[peaks] = False
-        for peak in highest:
-            if not rem[peak]:
-                sl = slice(max(0, peak - min_dist), peak + min_dist + 1)
-                rem[sl] = True
-                rem[peak] = False
-        peaks = np.arange(y.size)[~rem]
+    step = _fill_flat_steps(step)
+    rising_in = np.concatenate([[False], step > 0.])
+    falling_out = np.concatenate([step < 0., [False]])
+    peaks = np.flatnonzero(rising_in & falling_out & (y > level))
+    reach = int(min_dist)
+    if peaks.size > 1 and reach > 1:
+        kept = np.zeros(y.size, dtype=bool)
+        kept[peaks] = True
+        for p in peaks[np.argsort(y[peaks])][::-1]:          # highest first; a surviving peak clears its neighbourhood
+            if kept[p]:
+                kept[max(0, p - reach):p + reach + 1] = False
+                kept[p] = True
+        peaks = np.flatnonzero(kept)
     return peaks
 
 
 def init_cparam(y, fs, maxh, ideal_f0, scaled=True, win_size=10, thres=0.1, min_dis=0.8):
-    """Component-kernel parameters from the spectrum of a training note (methods.py:91-153): frequencies and
-    (normalised) variances of up to `maxh` spectral peaks.  Quirks kept: the low-frequency filter loop
-    (:124-130) overwrites its result on every pass, so only the LAST peak is ever dropped (when it lies below
-    0.75 f0); the smoothed spectrum `Ss` (:108) is computed and never used."""
-    from scipy.fftpack import fft
-    y = np.asarray(y, dtype=np.float64)
-    N = y.size
-    Y = fft(y.reshape(-1,))
-    S = 2. / N * np.abs(Y[0:N // 2])
-    F = np.linspace(0, fs / 2., N // 2)
-    Sslog = np.log(S)
-    Sslog = Sslog + np.abs(np.min(Sslog))
-    Sslog /= np.max(Sslog)
-    thres = thres * np.max(Sslog)
-    min_dist = min_dis * np.argmin(np.abs(F - ideal_f0))
-    idx = peak_indexes(Sslog, thres=thres, min_dist=min_dist)
-    F_star, S_star = F[idx], S[idx]
-    idx_sorted = np.argsort(F_star.copy())
-    S_star = S_star[idx_sorted]
-    F_star = np.sort(F_star)
-    F_star2, S_star2 = F_star.copy(), S_star.copy()
-    for index in range(F_star.size):
-        if F_star[index] < 0.75 * ideal_f0:
-            F_star2 = np.delete(F_star, [index])
-            S_star2 = np.delete(S_star, [index])
-        else:
-            F_star2 = F_star.copy()
-            S_star2 = S_star.copy()
-    aux1 = np.flip(np.sort(S_star2), 0)
-    aux2 = np.flip(np.argsort(S_star2), 0)
-    if aux1.size > maxh:
-        vvec = aux1[0:maxh]
-        idxf = aux2[0:maxh]
-    else:
-        vvec = aux1
-        idxf = aux2
+    """Partial frequencies and (normalised) variances for a component kernel from the magnitude spectrum of one
+    training note: peaks of the log-spectrum at least `min_dis` x (bin of ideal_f0) apart, the `maxh` strongest,
+    returned in order of frequency as [frequencies, variances, F, S, threshold].  (methods.py:91-153)
+
+    Quirks of the reference kept on purpose: its low-frequency filter (:124-130) re-derives its result from the
+    unfiltered arrays on every pass, so in effect only the HIGHEST-frequency peak is examined (and dropped when it
+    lies below 0.75 f0); the log-spectrum is shifted by |min| rather than by -min; `win_size` is accepted and, as
+    there (the smoothed spectrum of :107-108 is never used), has no effect.  With no peak at all the reference
+    dies on an unbound name; here that is a ValueError."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    half = y.size // 2
+    S = (2. / y.size) * np.abs(np.fft.fft(y)[:half])
+    F = np.linspace(0, fs / 2., half)
+    logS = np.log(S)
+    logS = logS + np.abs(logS.min())
+    logS = logS / logS.max()
+    thres = thres * logS.max()
+    f0_bin = int(np.argmin(np.abs(F - ideal_f0)))
+    at = peak_indexes(logS, thres=thres, min_dist=min_dis * f0_bin)
+    if at.size == 0:
+        raise ValueError("init_cparam: no spectral peak above the threshold")
+    by_freq = np.argsort(F[at])
+    pk_f, pk_s = F[at][by_freq], S[at][by_freq]
+    if pk_f[-1] < 0.75 * ideal_f0:
+        pk_f, pk_s = pk_f[:-1], pk_s[:-1]
+    strongest = np.argsort(pk_s)[::-1][:maxh]
+    var = pk_s[strongest]
     if scaled:
-        vvec = vvec * (1. / np.sum(vvec))
-    freq_final = F_star2[idxf]
-    var_final = vvec
-    idx_sorted = np.argsort(freq_final.copy())
-    var_final = var_final[idx_sorted]
-    freq_final = np.sort(freq_final)
-    return [freq_final, var_final, F, S, thres]
+        var = var * (1. / np.sum(var))
+    order = np.argsort(pk_f[strongest])
+    return [pk_f[strongest][order], var[order], F, S, thres]

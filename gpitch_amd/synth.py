@@ -71,3 +71,48 @@ def make_problem(N, M, P, num_partials=5, seed=0, fs=16000, noise_var=1.0, base_
     return dict(x=x, y=y, za=za, zc=zc, kern_act=kern_act, kern_com=kern_com,
                 q_mu_act=q_mu_act, q_sqrt_act=q_sqrt_act, q_mu_com=q_mu_com, q_sqrt_com=q_sqrt_com,
                 noise_var=float(noise_var), N=N, M=M, P=P, fs=fs, num_partials=num_partials)
+
+
+def kernels_from_problem(prob):
+    """product kernel objects for the oracle-format kernel dicts of gpitch_amd.synth.make_problem"""
+    import gpitch_amd
+    from gpitch_amd.kernels import Matern12, Matern32, Matern52, RBF
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm, Matern12sm
+    cls = {"matern12": Matern12, "matern32": Matern32, "matern52": Matern52, "rbf": RBF}
+
+    def mk(d):
+        if d["type"] == "mercer_matern12sm":
+            return MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]),
+                                    variance=d["variance"], lengthscales=d["lengthscales"])
+        if d["type"] == "matern32sm":
+            from gpitch_amd.kernels import Matern32sm
+            return Matern32sm(1, len(d["frequency"]), lengthscales=d["lengthscales"], variances=np.array(d["energy"]),
+                              frequencies=np.array(d["frequency"]))
+        if d["type"] == "mercer_matern52sm":
+            from gpitch_amd.kernels import Matern52, MercerCosMix
+            a = Matern52(1, lengthscales=d["lengthscales"], variance=1.0)
+            a.variance.fixed = True
+            b = MercerCosMix(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=d["variance"],
+                             features_as_params=True)
+            b.variance.fixed = True
+            return a * b
+        if d["type"] == "matern12sm":
+            return Matern12sm(1, variance=d["variance"], lengthscales=d["lengthscales"],
+                              energy=np.array(d["energy"]), frequency=np.array(d["frequency"]))
+        return cls[d["type"]](1, variance=d["variance"], lengthscales=d["lengthscales"])
+    return [[mk(d) for d in prob["kern_act"]], [mk(d) for d in prob["kern_com"]]]
+
+
+def pdgp_from_problem(prob, whiten=True, minibatch_size=None, nlinfun=None, handle=None, shard=None):
+    import gpitch_amd
+    from gpitch_amd.pdgp import Pdgp
+    kern = kernels_from_problem(prob)
+    m = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kern, whiten=whiten, minibatch_size=minibatch_size,
+             nlinfun=nlinfun or gpitch_amd.logistic_tf, handle=handle, shard=shard)
+    for i in range(prob["P"]):
+        m.q_mu_act[i].value = prob["q_mu_act"][i]
+        m.q_mu_com[i].value = prob["q_mu_com"][i]
+        m.q_sqrt_act[i].value = prob["q_sqrt_act"][i]
+        m.q_sqrt_com[i].value = prob["q_sqrt_com"][i]
+    m.likelihood.variance = prob["noise_var"]
+    return m

@@ -13,16 +13,23 @@ def _hann(n):
     return signal.windows.hann(n)
 
 
+def _half(ws):
+    return (ws - 1) // 2
+
+
 def windowed(x, y, ws):
-    """window_overlap.py:7-16"""
-    n = x.size
-    l = (ws - 1) // 2
-    nw = (n - ws) // l + 1
-    xout, yout = [], []
-    for i in range(nw):
-        xout.append(x[i * l:i * l + ws].copy().reshape(-1, 1))
-        yout.append(y[i * l:i * l + ws].copy().reshape(-1, 1))
-    return xout, yout
+    """Half-overlapping windows of `ws` samples (hop (ws - 1) // 2; whatever does not fill a last window is
+    dropped), as two lists of (ws, 1) arrays.  (window_overlap.py:7-16)"""
+    hop = _half(ws)
+    count = (np.size(x) - ws) // hop + 1
+    if count <= 0:
+        return [], []
+    starts = hop * np.arange(count)
+
+    def cut(a):
+        frames = np.lib.stride_tricks.sliding_window_view(np.asarray(a).reshape(-1), ws)[starts]
+        return [f.reshape(-1, 1).copy() for f in frames]
+    return cut(x), cut(y)
 
 
 def _merge(y, ws, n, square):
@@ -73,39 +80,38 @@ def merged_on_device(windows, ws, n, square=False, handle=None):
 
 
 def merged_x(x, ws):
-    """window_overlap.py:60-73"""
-    l = (ws - 1) // 2
-    nw = len(x)
-    n = (ws - 1) // 2 * (nw - 1) + ws
-    xout = np.zeros((n, 1))
-    xout[0:l] = x[0][0:l]
-    xout[-l - 1:] = x[-1][-l - 1:]
-    for i in range(nw - 1):
-        xout[(i + 1) * l:(i + 2) * l] = x[i][-l - 1:-1].copy()
-    return xout
+    """The time axis the windows of `windowed` came from, rebuilt from the windows: first half-window of the first
+    one, the second hop of every window but the last, the tail of the last.  (window_overlap.py:60-73)"""
+    hop = _half(ws)
+    stack = np.stack([np.asarray(xi).reshape(-1) for xi in x])
+    count = stack.shape[0]
+    out = np.zeros(hop * (count - 1) + ws)
+    out[:hop] = stack[0, :hop]
+    out[out.size - hop - 1:] = stack[-1, -hop - 1:]
+    out[hop:count * hop] = stack[:-1, -hop - 1:-1].reshape(-1)
+    return out.reshape(-1, 1)
 
 
 def augmentate(x, y, augment_size=1600):
-    """window_overlap.py:213-220"""
-    addzeros = np.zeros((augment_size, 1))
-    yaug1 = np.append(addzeros, y.copy()).reshape(-1, 1)
-    yaug = np.append(yaug1, addzeros).reshape(-1, 1)
-    alpha = augment_size / 16000.
-    xaug = np.linspace(x[0] - alpha, x[-1] + alpha, x.size + 2 * augment_size).reshape(-1, 1)
+    """`augment_size` zeros before and after `y`; the time axis extended by augment_size / 16000 s either side over
+    the new length (the reference hard-codes 16 kHz here).  (window_overlap.py:213-220)"""
+    yaug = np.pad(np.asarray(y, dtype=np.float64).reshape(-1), augment_size).reshape(-1, 1)
+    margin = augment_size / 16000.
+    xaug = np.linspace(x[0] - margin, x[-1] + margin, np.size(x) + 2 * augment_size).reshape(-1, 1)
     return xaug, yaug
 
 
 def segmented(x, y, window_size=32000, aug=False):
-    """window_overlap.py:194-211: non-overlapping segments (trailing remainder dropped)"""
-    num_windows = y.size // window_size
-    xs, ys = [], []
-    for i in range(num_windows):
-        yaux = y[i * window_size:(i + 1) * window_size].copy()
-        xaux = x[i * window_size:(i + 1) * window_size].copy()
-        if aug:
-            xaug, yaug = augmentate(xaux, yaux)
-        else:
-            xaug, yaug = xaux.copy(), yaux.copy()
-        ys.append(yaug)
-        xs.append(xaug)
+    """Consecutive non-overlapping segments of `window_size` samples (a trailing remainder is dropped), optionally
+    zero-padded by `augmentate`.  (window_overlap.py:194-211)"""
+    count = np.size(y) // window_size
+
+    def cut(a):
+        a = np.asarray(a)
+        blocks = a[:count * window_size].reshape((count, window_size) + a.shape[1:])
+        return [b.copy() for b in blocks]
+    xs, ys = cut(x), cut(y)
+    if aug:
+        pairs = [augmentate(xi, yi) for xi, yi in zip(xs, ys)]
+        xs, ys = [p[0] for p in pairs], [p[1] for p in pairs]
     return xs, ys

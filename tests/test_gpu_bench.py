@@ -27,6 +27,11 @@ def test_bench_single_process_line():
     assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in d["roofline"]
+    # roofline.frac is the dominant kernel's own flops over its own duration: reproducible with one division
+    r = d["roofline"]
+    assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-9 * r["achieved"]
+    assert abs(d["mfma_frac_step"]["achieved"]
+               - d["mfma_frac_step"]["algorithmic_flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6
     assert d["config"]["workload"].startswith("pdgp ELBO step")
 
 
@@ -40,3 +45,15 @@ def test_bench_two_rank_rehearsal(shard, scaling):
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
     assert d["config"]["parallelism"].startswith("window-per-gpu" if shard == "window" else "pitch-sharded")
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's form of the command) must start two ranks
+    and say so; the extra pitch-sharded strong-scaling line rides on the same JSON."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + SMALL,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["pitch_sharded"]["scaling"] == "strong" and d["pitch_sharded"]["value"] > 0
