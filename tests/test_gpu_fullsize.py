@@ -78,3 +78,61 @@ def test_cfg5_sgprss_N65536_M512_P5(gp_handle):
     got = m.build_likelihood()
     ref = orc.sgpr_bound(X, Y, Z, kl, 0.5)
     assert abs(got - ref) <= FULLSIZE_RTOL * abs(ref), (got, ref)
+
+
+def _k1_closed_form(y, N, kern_act, kern_com, s2):
+    """K1: at q_mu = 0, q_sqrt = I (whitened) KL = 0, fmean = 0, fvar = Kdiag, so
+    ELBO = -1/2 [sum y^2 + N sum_i v_f,i E2_i] / s2 - N/2 (log 2 pi + log s2), independent of M, Z and the lengthscales."""
+    from oracle import gpflow05 as orc
+    tot = np.sum(y ** 2)
+    for ka, kc in zip(kern_act, kern_com):
+        _, E2 = orc.hermgauss1d(np.zeros((1, 1)), np.full((1, 1), ka["variance"]), 20, orc.logistic)
+        tot += N * kc["variance"] * sum(kc["energy"]) * E2[0, 0]
+    return -0.5 * tot / s2 - 0.5 * N * (np.log(2 * np.pi) + np.log(s2))
+
+
+def test_cfg4_windowed_N262144_twelve_pitches(gp_handle):
+    """configs[3]: 12 pitches, N = 262144 'windowed', one window per GPU on 8 GPUs.  The reference cuts long audio
+    into independent pieces that are fitted one after another (window_overlap.py:194-211 non-overlapping segments;
+    :7-16 half-overlapping windows of 2001; transcription.py:265-288): here the 8 x 32768 segments go through
+    dist.window_assignment exactly as 8 ranks would take them (run one after another on the one GPU of this box),
+    every window at full size (M = 512, P = 12) against the K1 closed form, the job's total = the sum the scalar
+    all-reduce forms, and one window at the transcription model's size (M = 256) against the oracle."""
+    import gpitch_amd
+    from gpitch_amd import dist as gp_dist
+    from gpitch_amd.synth import make_problem, uniform_inducing
+    from gpitch_amd.window_overlap import segmented, windowed
+    NT, NW, P = 262144, 32768, 12
+    long_prob = make_problem(NT, 512, P, num_partials=20, seed=4, trivial_q=True)
+    xs, ys = segmented(long_prob["x"], long_prob["y"], window_size=NW)
+    assert len(xs) == 8 and all(xi.shape == (NW, 1) for xi in xs)
+    xw, yw = windowed(long_prob["x"], long_prob["y"], 2001)
+    assert len(xw) == 261 and xw[-1].shape == (2001, 1)          # the other split SURVEY section 8d names
+
+    def window_problem(w, M, trivial=True, seed=0):
+        p = make_problem(NW, M, P, num_partials=20 if trivial else 5, seed=seed, trivial_q=trivial)
+        p["x"], p["y"] = xs[w].copy(), ys[w].copy()
+        z = uniform_inducing(p["x"], M)
+        p["za"], p["zc"] = [z.copy() for _ in range(P)], [z.copy() for _ in range(P)]
+        return p
+    world = 8
+    seen, total, total_ref = [], 0.0, 0.0
+    for rank in range(world):
+        for w in gp_dist.window_assignment(len(xs), world, rank):
+            prob = window_problem(w, 512)
+            model = pdgp_from_problem(prob, handle=gp_handle)
+            got = model.compute_log_likelihood()
+            ref = _k1_closed_form(prob["y"], NW, prob["kern_act"], prob["kern_com"], prob["noise_var"])
+            assert abs(got - ref) <= 1e-8 * abs(ref), (w, got, ref)
+            total += got
+            total_ref += ref
+            seen.append(w)
+            del model
+    assert sorted(seen) == list(range(8))                         # every window fitted exactly once
+    assert abs(total - total_ref) <= 1e-8 * abs(total_ref)
+    # one window (the sixth) with a non-trivial variational state, at the transcription model's M, against the oracle
+    prob = window_problem(5, 256, trivial=False, seed=9)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    ref = float(oracle_elbo(prob))
+    assert abs(got - ref) <= FULLSIZE_RTOL * abs(ref), (got, ref)

@@ -467,6 +467,30 @@ def test_blocked_kuu_factorisation_with_partial_last_panel(gp_handle, N):
     np.testing.assert_allclose(ma[0], rm, rtol=0, atol=1e-6 * np.abs(rm).max())
 
 
+def test_headline_M512_blocked_factorisation_gradient_vs_autograd(gp_handle):
+    """M = 512 (the bench shape's inducing count: four 128-column panels, resident factor + blocked inverse, 4 x 4
+    tile grids in every strip product) at P = 1 and a batch the oracle differentiates in seconds: the ELBO and every
+    gradient entry against torch autograd through the oracle.  cond(Kuu) ~ 1e9, so both sides carry cond * eps."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(8192, 512, 1, num_partials=5, seed=21)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model._pack()
+    f = model._elbo(True)
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    assert abs(f - ref_f) <= 1e-8 * abs(ref_f), (f, ref_f)
+    got_g = model_grad_dict(model)
+    worst = {}
+    for name, rg in ref_g.items():
+        gg = got_g[name]
+        if name.startswith("q_sqrt"):
+            rg = np.tril(rg[:, :, 0])[:, :, None]
+            assert np.all(np.triu(gg[:, :, 0], 1) == 0)
+        scale = max(np.abs(rg).max(), 1e-12)
+        worst[name] = np.abs(gg.reshape(rg.shape) - rg).max() / scale
+    bad = {k: v for k, v in worst.items() if v > 2e-5}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("N,M,P", [(4096, 48, 2), (4200, 300, 1)])
 def test_overlap_levels_give_identical_results(gp_handle, N, M, P):
     """gp_pdgp_set_overlap changes only the schedule (helper-stream fork / join points); the ELBO and every gradient
