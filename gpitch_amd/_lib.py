@@ -25,12 +25,12 @@ TIMER_NAMES = ["kuf_build", "cond_A", "cond_LTA", "nt_gemm", "kuf_bar", "chol", 
 # every symbol include/gpitch_abi.h declares
 ABI_SYMBOLS = [
     "gp_create", "gp_destroy", "gp_sync", "gp_last_error", "gp_abi_version", "gp_last_not_pd_index",
-    "gp_kernel_build", "gp_kernel_diag", "gp_chol_workspace_bytes", "gp_kuu_cholesky", "gp_cholesky_inplace",
-    "gp_conditional_workspace_bytes", "gp_conditional_diag", "gp_gauss_kl_workspace_bytes", "gp_gauss_kl", "gp_gauss_kl_matrix", "gp_mpd_varexp",
+    "gp_kernel_build", "gp_kernel_build_f32", "gp_kernel_diag", "gp_chol_workspace_bytes", "gp_kuu_cholesky", "gp_cholesky_inplace",
+    "gp_conditional_workspace_bytes", "gp_conditional_diag", "gp_conditional_diag_f32", "gp_gauss_kl_workspace_bytes", "gp_gauss_kl", "gp_gauss_kl_matrix", "gp_mpd_varexp",
     "gp_pdgp_create", "gp_pdgp_destroy", "gp_pdgp_num_params", "gp_pdgp_layout", "gp_pdgp_workspace_bytes",
-    "gp_pdgp_set_workspace", "gp_pdgp_set_grad_needs", "gp_pdgp_set_overlap", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_predict", "gp_pdgp_predict_reuse",
+    "gp_pdgp_set_workspace", "gp_pdgp_set_precision", "gp_pdgp_set_grad_needs", "gp_pdgp_set_overlap", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_predict", "gp_pdgp_predict_reuse",
     "gp_overlap_merge", "gp_transform_register_logistic", "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
-    "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace",
+    "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace", "gp_sgpr_set_precision",
     "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_exchange_doubles", "gp_sgpr_bound_begin", "gp_sgpr_bound_end", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
 ]
@@ -67,6 +67,19 @@ class SgprConfig(C.Structure):
 _lib = None
 
 
+def precision_bits(float_type):
+    """64 or 32 from what a caller passes as the reference's `float_type` setting (pdgp.py:13): None / np.float64 /
+    'float64' / 64 -> 64; np.float32 / 'float32' / 32 -> 32."""
+    if float_type is None:
+        return 64
+    if float_type in (32, 64):
+        return int(float_type)
+    bits = np.dtype(float_type).itemsize * 8
+    if bits not in (32, 64):
+        raise ValueError("float_type must be float64 or float32")
+    return bits
+
+
 def load_library():
     """dlopen the C-ABI library.  Raises (never falls back) when it is missing."""
     global _lib
@@ -91,12 +104,14 @@ def load_library():
         "gp_abi_version": (i32, []),
         "gp_last_not_pd_index": (i32, [vp]),
         "gp_kernel_build": (i32, [vp, KD, vp, i32, vp, i32, vp, i64, i32]),
+        "gp_kernel_build_f32": (i32, [vp, KD, vp, i32, vp, i32, vp, i64, i32]),
         "gp_kernel_diag": (i32, [vp, KD, i32, vp, i32]),
         "gp_chol_workspace_bytes": (sz, [i32]),
         "gp_kuu_cholesky": (i32, [vp, KD, vp, i32, dbl, vp, vp, vp, sz]),
         "gp_cholesky_inplace": (i32, [vp, vp, i32, i64]),
         "gp_conditional_workspace_bytes": (sz, [i32, i32]),
         "gp_conditional_diag": (i32, [vp, KD, vp, i32, vp, i32, vp, vp, i32, dbl, vp, vp, vp, sz]),
+        "gp_conditional_diag_f32": (i32, [vp, KD, vp, i32, vp, i32, vp, vp, dbl, vp, vp, vp, sz]),
         "gp_gauss_kl_workspace_bytes": (sz, [i32, i32]),
         "gp_gauss_kl": (i32, [vp, vp, vp, i32, KD, vp, dbl, C.POINTER(dbl), vp, sz]),
         "gp_gauss_kl_matrix": (i32, [vp, vp, vp, i32, vp, C.POINTER(dbl), vp, sz]),
@@ -107,6 +122,7 @@ def load_library():
         "gp_pdgp_layout": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
         "gp_pdgp_workspace_bytes": (sz, [vp]),
         "gp_pdgp_set_workspace": (i32, [vp, vp, sz]),
+        "gp_pdgp_set_precision": (i32, [vp, i32]),
         "gp_pdgp_set_grad_needs": (i32, [vp, i32, i32, i32]),
         "gp_pdgp_set_overlap": (i32, [vp, i32]),
         "gp_pdgp_elbo": (i32, [vp, vp, vp, vp, i32, dbl, vp, C.POINTER(dbl), vp]),
@@ -124,6 +140,7 @@ def load_library():
         "gp_sgpr_num_params": (i64, [vp]),
         "gp_sgpr_workspace_bytes": (sz, [vp]),
         "gp_sgpr_set_workspace": (i32, [vp, vp, sz]),
+        "gp_sgpr_set_precision": (i32, [vp, i32]),
         "gp_sgpr_bound": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl)]),
         "gp_sgpr_bound_grad": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl), vp]),
         "gp_sgpr_exchange_doubles": (i64, [vp]),

@@ -181,6 +181,26 @@ gp_status gp_kernel_build(gp_handle h, const gp_kernel_desc* kern, const double*
   return s;
 }
 
+// float32 output of the same build (inputs and arithmetic float64, one rounding at the store): the Kuf strips of the
+// float32 configurations
+gp_status gp_kernel_build_f32(gp_handle h, const gp_kernel_desc* kern, const double* x1, int32_t n1, const double* x2,
+                              int32_t n2, float* out, int64_t ld, int32_t accumulate) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!kern_ok(kern) || !x1 || !out || n1 < 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_kernel_build_f32: bad argument");
+  if (!x2) n2 = n1;
+  if (n2 < 0 || ld < n2) return gp_fail(h, GP_ERR_BAD_ARG, "gp_kernel_build_f32: bad n2/ld");
+  if (n1 == 0 || n2 == 0) return GP_OK;
+  DevKern k = dev_kern(kern);
+  double* feat = nullptr;
+  if (gp_kern_is_mercer(k.type)) {
+    size_t nd = kernel_build_feat_ws_doubles(k.m, n1, x2 ? n2 : n1);
+    GP_HIP_CHECK(h, hipMallocAsync((void**)&feat, nd * sizeof(double), h->stream));
+  }
+  gp_status s = launch_kernel_build(h, k, x1, n1, x2, n2, reinterpret_cast<double*>(out), ld, accumulate, 0.0, feat, 0, 1);
+  if (feat) GP_HIP_CHECK(h, hipFreeAsync(feat, h->stream));
+  return s;
+}
+
 gp_status gp_kernel_diag(gp_handle h, const gp_kernel_desc* kern, int32_t n, double* out, int32_t accumulate) {
   if (!h) return GP_ERR_BAD_ARG;
   if (!kern_ok(kern) || !out || n < 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_kernel_diag: bad argument");
@@ -219,26 +239,47 @@ size_t gp_conditional_workspace_bytes(int32_t N, int32_t M) {
   return cond_task_workspace_doubles(M, N, 32, false) * sizeof(double) + cond_batch_desc_bytes(1) + 4096;
 }
 
-gp_status gp_conditional_diag(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N, const double* z,
-                              int32_t M, const double* q_mu, const double* q_sqrt, int32_t whiten, double jitter,
-                              double* fmean, double* fvar, void* workspace, size_t workspace_bytes) {
+static gp_status conditional_diag_impl(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N,
+                                       const double* z, int32_t M, const double* q_mu, const double* q_sqrt,
+                                       int32_t whiten, double jitter, double* fmean, double* fvar, void* workspace,
+                                       size_t workspace_bytes, bool f32, const char* who) {
   if (!h) return GP_ERR_BAD_ARG;
   if (!kern_ok(kern) || !xnew || !z || !q_mu || !fmean || !fvar || N < 0 || M <= 0)
-    return gp_fail(h, GP_ERR_BAD_ARG, "gp_conditional_diag: bad argument");
+    return gp_fail(h, GP_ERR_BAD_ARG, who);
   if (N == 0) return GP_OK;
   GpArena ar(workspace, workspace_bytes);
   CondBatch cb;
+  cb.f32 = f32;
   cb.tasks.resize(1);
   CondTask& t = cb.tasks[0];
   t.kern = dev_kern(kern); t.z = z; t.M = M; t.q_mu = q_mu; t.q_sqrt = q_sqrt; t.fmean = fmean; t.fvar = fvar;
   cb.desc_bytes = cond_batch_desc_bytes(1);
   cb.d_desc = ar.take<char>(cb.desc_bytes);
-  if (!cond_task_carve(ar, t, N, whiten != 0) || !cb.d_desc)
+  if (!cond_task_carve(ar, t, N, whiten != 0, f32) || !cb.d_desc)
     return gp_fail(h, GP_ERR_WORKSPACE, "gp_conditional_diag: workspace too small");
   cb.N = N;
-  GP_CHECK(cond_batch_upload(h, cb, whiten != 0, jitter));
-  GP_CHECK(cond_batch_run(h, cb, xnew, N, whiten != 0, jitter));
-  return check_not_pd(h);
+  gp_status st = cond_batch_upload(h, cb, whiten != 0, jitter);
+  if (st == GP_OK) st = cond_batch_run(h, cb, xnew, N, whiten != 0, jitter);
+  // cb.h_desc (a member of this stack object) is the source of an asynchronous descriptor copy: the stream is drained
+  // on EVERY path before it goes out of scope (check_not_pd synchronises)
+  const gp_status pd = check_not_pd(h);
+  return st != GP_OK ? st : pd;
+}
+
+gp_status gp_conditional_diag(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N, const double* z,
+                              int32_t M, const double* q_mu, const double* q_sqrt, int32_t whiten, double jitter,
+                              double* fmean, double* fvar, void* workspace, size_t workspace_bytes) {
+  return conditional_diag_impl(h, kern, xnew, N, z, M, q_mu, q_sqrt, whiten, jitter, fmean, fvar, workspace,
+                               workspace_bytes, false, "gp_conditional_diag: bad argument");
+}
+
+// the same conditional with the M x N strips (Kuf, A) in float32 and the two strip products on the float32 matrix
+// path; Kuu, its factor, W, and every reduction stay float64 (whitened form only)
+gp_status gp_conditional_diag_f32(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N, const double* z,
+                                  int32_t M, const double* q_mu, const double* q_sqrt, double jitter, double* fmean,
+                                  double* fvar, void* workspace, size_t workspace_bytes) {
+  return conditional_diag_impl(h, kern, xnew, N, z, M, q_mu, q_sqrt, 1, jitter, fmean, fvar, workspace, workspace_bytes,
+                               true, "gp_conditional_diag_f32: bad argument");
 }
 
 gp_status gp_mpd_varexp(gp_handle h, const double* Fmu, const double* Fvar, const double* y, int32_t N, int32_t P,

@@ -23,9 +23,14 @@ __global__ void __launch_bounds__(256) rowdot_kernel(const GemmProblem* __restri
   const GemmProblem p = probs[blockIdx.y];
   const int i = blockIdx.x;
   if (i >= p.M) return;
-  const double* row = p.A + (int64_t)i * p.lda;
   double acc = 0.0;
-  for (int n = threadIdx.x; n < p.N; n += 256) acc = fma(row[n], p.v0[n], acc);
+  if (p.a_f32) {
+    const float* row = reinterpret_cast<const float*>(p.A) + (int64_t)i * p.lda;
+    for (int n = threadIdx.x; n < p.N; n += 256) acc = fma((double)row[n], p.v0[n], acc);
+  } else {
+    const double* row = p.A + (int64_t)i * p.lda;
+    for (int n = threadIdx.x; n < p.N; n += 256) acc = fma(row[n], p.v0[n], acc);
+  }
   __shared__ double red[4];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -127,6 +132,10 @@ gp_status launch_matvec_batched(gp_handle h, const GemmProblem* d, int batch, in
 // gz_part[colblock][i] = sum_{j in block} Gw[i][j] * dK[i][j]/dx1_i
 #define HY_THREADS 256
 #define HY_ROWS 32
+// element `idx` of a strip that is float64 or (g32, a float32 plan) float32
+__device__ __forceinline__ double hy_ld(const double* __restrict__ p, int64_t idx, int g32) {
+  return g32 ? (double)reinterpret_cast<const float*>(p)[idx] : p[idx];
+}
 
 int hyper_num_sums(int m) { return 2 + 2 * m; }
 // rows of x1 per workgroup: HY_ROWS for the strips; small contractions (window-sized problems, the Kuu side) get
@@ -157,7 +166,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
                                                                     const double* __restrict__ f1,
                                                                     const double* __restrict__ f2,
                                                                     double* __restrict__ partials,
-                                                                    double* __restrict__ gz_part, int wg_rows) {
+                                                                    double* __restrict__ gz_part, int wg_rows, int g32) {
   extern __shared__ double smem[];  // [HY_ROWS][2*MPAD] row features | omega[MPAD] | reduction scratch
   const double* th = k.theta;
   const double var = th[0], ls = th[1];
@@ -201,8 +210,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
     const double xa = x1[i];
     double w = 0.0;
     if (live) {
-      w = G[(int64_t)i * ldg + j];
-      if (symmetric) w = 0.5 * (w + G[(int64_t)j * ldg + i]);
+      w = hy_ld(G, (int64_t)i * ldg + j, g32);
+      if (symmetric) w = 0.5 * (w + hy_ld(G, (int64_t)j * ldg + i, g32));
       if (alpha) w = fma(alpha[i], gmj, w);
     }
     const double a = row_a[i - i0], aa = __dmul_rn(a, a);
@@ -318,7 +327,7 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
                                                             const double* __restrict__ Kuf, int64_t ldk,
                                                             const double* __restrict__ f1,
                                                             const double* __restrict__ f2,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials, int g32) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int NF = 2 * MPAD;                 // features per row: cos block, then sin block
   constexpr int NT = (NF + 15) / 16;           // 16-row MFMA tiles of the feature dimension
@@ -355,8 +364,8 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
     for (int ks = 0; ks < KS; ks++) {
       const int i = r0 + ks * 4 + kq;
       const bool on = live && (i < n1);
-      g[ks] = on ? G[(int64_t)i * ldg + j] : 0.0;
-      kk[ks] = on ? Kuf[(int64_t)i * ldk + j] : 0.0;
+      g[ks] = on ? hy_ld(G, (int64_t)i * ldg + j, g32) : 0.0;
+      kk[ks] = on ? hy_ld(Kuf, (int64_t)i * ldk + j, g32) : 0.0;
     }
   };
   fetch(0, gw, kvv);
@@ -457,7 +466,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
                                                                  const double* __restrict__ alpha,
                                                                  const double* __restrict__ gm, int symmetric,
                                                                  double* __restrict__ partials,
-                                                                 double* __restrict__ gz_part, int wg_rows) {
+                                                                 double* __restrict__ gz_part, int wg_rows, int g32) {
   extern __shared__ double smem[];   // e[m] | omega[m] | reduction scratch [4][max(2+2m, HY_ROWS)]
   const double* th = k.theta;
   const double var = th[0], ls = th[1];
@@ -486,8 +495,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
   for (int i = i0; i < iend; i++) {
     double w = 0.0;
     if (live) {
-      w = G[(int64_t)i * ldg + j];
-      if (symmetric) w = 0.5 * (w + G[(int64_t)j * ldg + i]);
+      w = hy_ld(G, (int64_t)i * ldg + j, g32);
+      if (symmetric) w = 0.5 * (w + hy_ld(G, (int64_t)j * ldg + i, g32));
       if (alpha) w = fma(alpha[i], gmj, w);
     }
     const double d = __dadd_rn(__dadd_rn(x1[i], -xb), 1e-12);
@@ -562,19 +571,19 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
 template <int MPAD, bool SM, int KT = -1>
 static void launch_hyper_t(gp_handle h, dim3 grid, size_t sh, DevKern k, const double* x1, int n1, const double* x2,
                            int n2, const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
-                           const double* f1, const double* f2, double* partials, double* gz, int wg_rows) {
+                           const double* f1, const double* f2, double* partials, double* gz, int wg_rows, int g32) {
   if (gz)
     hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, true, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2,
-                       n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows);
+                       n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows, g32);
   else
     hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, false, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1,
-                       x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows);
+                       x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows, g32);
 }
 
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
                                 const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
                                 const double* feat, double* partials, int* nparts, double* gz_partials,
-                                const double* kvals, int64_t ldk) {
+                                const double* kvals, int64_t ldk, int g32) {
   GpTimerScope ts(h, GP_TIMER_HYPER);
   const int wg_rows = hy_rows_for(n1, n2);
   if (gp_kern_is_broadcast(k.type)) {
@@ -584,10 +593,10 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     const size_t sh = (2 * (size_t)k.m + 4 * (size_t)redw) * sizeof(double);
     if (gz_partials)
       hipLaunchKernelGGL((hyper_m12sm_kernel<true>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                         alpha, gm, symmetric, partials, gz_partials, wg_rows);
+                         alpha, gm, symmetric, partials, gz_partials, wg_rows, g32);
     else
       hipLaunchKernelGGL((hyper_m12sm_kernel<false>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                         alpha, gm, symmetric, partials, gz_partials, wg_rows);
+                         alpha, gm, symmetric, partials, gz_partials, wg_rows, g32);
     GP_HIP_CHECK(h, hipGetLastError());
     if (nparts) *nparts = grid.x * grid.y;
     return GP_OK;
@@ -604,7 +613,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     // Kuf side with the covariance strip still in memory: the matrix-core form (hyper_sm_mfma_kernel)
     dim3 gridm((n2 + 63) / 64);
 #define HY_MFMA(MP) hipLaunchKernelGGL((hyper_sm_mfma_kernel<MP>), gridm, dim3(256), 0, h->stream, k, x1, n1, x2, n2, G, ldg, \
-                                     alpha, gm, kvals, ldk, f1, f2, partials)
+                                     alpha, gm, kvals, ldk, f1, f2, partials, g32)
     switch (mp) {
       case 4: HY_MFMA(4); break;
       case 8: HY_MFMA(8); break;
@@ -620,7 +629,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     if (nparts) *nparts = gridm.x;
     return GP_OK;
   }
-#define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials, wg_rows
+#define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials, wg_rows, g32
   if (!sm) switch (k.type) {
     case GP_KERN_MATERN12: launch_hyper_t<1, false, GP_KERN_MATERN12>(h, HY_ARGS); break;
     case GP_KERN_MATERN32: launch_hyper_t<1, false, GP_KERN_MATERN32>(h, HY_ARGS); break;
@@ -756,7 +765,6 @@ enum BwdSlot { S_H = 0, S_U, S_HLQ, S_QW_MU, S_QW_L, S_GQ_MU, S_GQ_L,
                S_COUNT };
 static_assert(S_COUNT <= 24, "gp_pdgp_plan_s::off_bwd");
 
-static inline int64_t ldN_b(int N) { return (N + 1) & ~1; }
 
 gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad) {
   (void)x;
@@ -768,7 +776,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
   p->off_fin_items = p->off_kl2 + pdgp_kl_region_bytes(G);
   p->h_fin_items.clear();       // the descriptor block is rewritten: force a fresh upload of the finish items
   const bool white = p->whiten != 0;
-  const int64_t ldN = ldN_b(n);
+  const int64_t ldN = gp_strip_ld(n, p->f32 != 0);
   size_t slab_off = 0;
   p->kgps.clear();
   for (int g = 0; g < G; g++)
@@ -873,7 +881,8 @@ gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n, bool* kl_done) {
 gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad) {
   gp_handle h = p->h;
   const int G = p->G, maxM = p->maxM;
-  const int64_t ldN = ldN_b(n);
+  const int64_t ldN = gp_strip_ld(n, p->f32 != 0);
+  const int f32 = p->f32;
   auto D = [&](int slot) { return (const GemmProblem*)(p->d_misc + p->off_bwd[slot]); };
   GemmFlags f;
   const bool white = p->whiten != 0;
@@ -899,7 +908,8 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   auto h_chain_head = [&]() -> gp_status {
     GemmFlags f;
     // H = A diag(2 gv) A^T  (symmetric, split-K over the frames); u = A gm and grad q_mu += u are fused into it
-    GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
+    if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
+    else GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
     // grad q_sqrt += tril(H Lq)
     f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
     GP_CHECK(launch_gemm_batched(h, D(S_HLQ), G, maxM, maxM, f));
@@ -982,7 +992,8 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     }
     // Kuf_bar (dense part) = R (A diag(2 gv))
     f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
-    GP_CHECK(launch_gemm_batched(h, D(S_G), nK, maxM, n, f));
+    if (f32) GP_CHECK(launch_gemm_f32_role(h, D(S_G), nK, maxM, n, f));
+    else GP_CHECK(launch_gemm_batched(h, D(S_G), nK, maxM, n, f));
     if (!forked) {
       if (early_fork) { GP_CHECK(h_chain_head()); GP_CHECK(wbar_chain()); }   // (no helper stream to be had)
       GP_CHECK(kuu_side());
@@ -1004,7 +1015,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       const double* gm = p->gFmu + (size_t)g * n;
       double* gz_uf = q.need_z ? bb.gz_part : nullptr;
       return launch_hyper_contract(h, t.kern, z, q.M, x, n, bb.G, ldN, bb.alpha, gm, 0, t.feat, bb.hyp_part, &np_uf[g], gz_uf,
-                                   t.Kuf, ldN);
+                                   t.Kuf, ldN, f32);
     };
     const bool split = forked && p->overlap >= 2 && gp_aux_resume(h);
     if (split) {

@@ -437,10 +437,12 @@ static size_t chol_smem_bytes(int maxM, int* cap) {
   return dbytes;
 }
 static gp_status chol_set_attr(gp_handle h) {
-  static std::atomic<bool> done{false};   // several handles / threads may race here: a repeated call is harmless
-  if (!done.load(std::memory_order_acquire)) {
+  // per-DEVICE attribute: one bit per device (several handles / threads may race here: a repeated call is harmless)
+  static std::atomic<uint32_t> done{0};
+  const uint32_t bit = 1u << (h->device & 31);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    done.store(true, std::memory_order_release);
+    done.fetch_or(bit, std::memory_order_release);
   }
   return GP_OK;
 }
@@ -460,12 +462,13 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
 }
 
 static gp_status chol_inverse_set_attr(gp_handle h) {
-  static std::atomic<bool> done{false};
-  if (!done.load(std::memory_order_acquire)) {
+  static std::atomic<uint32_t> done{0};
+  const uint32_t bit = 1u << (h->device & 31);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_inverse_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(CHS_DOUBLES * sizeof(double))));
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)chol_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    done.store(true, std::memory_order_release);
+    done.fetch_or(bit, std::memory_order_release);
   }
   return GP_OK;
 }

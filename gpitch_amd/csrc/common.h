@@ -169,8 +169,10 @@ static inline DevKern dev_kern(const gp_kernel_desc* k) { return DevKern{k->type
 // launchers implemented across the .hip files (all enqueue on h->stream)
 
 // cov.hip
+// f32out != 0: `out` is a float32 matrix (ld in floats) — the strips of a float32 plan; the arithmetic stays float64
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
-                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws, int feat_ready = 0);
+                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws, int feat_ready = 0,
+                              int f32out = 0);
 size_t kernel_build_feat_ws_doubles(int m, int n1, int n2);
 int sm_mpad(int m);  // spectral-mixture partial count padded to a multiple of 4 (feature tables are zero-padded)
 gp_status launch_kernel_diag(gp_handle h, DevKern k, int n, double* out, int accumulate);
@@ -202,6 +204,8 @@ struct GemmProblem {
   double* o0; double* o1; double* o2;
   DevKern kern;           // for epilogues that re-evaluate the covariance (hyper-gradient)
   const double* xa; const double* xb;  // kernel inputs (z, x) for those epilogues
+  int a_f32;              // small vector kernels (rowdot): A is a float32 strip (lda in floats)
+  int pad_;
 };
 enum GemmTri { TRI_NONE = 0, TRI_LOWER = 1, TRI_UPPER = 2 };
 struct GemmFlags {
@@ -233,16 +237,30 @@ gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs,
 gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, double* const* d_W, const int* d_M,
                                      const int* d_ld, int batch);
 int gemm_nt_nsplit(int M, int Nlong, int batch);
+gp_status launch_slab_reduce(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int nsplit, int sym, double alpha);
+// gemm_f32.hip: the strip products on float32 strips (roles 1-3: A float64 M x M, B / C float32 strips; nt: float32
+// strips, float64 slabs).  Same descriptor struct; ldb / ldc (and lda for nt) count floats.
+gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f);
+gp_status launch_gemm_f32_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
+                                            int nsplit, int sym, int scale_by_k, double alpha);
+// leading dimension (in elements) of an M x N strip: even for float64, a multiple of 4 for float32 (16-byte rows)
+static inline int64_t gp_strip_ld(int N, bool f32) { return f32 ? (((int64_t)N + 3) & ~(int64_t)3) : (((int64_t)N + 1) & ~(int64_t)1); }
+// doubles that hold an M x ld strip of either type
+static inline size_t gp_strip_doubles(size_t M, int N, bool f32) {
+  const size_t e = M * (size_t)gp_strip_ld(N, f32);
+  return f32 ? (e + 1) / 2 : e;
+}
 int gemm_rowblocks(int M, int big_tiles);
 
 // grouped covariance builds (cov.hip): one launch for all matrices of a kernel family
 struct CovItem {
   DevKern k; const double* x1; const double* x2; double* out; const double* f1; const double* f2;
   int64_t ld; double diag_add; int n1, n2, accumulate, vec_ok;
+  int f32out, pad_;     // out is float32 (ld in floats)
 };
 struct FeatItem { DevKern k; const double* x; double* f; int n; int pad; };
 void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const double* x2, int n2, double* out, int64_t ld,
-                   int accumulate, double diag_add, double* feat_ws);
+                   int accumulate, double diag_add, double* feat_ws, int f32out = 0);
 gp_status launch_sm_features_items(gp_handle h, const FeatItem* d_items, int count, int max_n, int mpad,
                                    const double* x_shared, int n_shared);
 gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem* d_items, int count, int max_n1,

@@ -37,6 +37,22 @@ __device__ __forceinline__ double r2_expand(double a, double aa, double b, doubl
   return __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, b), aa), bb);
 }
 
+// store CPT results of one row as float32 (the strips of a float32 plan; `off` and the leading dimension count floats)
+template <int CPT>
+__device__ __forceinline__ void cov_store_f32(double* out, size_t off, int cols_left, const double* res, int accumulate,
+                                              int vec_ok) {
+  float* o = reinterpret_cast<float*>(out) + off;
+  if (CPT == 2 && vec_ok && cols_left > 1) {
+    float2 v = make_float2((float)res[0], (float)res[CPT - 1]);
+    if (accumulate) { const float2 old = *reinterpret_cast<float2*>(o); v.x += old.x; v.y += old.y; }
+    *reinterpret_cast<float2*>(o) = v;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPT; c++)
+      if (c < cols_left) o[c] = accumulate ? o[c] + (float)res[c] : (float)res[c];
+  }
+}
+
 // Precompute spectral-mixture features, zero-padded to MPAD partials so the consumers can unroll without
 // guards:  f[q][j] = sqrt(e_q) cos(2 pi f_q x_j),  f[MPAD + q][j] = sqrt(e_q) sin(2 pi f_q x_j),  q < m;  0 for q >= m.
 __global__ void __launch_bounds__(256) sm_features_kernel(DevKern k, const double* __restrict__ x, int n,
@@ -70,13 +86,13 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
                                                                 int accumulate, double diag_add,
                                                                 const double* __restrict__ f1,
                                                                 const double* __restrict__ f2, int vec_ok,
-                                                                const CovItem* __restrict__ items, int wg_rows) {
+                                                                const CovItem* __restrict__ items, int wg_rows, int f32out) {
   // wg_rows: rows handled per workgroup (<= COV_ROWS; fewer for small matrices, which otherwise occupy a handful of CUs)
   if (items) {
     const CovItem it = items[blockIdx.z];
     k = it.k; x1 = it.x1; n1 = it.n1; out = it.out; ld = it.ld;
     if (it.n2 >= 0) { x2 = it.x2; n2 = it.n2; }         // n2 < 0: every item shares the launch's x2 / n2 (the frames)
-    accumulate = it.accumulate; diag_add = it.diag_add; f1 = it.f1; f2 = it.f2; vec_ok = it.vec_ok;
+    accumulate = it.accumulate; diag_add = it.diag_add; f1 = it.f1; f2 = it.f2; vec_ok = it.vec_ok; f32out = it.f32out;
     if ((int)(blockIdx.y * wg_rows) >= n1) return;       // the grid is sized for the largest item
   }
   extern __shared__ double smem[];  // MODE 1: z-features for this block's rows [COV_ROWS][2m]
@@ -150,6 +166,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
         }
         if (self_cov && i == j0 + c) res[c] += diag_add;
       }
+      if (f32out) { cov_store_f32<CPT>(out, (size_t)i * ld + j0, n2 - j0, res, accumulate, vec_ok); continue; }
       double* o = out + (size_t)i * ld + j0;
       if (CPT == 2 && vec_ok && j0 + 1 < n2) {
         double2 v = make_double2(res[0], res[CPT - 1]);
@@ -194,6 +211,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   #pragma unroll
       for (int c = 0; c < CPT; c++)
         if (DIAG && i == j0 + c) res[c] += diag_add;
+      if (f32out) { cov_store_f32<CPT>(out, (size_t)i * ld + j0, n2 - j0, res, accumulate, vec_ok); continue; }
       double* o = out + (size_t)i * ld + j0;
       if (CPT == 2 && vec_ok && j0 + 1 < n2) {
         double2 v = make_double2(res[0], res[CPT - 1]);
@@ -234,14 +252,14 @@ size_t kernel_build_feat_ws_doubles(int m, int n1, int n2) {
 template <int MPAD>
 static void launch_mercer(gp_handle h, dim3 grid, DevKern k, const double* x1, int n1, const double* x2, int n2,
                           double* out, int64_t ld, int accumulate, double diag_add, const double* f1, const double* f2,
-                          int vec_ok, const CovItem* items, int rows = COV_ROWS) {
+                          int vec_ok, const CovItem* items, int rows = COV_ROWS, int f32out = 0) {
   size_t sh = (size_t)COV_ROWS * 2 * MPAD * sizeof(double);
   if (k.type == GP_KERN_MERCER_MATERN12SM)
     hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 0>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
-                       ld, accumulate, diag_add, f1, f2, vec_ok, items, rows);
+                       ld, accumulate, diag_add, f1, f2, vec_ok, items, rows, f32out);
   else
     hipLaunchKernelGGL((cov_build_kernel<1, 2, MPAD, 2>), grid, dim3(COV_THREADS), sh, h->stream, k, x1, n1, x2, n2, out,
-                       ld, accumulate, diag_add, f1, f2, vec_ok, items, rows);
+                       ld, accumulate, diag_add, f1, f2, vec_ok, items, rows, f32out);
 }
 
 // rows per workgroup: the full COV_ROWS for strips; small matrices (window-sized problems, Kuu) get more, smaller
@@ -254,11 +272,13 @@ static int cov_rows_for(int n1, int n2) {
 }
 
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
-                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws, int feat_ready) {
+                              double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws, int feat_ready,
+                              int f32out) {
   // feat_ready: the feature tables in feat_ws (layout of launch_sm_features: x1 block, then x2 block) are current
   if (n1 <= 0 || n2 <= 0) return GP_OK;
   if (x2 == nullptr) { x2 = x1; n2 = n1; }
   const int vec_ok = ((ld % 2) == 0) && ((((uintptr_t)out) & 15) == 0);
+  if (f32out && x2 == x1 && diag_add != 0.0) return gp_fail(h, GP_ERR_UNSUPPORTED, "float32 output is for Kuf strips, not Kuu");
   const bool big = (int64_t)n1 * n2 >= (1 << 20);   // M x N strips; the small Kuu builds are booked elsewhere
   GpTimerScope ts(h, !big ? GP_TIMER_SMALL_GEMM
                           : (gp_kern_is_mercer(k.type) ? GP_TIMER_KUF_BUILD_SM : GP_TIMER_KUF_BUILD));
@@ -278,26 +298,26 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
     const int rows = cov_rows_for(n1, n2);
     dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + rows - 1) / rows);
     switch (mp) {
-      case 4: launch_mercer<4>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
-      case 8: launch_mercer<8>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
-      case 12: launch_mercer<12>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
-      case 16: launch_mercer<16>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
-      case 20: launch_mercer<20>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
-      case 24: launch_mercer<24>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
-      case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
-      default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows); break;
+      case 4: launch_mercer<4>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
+      case 8: launch_mercer<8>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
+      case 12: launch_mercer<12>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
+      case 16: launch_mercer<16>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
+      case 20: launch_mercer<20>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
+      case 24: launch_mercer<24>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
+      case 28: launch_mercer<28>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
+      default: launch_mercer<32>(h, grid, k, x1, n1, x2, n2, out, ld, accumulate, diag_add, f1, f2, vec_ok, (const CovItem*)nullptr, rows, f32out); break;
     }
   } else if (gp_kern_is_broadcast(k.type)) {
     if (k.m < 1) return gp_fail(h, GP_ERR_BAD_ARG, "num_partials must be >= 1");
     const int rows = cov_rows_for(n1, n2);
     dim3 grid((n2 + COV_THREADS - 1) / COV_THREADS, (n1 + rows - 1) / rows);
     hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, x2, n2, out, ld,
-                       accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr, rows);
+                       accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr, rows, f32out);
   } else if (k.type >= GP_KERN_MATERN12 && k.type <= GP_KERN_RBF) {
     const int rows = cov_rows_for(n1, n2);
     dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + rows - 1) / rows);
 #define COV_STAT(T) hipLaunchKernelGGL((cov_build_kernel<0, 2, 1, T>), grid, dim3(COV_THREADS), 0, h->stream, k, x1, n1, \
-                                      x2, n2, out, ld, accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr, rows)
+                                      x2, n2, out, ld, accumulate, diag_add, nullptr, nullptr, vec_ok, (const CovItem*)nullptr, rows, f32out)
     switch (k.type) {
       case GP_KERN_MATERN12: COV_STAT(GP_KERN_MATERN12); break;
       case GP_KERN_MATERN32: COV_STAT(GP_KERN_MATERN32); break;
@@ -376,7 +396,10 @@ __global__ void __launch_bounds__(256) cov_mercer_mfma_kernel(const CovItem* __r
         double env;
         if (ENV == 0) env = gp_exp_neg(-rr, etab);
         else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
-        if (live && i < n1) out[(size_t)i * ld + j] = var * env * acc[r];
+        if (live && i < n1) {
+          if (it.f32out) reinterpret_cast<float*>(out)[(size_t)i * ld + j] = (float)(var * env * acc[r]);
+          else out[(size_t)i * ld + j] = var * env * acc[r];
+        }
       }
     }
   }
@@ -384,7 +407,8 @@ __global__ void __launch_bounds__(256) cov_mercer_mfma_kernel(const CovItem* __r
 
 // ---- grouped launches: all matrices of one kernel family (same type, same padded partial count) in one launch ----
 void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const double* x2, int n2, double* out, int64_t ld,
-                   int accumulate, double diag_add, double* feat_ws) {
+                   int accumulate, double diag_add, double* feat_ws, int f32out) {
+  it->f32out = f32out; it->pad_ = 0;
   if (!x2 && n2 >= 0) { x2 = x1; n2 = n1; }      // n2 < 0: x2 / n2 come from the launch (shared frames)
   it->k = k; it->x1 = x1; it->n1 = n1; it->x2 = x2; it->n2 = n2; it->out = out; it->ld = ld;
   it->accumulate = accumulate; it->diag_add = diag_add;
@@ -456,12 +480,12 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
     dim3 grid((max_n2 + COV_THREADS - 1) / COV_THREADS, (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
     hipLaunchKernelGGL((cov_build_kernel<2, 1, 1>), grid, dim3(COV_THREADS), 0, h->stream, k0, (const double*)nullptr, 0,
                        x2_shared, n2_shared, (double*)nullptr, (int64_t)0, 0, 0.0, (const double*)nullptr,
-                       (const double*)nullptr, 0, d_items, COV_ROWS);
+                       (const double*)nullptr, 0, d_items, COV_ROWS, 0);
   } else {
     dim3 grid((max_n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (max_n1 + COV_ROWS - 1) / COV_ROWS, count);
 #define COV_STAT_ITEMS(T) hipLaunchKernelGGL((cov_build_kernel<0, 2, 1, T>), grid, dim3(COV_THREADS), 0, h->stream, k0, \
                                             (const double*)nullptr, 0, x2_shared, n2_shared, (double*)nullptr,             \
-                                            (int64_t)0, 0, 0.0, (const double*)nullptr, (const double*)nullptr, 0, d_items, COV_ROWS)
+                                            (int64_t)0, 0, 0.0, (const double*)nullptr, (const double*)nullptr, 0, d_items, COV_ROWS, 0)
     switch (type) {
       case GP_KERN_MATERN12: COV_STAT_ITEMS(GP_KERN_MATERN12); break;
       case GP_KERN_MATERN32: COV_STAT_ITEMS(GP_KERN_MATERN32); break;

@@ -31,7 +31,7 @@ gp_status launch_tril_add_batched(gp_handle h, const GemmProblem* d_probs, int b
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
                                 const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
                                 const double* feat, double* partials, int* nparts, double* gz_partials,
-                                const double* kvals = nullptr, int64_t ldk = 0);
+                                const double* kvals = nullptr, int64_t ldk = 0, int g32 = 0);   // g32: G (and kvals) are float32 strips
 gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, int nparts, const double* gv_sum,
                               double* g_theta, const double* gz_partials, int ncolblocks, int n1, double* g_z);
 int hyper_num_sums(int m);
@@ -68,6 +68,7 @@ struct CondBatch {
   size_t off_chol_ptrs = 0, off_w_ptrs = 0, off_Ms = 0, off_lds = 0, off_f1 = 0, off_f1u = 0, off_f2 = 0, off_finish = 0;
   bool uploaded = false;
   bool overlap = true;    // run the Kuu factorisation on the handle's helper stream next to the Kuf builds
+  bool f32 = false;       // the M x N strips (Kuf, A) are float32 and the strip products run on the float32 matrix path
   // grouped covariance builds (one launch per kernel family)
   struct Group { int type = 0, m = 0, first = 0, maxM = 0; std::vector<int> members; };
   std::vector<Group> groups;
@@ -78,10 +79,10 @@ struct CondBatch {
   size_t off_diag_mats = 0, off_diag_w = 0, off_diag_M = 0, off_diag_ld = 0;   // all panels' diagonal blocks, one batch
 };
 
-size_t cond_task_workspace_doubles(int M, int N, int num_partials, bool whiten);
+size_t cond_task_workspace_doubles(int M, int N, int num_partials, bool whiten, bool f32 = false);
 size_t cond_batch_desc_bytes(int count);
 // carve the per-task buffers out of the arena
-bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten);
+bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten, bool f32 = false);
 gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitter);
 // run: Kuu -> chol -> W ; Kuf ; A = W Kuf ; (A2 = W^T A) ; Lq^T A ; reductions -> fmean, fvar
 gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter,

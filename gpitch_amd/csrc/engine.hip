@@ -5,33 +5,32 @@
 #include "engine.h"
 #include <string.h>
 
-static inline int ldN_of(int N) { return (N + 1) & ~1; }
 #define CB_NB 128          // panel width of the blocked Kuu factorisation
 #define CB_MAX_PANELS 8    // M <= 1024
 
-size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten) {
-  const size_t ldN = ldN_of(N);
+size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten, bool f32) {
+  const size_t strip = gp_strip_doubles((size_t)M, N, f32);
   const int rb = gemm_rowblocks(M, 1);
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   add((size_t)M * M); add((size_t)M * M);          // L, W
   add((size_t)CB_NB * M);                          // block-row scratch of the blocked inverse
-  add((size_t)M * ldN); add((size_t)M * ldN);      // Kuf, A
-  if (!whiten) add((size_t)M * ldN);               // A2
+  add(strip); add(strip);                          // Kuf, A
+  if (!whiten) add(strip);                         // A2
   if (m > 0) { add(kernel_build_feat_ws_doubles(m, M, N)); add(kernel_build_feat_ws_doubles(m, M, M)); }
   add((size_t)rb * N); add((size_t)rb * N); add((size_t)rb * N);  // s1, s2, dot
   return d;
 }
 
-bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten) {
-  const size_t ldN = ldN_of(N);
+bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten, bool f32) {
+  const size_t strip = gp_strip_doubles((size_t)t.M, N, f32);
   const int rb = gemm_rowblocks(t.M, 1);
   t.L = ar.take<double>((size_t)t.M * t.M);
   t.W = ar.take<double>((size_t)t.M * t.M);
   t.Tblk = ar.take<double>((size_t)CB_NB * t.M);
-  t.Kuf = ar.take<double>((size_t)t.M * ldN);
-  t.A = ar.take<double>((size_t)t.M * ldN);
-  t.A2 = whiten ? nullptr : ar.take<double>((size_t)t.M * ldN);
+  t.Kuf = ar.take<double>(strip);
+  t.A = ar.take<double>(strip);
+  t.A2 = whiten ? nullptr : ar.take<double>(strip);
   const bool mercer = (t.kern.m > 0 && gp_kern_is_mercer(t.kern.type));
   t.feat = mercer ? ar.take<double>(kernel_build_feat_ws_doubles(t.kern.m, t.M, N)) : nullptr;
   // the Kuu build has its own feature table: it runs concurrently with the Kuf build (cond_batch_run)
@@ -63,7 +62,8 @@ size_t cond_batch_desc_bytes(int count) {
 gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitter) {
   const int G = (int)cb.tasks.size();
   const int N = cb.N;
-  const int64_t ldN = ldN_of(N);
+  const int64_t ldN = gp_strip_ld(N, cb.f32);
+  if (cb.f32 && !whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "float32 strips: whitened conditionals only");
   size_t need = cond_batch_desc_bytes(G);
   if (cb.desc_bytes < need || !cb.d_desc) return gp_fail(h, GP_ERR_WORKSPACE, "descriptor workspace too small");
   cb.h_desc.assign(need, 0);
@@ -142,7 +142,7 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
         const CondTask& t = cb.tasks[g];
         if (t.M > gr.maxM) gr.maxM = t.M;
         cov_item_fill(&uu[pos], t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat_uu);
-        cov_item_fill(&uf[pos], t.kern, t.z, t.M, nullptr, -1, t.Kuf, ldN, 0, 0.0, t.feat);
+        cov_item_fill(&uf[pos], t.kern, t.z, t.M, nullptr, -1, t.Kuf, ldN, 0, 0.0, t.feat, cb.f32 ? 1 : 0);
         fzuu[pos] = FeatItem{t.kern, t.z, t.feat_uu, t.M, 0};
         fzuf[pos] = FeatItem{t.kern, t.z, t.feat, t.M, 0};
         const int mp = sm_mpad(t.kern.m);
@@ -346,7 +346,8 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     GemmFlags f;
     f.triA = TRI_LOWER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A; f.role = 1;
     f.epilogue = EPI_STORE | EPI_COLSUMSQ | (whiten ? EPI_COLDOT : 0);
-    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, f));
+    if (cb.f32) GP_CHECK(launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, f));
+    else GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, f));
   }
   if (!whiten) {
     GemmFlags f;
@@ -363,7 +364,8 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     GemmFlags f;
     f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_LTA; f.role = 2;
     f.epilogue = EPI_COLSUMSQ;
-    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
+    if (cb.f32) GP_CHECK(launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
+    else GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
   }
   // 6. fmean / fvar
   GP_CHECK(launch_cond_finish(h, cb.d_desc + cb.off_finish, G, N));

@@ -535,11 +535,14 @@ static gp_status launch_one(gp_handle h, const GemmProblem* d_probs, int batch, 
   int ntiles = df.tilesM * df.tilesN;
   if (ksplit > 1 && df.triC == TRI_LOWER) ntiles = df.tilesM * (df.tilesM + 1) / 2;
   dim3 grid(ntiles * (ksplit > 1 ? ksplit : 1), 1, batch);
-  static std::atomic<bool> attr_set{false};   // per instantiation; a repeated call from another thread is harmless
-  if (!attr_set.load(std::memory_order_acquire)) {
+  // the dynamic-LDS limit is a per-DEVICE attribute of the function: one bit per device, per instantiation (a
+  // repeated call from another thread is harmless)
+  static std::atomic<uint32_t> attr_devs{0};
+  const uint32_t bit = 1u << (h->device & 31);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
     GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f64_kernel<BM, BN, TA, TB, TAG>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
-    attr_set.store(true, std::memory_order_release);
+    attr_devs.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, TA, TB, TAG>), grid, dim3(gemm_threads(BM, TAG)), S::BYTES, h->stream, d_probs, df);
   GP_HIP_CHECK(h, hipGetLastError());
@@ -608,13 +611,14 @@ gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs,
     df.epi = 1;
     GP_CHECK((launch_one<128, 128, false, true, 4>(h, d_probs, batch, maxM, maxM, df, nsplit > 1 ? nsplit : 2)));
   }
-  {
-    GpTimerScope ts(h, GP_TIMER_SMALL_GEMM);
-    int blocks = (int)(((int64_t)maxM * maxM + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1, batch), dim3(256), 0, h->stream, d_probs,
-                       nsplit > 1 ? nsplit : 2, sym, alpha);
-    GP_HIP_CHECK(h, hipGetLastError());
-  }
+  return launch_slab_reduce(h, d_probs, batch, maxM, nsplit > 1 ? nsplit : 2, sym, alpha);
+}
+
+gp_status launch_slab_reduce(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int nsplit, int sym, double alpha) {
+  GpTimerScope ts(h, GP_TIMER_SMALL_GEMM);
+  int blocks = (int)(((int64_t)maxM * maxM + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1, batch), dim3(256), 0, h->stream, d_probs, nsplit, sym, alpha);
+  GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }

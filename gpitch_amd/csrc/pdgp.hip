@@ -4,7 +4,6 @@
 #include "pdgp_plan.h"
 #include <string.h>
 
-static inline int64_t ldN_of64(int N) { return (N + 1) & ~1; }
 
 static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
   size_t d = 0;
@@ -12,7 +11,7 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
   for (int g = 0; g < p->G; g++) {
     const size_t M = p->gps[g].M;
     for (int i = 0; i < 6; i++) add(M * M);
-    add(M * (size_t)ldN_of64(p->maxN));
+    add(gp_strip_doubles(M, p->maxN, p->f32 != 0));
     add(M); add(M); add(M); add((size_t)65 * M);
     const size_t ns = hyper_num_sums(p->gps[g].m);
     const size_t colblocks = (p->maxN + 255) / 256 + 1;
@@ -82,6 +81,14 @@ gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, 
   }
   return GP_OK;
 }
+gp_status gp_pdgp_set_precision(gp_pdgp_plan p, int32_t bits) {
+  if (!p || (bits != 32 && bits != 64)) return GP_ERR_BAD_ARG;
+  if (p->ws) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_pdgp_set_precision: call it before gp_pdgp_set_workspace");
+  if (bits == 32 && !p->whiten) return gp_fail(p->h, GP_ERR_UNSUPPORTED, "gp_pdgp_set_precision: float32 strips need whiten = 1");
+  p->f32 = (bits == 32);
+  p->cb.f32 = (bits == 32);
+  return GP_OK;
+}
 gp_status gp_pdgp_set_overlap(gp_pdgp_plan p, int32_t level) {
   if (!p || level < 0 || level > 2) return GP_ERR_BAD_ARG;
   p->overlap = level;
@@ -108,7 +115,7 @@ static size_t pdgp_misc_bytes(const gp_pdgp_plan_s* p) {
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   if (!p) return 0;
   size_t d = 0;
-  for (int g = 0; g < p->G; g++) d += cond_task_workspace_doubles(p->gps[g].M, p->maxN, p->gps[g].m, p->whiten != 0);
+  for (int g = 0; g < p->G; g++) d += cond_task_workspace_doubles(p->gps[g].M, p->maxN, p->gps[g].m, p->whiten != 0, p->f32 != 0);
   auto addd = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   for (int i = 0; i < 4; i++) addd((size_t)p->G * p->maxN);
   addd((size_t)p->G * GP_KL_BLOCKS);
@@ -147,7 +154,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
     CondTask& t = p->cb.tasks[g];
     t.M = p->gps[g].M;
     t.kern = DevKern{p->gps[g].ktype, p->gps[g].m, nullptr};
-    if (!cond_task_carve(ar, t, p->maxN, p->whiten != 0)) return gp_fail(p->h, GP_ERR_WORKSPACE, "workspace carve failed");
+    if (!cond_task_carve(ar, t, p->maxN, p->whiten != 0, p->f32 != 0)) return gp_fail(p->h, GP_ERR_WORKSPACE, "workspace carve failed");
   }
   p->bw.assign(p->G, BwdBufs());
   p->tr_part.assign(p->G, nullptr);
@@ -161,7 +168,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       BwdBufs& b = p->bw[g];
       b.H = ar.take<double>(M * M); b.E = ar.take<double>(M * M); b.T1 = ar.take<double>(M * M);
       b.T2 = ar.take<double>(M * M); b.Wbar = ar.take<double>(M * M); b.R = ar.take<double>(M * M);
-      b.G = ar.take<double>(M * (size_t)ldN_of64(p->maxN));
+      b.G = ar.take<double>(gp_strip_doubles(M, p->maxN, p->f32 != 0));
       b.u = ar.take<double>(M); b.Lu = ar.take<double>(M); b.alpha = ar.take<double>(M);
       b.upart = ar.take<double>((size_t)p->nsplit * M);
       const size_t ns = hyper_num_sums(p->gps[g].m);

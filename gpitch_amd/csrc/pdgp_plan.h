@@ -42,6 +42,7 @@ struct BwdBufs {  // per-GP backward workspace (device)
 struct gp_pdgp_plan_s {
   gp_handle h = nullptr;
   int P = 0, G = 0, whiten = 1, nlin = 0, maxN = 0;
+  int f32 = 0;               // gp_pdgp_set_precision: the M x N strips (Kuf, A, Kuf_bar) are float32 (gemm_f32.hip)
   double jitter = 1e-6;
   std::vector<PdgpGP> gps;
   int64_t nparams = 0;

@@ -11,6 +11,7 @@
 struct gp_sgpr_plan_s {
   gp_handle h = nullptr;
   int P = 0, maxN = 0, M = 0, reg = 0;
+  int f32 = 0;                 // gp_sgpr_set_precision: Kuf, A, Kuf_bar strips in float32 (gemm_f32.hip)
   double jitter = 1e-6;
   std::vector<int> ktype, m;
   std::vector<int64_t> off_theta;
@@ -172,16 +173,16 @@ static size_t sgpr_feat_stride(const gp_sgpr_plan_s* p) {
 static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
-  const size_t M = p->M, ld = ldN64(p->maxN);
+  const size_t M = p->M, strip = gp_strip_doubles(M, p->maxN, p->f32 != 0);
   const int rb = gemm_rowblocks(p->M, 1);
   for (int i = 0; i < 5; i++) add(M * M);           // L, W, H, LB, WB
-  add(M * ld); add(M * ld);                          // Kuf, A
+  add(strip); add(strip);                            // Kuf, A
   add(sgpr_feat_stride(p) * p->P);                   // one feature table per kernel of the sum
   add((size_t)rb * p->maxN); add((size_t)rb * p->maxN); add((size_t)rb * p->maxN);
   add(M); add(M); add(64);
   add((size_t)p->nsplit * M * M);
   for (int i = 0; i < 6; i++) add(M * M);            // E2, T1, T2, Wbar, R, Binv
-  add(M * ld); add(M); add(M); add(M); add(p->maxN);
+  add(strip); add(M); add(M); add(M); add(p->maxN);
   {
     const size_t ns = hyper_num_sums(p->maxm);
     add(ns * hyper_kuf_records(p->maxN, (int)M));
@@ -218,6 +219,12 @@ gp_status gp_sgpr_create(gp_handle h, const gp_sgpr_config* cfg, gp_sgpr_plan* o
 }
 
 gp_status gp_sgpr_destroy(gp_sgpr_plan p) { delete p; return GP_OK; }
+gp_status gp_sgpr_set_precision(gp_sgpr_plan p, int32_t bits) {
+  if (!p || (bits != 32 && bits != 64)) return GP_ERR_BAD_ARG;
+  if (p->ws) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_sgpr_set_precision: call it before gp_sgpr_set_workspace");
+  p->f32 = (bits == 32);
+  return GP_OK;
+}
 int64_t gp_sgpr_num_params(gp_sgpr_plan p) { return p ? p->nparams : 0; }
 size_t gp_sgpr_workspace_bytes(gp_sgpr_plan p) { return p ? sgpr_ws_doubles(p) * sizeof(double) + 2 * SG_DESC_BYTES + 4096 : 0; }
 
@@ -227,12 +234,12 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   if (!workspace || bytes < gp_sgpr_workspace_bytes(p) || (((uintptr_t)workspace) & 255))
     return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: workspace too small or not 256-byte aligned");
   GpArena ar(workspace, bytes);
-  const size_t M = p->M, ld = ldN64(p->maxN);
+  const size_t M = p->M, strip = gp_strip_doubles(M, p->maxN, p->f32 != 0);
   const int rb = gemm_rowblocks(p->M, 1);
   p->d_desc = ar.take<char>(2 * SG_DESC_BYTES);
   p->L = ar.take<double>(M * M); p->W = ar.take<double>(M * M); p->H = ar.take<double>(M * M);
   p->LB = ar.take<double>(M * M); p->WB = ar.take<double>(M * M);
-  p->Kuf = ar.take<double>(M * ld); p->A = ar.take<double>(M * ld);
+  p->Kuf = ar.take<double>(strip); p->A = ar.take<double>(strip);
   p->feat = ar.take<double>(sgpr_feat_stride(p) * p->P);
   p->s1 = ar.take<double>((size_t)rb * p->maxN); p->s2 = ar.take<double>((size_t)rb * p->maxN);
   p->dot = ar.take<double>((size_t)rb * p->maxN);
@@ -240,7 +247,7 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   p->slabs = ar.take<double>((size_t)p->nsplit * M * M);
   p->E2 = ar.take<double>(M * M); p->T1 = ar.take<double>(M * M); p->T2 = ar.take<double>(M * M);
   p->Wbar = ar.take<double>(M * M); p->R = ar.take<double>(M * M); p->Binv = ar.take<double>(M * M);
-  p->G = ar.take<double>(M * ld); p->ubar = ar.take<double>(M); p->Lu = ar.take<double>(M); p->alpha = ar.take<double>(M);
+  p->G = ar.take<double>(strip); p->ubar = ar.take<double>(M); p->Lu = ar.take<double>(M); p->alpha = ar.take<double>(M);
   p->ones = ar.take<double>(p->maxN);
   {
     const size_t ns = hyper_num_sums(p->maxm);
@@ -292,13 +299,14 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
                             const double* Z, SgDesc* desc) {
   gp_handle h = p->h;
   const int M = p->M;
-  const int64_t ld = ldN64(N);
+  const int f32 = p->f32;
+  const int64_t ld = gp_strip_ld(N, f32 != 0);
   const int rb = gemm_rowblocks(M, 1);
   std::vector<GemmProblem> probs(3);
   memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
   { GemmProblem& r = probs[0]; r.A = p->W; r.lda = M; r.B = p->Kuf; r.ldb = ld; r.C = p->A; r.ldc = ld; r.M = M; r.N = N; r.K = M; r.o0 = p->s1; }
   { GemmProblem& r = probs[1]; r.A = p->A; r.lda = ld; r.B = p->A; r.ldb = ld; r.C = p->H; r.ldc = M; r.M = M; r.N = M; r.K = N; r.o2 = p->slabs; }
-  { GemmProblem& r = probs[2]; r.A = p->A; r.lda = ld; r.M = M; r.N = N; r.v0 = Y; r.o0 = p->u; }
+  { GemmProblem& r = probs[2]; r.A = p->A; r.lda = ld; r.M = M; r.N = N; r.v0 = Y; r.o0 = p->u; r.a_f32 = f32; }
   GP_CHECK(sg_upload(p, probs, desc, 0));
   // Kuu, Kuf: GPflow Add kernel = sum over kern_list (sgpr_ss.py:42-43)
   for (int i = 0; i < p->P; i++) {
@@ -310,13 +318,15 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   GP_CHECK(launch_cholesky_inverse_single(h, p->L, p->W, M, M));
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
-    GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat + (size_t)i * sgpr_feat_stride(p), 1));
+    GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat + (size_t)i * sgpr_feat_stride(p), 1, f32));
   }
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ;
-    GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
+    if (f32) { f.role = 1; GP_CHECK(launch_gemm_f32_role(h, desc->probs + 0, 1, M, N, f)); }
+    else GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
   hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, p->scal + 2);
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, h->stream, Y, N, p->scal + 1);
-  GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
+  if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
+  else GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
   GP_CHECK(launch_rowdot_batched(h, desc->probs + 2, 1, M));
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
@@ -415,7 +425,8 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
                                const double* Z, double* grad, int include_replicated, const SgDesc& d) {
   gp_handle h = p->h;
   const int M = p->M;
-  const int64_t ld = ldN64(N);
+  const int f32 = p->f32;
+  const int64_t ld = gp_strip_ld(N, f32 != 0);
   GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
   enum { Q_BINV = 0, Q_UBAR, Q_EH, Q_WBAR, Q_LU, Q_RANK1, Q_R, Q_ALPHA, Q_G, Q_T2, Q_LBAR, Q_P, Q_T3, Q_S, Q_COUNT };
   std::vector<GemmProblem> pr(Q_COUNT);
@@ -461,7 +472,8 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
   GP_CHECK(launch_matvec_batched(h, D + Q_ALPHA, 1, M, 1));
   hipLaunchKernelGGL(fill_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, p->ones, N, 1.0);
   f = GemmFlags(); f.big_tiles = (M > 64); f.scale_mode = 1; f.timer = GP_TIMER_KUF_BAR; f.role = (M > 64) ? 3 : 0;
-  GP_CHECK(launch_gemm_batched(h, D + Q_G, 1, M, N, f));
+  if (f32) { f.role = 3; GP_CHECK(launch_gemm_f32_role(h, D + Q_G, 1, M, N, f)); }
+  else GP_CHECK(launch_gemm_batched(h, D + Q_G, 1, M, N, f));
   // Kuu side (same Cholesky-adjoint chain as the Pdgp backward)
   f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
   GP_CHECK(launch_gemm_batched(h, D + Q_T2, 1, M, M, f));
@@ -479,7 +491,7 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
     DevKern k = sg_kern(p, params, i);
     double* feat = p->feat + (size_t)i * sgpr_feat_stride(p);   // this kernel's (Z | X) features, from the forward pass
     int np_uf = 0, np_uu = 0;
-    GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, feat, p->hyp, &np_uf, nullptr));
+    GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, feat, p->hyp, &np_uf, nullptr, nullptr, 0, f32));
     GP_CHECK(launch_hyper_finish(h, k, p->hyp, np_uf, include_replicated ? p->scal + 4 : nullptr, grad + p->off_theta[i],
                                  nullptr, 0, M, nullptr));
     if (include_replicated) {
@@ -652,7 +664,8 @@ gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* 
   SgDesc d;
   GP_CHECK(sgpr_common(p, params, X, Y, N, Z, &d));
   const int M = p->M;
-  const int64_t ld = ldN64(n);
+  const int f32 = p->f32;
+  const int64_t ld = gp_strip_ld(n, f32 != 0);
   const int rb = gemm_rowblocks(M, 1);
   // tmp1 = W Kus (stored in A; colsumsq -> s1); tmp2 = WB tmp1 (colsumsq -> s2, dot with c -> dot)
   std::vector<GemmProblem> probs(2);
@@ -663,12 +676,14 @@ gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* 
   GP_CHECK(sg_upload(p, probs, &d2, 1));
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
-    GP_CHECK(launch_kernel_build(h, k, Z, M, Xnew, n, p->Kuf, ld, i > 0, 0.0, p->feat));
+    GP_CHECK(launch_kernel_build(h, k, Z, M, Xnew, n, p->Kuf, ld, i > 0, 0.0, p->feat, 0, f32));
   }
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ;
-    GP_CHECK(launch_gemm_batched(h, d2.probs + 0, 1, M, n, f)); }
+    if (f32) GP_CHECK(launch_gemm_f32_role(h, d2.probs + 0, 1, M, n, f));
+    else GP_CHECK(launch_gemm_batched(h, d2.probs + 0, 1, M, n, f)); }
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_COLSUMSQ | EPI_COLDOT;
-    GP_CHECK(launch_gemm_batched(h, d2.probs + 1, 1, M, n, f)); }
+    if (f32) GP_CHECK(launch_gemm_f32_role(h, d2.probs + 1, 1, M, n, f));
+    else GP_CHECK(launch_gemm_batched(h, d2.probs + 1, 1, M, n, f)); }
   hipLaunchKernelGGL(predict_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, p->dot, p->s1, p->s2, rb, n,
                      p->scal + 3, mean, var);
   GP_HIP_CHECK(h, hipGetLastError());

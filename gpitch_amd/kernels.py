@@ -41,7 +41,9 @@ class Kern(Parameterized):
         X2 = None if X2 is None else np.asarray(X2, dtype=np.float64).reshape(-1, 1)
         return X, X2
 
-    def K(self, X, X2=None, presliced=False):
+    def K(self, X, X2=None, presliced=False, float_type=None):
+        """float_type=np.float32: a float32 result (gp_kernel_build_f32; rows padded to a multiple of 4 floats on the
+        device, as the engine's Kuf strips are)"""
         h = _lib.default_handle()
         X, X2 = self._slice(X, X2)
         n1 = X.shape[0]
@@ -50,6 +52,12 @@ class Kern(Parameterized):
         d = _lib.KernelDesc(self.type_code, self.num_partials, th.data_ptr())
         dx1 = h.to_device(X)
         dx2 = None if X2 is None else h.to_device(X2)
+        if _lib.precision_bits(float_type) == 32:
+            ld = (n2 + 3) // 4 * 4
+            out32 = h.torch.zeros(n1, ld, dtype=h.torch.float32, device=h.device)
+            h.check(h.lib.gp_kernel_build_f32(h.h, C.byref(d), dx1.data_ptr(), n1,
+                                              None if dx2 is None else dx2.data_ptr(), n2, out32.data_ptr(), ld, 0))
+            return out32[:, :n2].cpu().numpy()
         out = h.empty(n1, n2)
         h.check(h.lib.gp_kernel_build(h.h, C.byref(d), dx1.data_ptr(), n1, None if dx2 is None else dx2.data_ptr(),
                                       n2, out.data_ptr(), n2, 0))

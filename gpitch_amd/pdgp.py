@@ -55,14 +55,22 @@ def pitch_assignment(num_sources, world_size, rank):
 
 class Pdgp(Parameterized):
     def __init__(self, x, y, z, kern, whiten=True, minibatch_size=None, nlinfun=logistic_tf, handle=None,
-                 max_predict_batch=None, shard=None):
+                 max_predict_batch=None, shard=None, float_type=None):
         """Pitch detection using Gaussian process (pdgp.py:49-111).
         x, y: (N,1) arrays; z = [[za_0..], [zc_0..]]; kern = [[kern_act...], [kern_com...]].
 
         shard=(rank, world) spreads ONE model over `world` GPUs (one process each): this rank's engine plan holds
         the pitches {p : p mod world == rank} (both GPs of a pitch), the likelihood noise is replicated, and each
         ELBO evaluation exchanges one all-reduce of 3n+1 doubles (include/gpitch_abi.h: gp_pdgp_elbo_begin/_end).
-        Every rank constructs the model with the same arguments."""
+        Every rank constructs the model with the same arguments.
+
+        float_type: the reference's `settings.dtypes.float_type` (pdgp.py:13), np.float64 (default) or np.float32.
+        With float32 the M x N strips (Kuf, Lm^-1 Kuf, Kuf_bar) and the four O(M^2 N) products are float32 on the
+        float32 matrix cores; parameters, Kuu, its Cholesky factor, all reductions, the likelihood and the
+        gradients stay float64 (include/gpitch_abi.h: gp_pdgp_set_precision).  Whitened models only."""
+        self._bits = _lib.precision_bits(float_type)
+        if self._bits == 32 and not whiten:
+            raise ValueError("float_type=float32 needs whiten=True")
         x = np.asarray(x, dtype=np.float64).reshape(-1, 1)
         y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
         if minibatch_size is None:
@@ -141,6 +149,8 @@ class Pdgp(Parameterized):
         plan = C.c_void_p()
         h.check(h.lib.gp_pdgp_create(h.h, C.byref(cfg), C.byref(plan)))
         self._plan = plan
+        if self._bits == 32:
+            h.check(h.lib.gp_pdgp_set_precision(plan, 32))
         n = self._nparams = int(h.lib.gp_pdgp_num_params(plan))
         self._layout = []
         for g in range(2 * P):

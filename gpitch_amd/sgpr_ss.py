@@ -23,7 +23,7 @@ class _Gaussian(Parameterized):
 
 
 class SGPRSS(Parameterized):
-    def __init__(self, X, Y, kern, Z, mean_function=None, reg=False, handle=None, shard=None):
+    def __init__(self, X, Y, kern, Z, mean_function=None, reg=False, handle=None, shard=None, float_type=None):
         """shard=(rank, world): ONE window spread over `world` GPUs by frames (one process each).  Every rank is
         built with the full X, Y; it uploads only its contiguous slice, and each bound / gradient evaluation
         exchanges one all-reduce of M^2 + M + 2 doubles (plus one of the small gradient vector): see
@@ -53,6 +53,9 @@ class SGPRSS(Parameterized):
                 raise ValueError("shard=(rank, world) needs 0 <= rank < world")
             shard = (rank, world)
         object.__setattr__(self, "_shard", shard)
+        # float_type: the reference's dtype setting (sgpr_ss.py:7 float_type = settings.dtypes.float_type); float32 puts
+        # the M x N strips and the strip products on the float32 matrix path (gp_sgpr_set_precision)
+        object.__setattr__(self, "_bits", _lib.precision_bits(float_type))
 
     def _frames(self):
         """frame indices this rank holds (all of them when unsharded): contiguous, sizes differ by at most one"""
@@ -93,6 +96,8 @@ class SGPRSS(Parameterized):
         plan = C.c_void_p()
         h.check(h.lib.gp_sgpr_create(h.h, C.byref(cfg), C.byref(plan)))
         self._plan, self._plan_key = plan, key
+        if self._bits == 32:
+            h.check(h.lib.gp_sgpr_set_precision(plan, 32))
         self._ws = h.workspace(h.lib.gp_sgpr_workspace_bytes(plan))
         h.check(h.lib.gp_sgpr_set_workspace(plan, self._ws.data_ptr(), self._ws.numel()))
         self._nparams = int(h.lib.gp_sgpr_num_params(plan))

@@ -91,6 +91,11 @@ int32_t gp_last_not_pd_index(gp_handle h);
  * `accumulate` != 0 adds into `out` (GPflow `Add` kernel: sgpr_ss.py:42-43). */
 gp_status gp_kernel_build(gp_handle h, const gp_kernel_desc* kern, const double* x1, int32_t n1,
                           const double* x2, int32_t n2, double* out, int64_t ld, int32_t accumulate);
+/* The same build with a float32 result (ld in floats; inputs and arithmetic float64, one rounding at the store):
+ * the Kuf strips of the configurations the reference would run with float_type = float32
+ * (gpitch/matern12_spectral_mixture.py:8-11 np_float_type). */
+gp_status gp_kernel_build_f32(gp_handle h, const gp_kernel_desc* kern, const double* x1, int32_t n1,
+                              const double* x2, int32_t n2, float* out, int64_t ld, int32_t accumulate);
 /* Kern.Kdiag(X): exact fill (matern12_spectral_mixture.py:58-62,119-121) */
 gp_status gp_kernel_diag(gp_handle h, const gp_kernel_desc* kern, int32_t n, double* out, int32_t accumulate);
 
@@ -113,6 +118,14 @@ gp_status gp_conditional_diag(gp_handle h, const gp_kernel_desc* kern, const dou
                               const double* z, int32_t M, const double* q_mu, const double* q_sqrt,
                               int32_t whiten, double jitter, double* fmean, double* fvar,
                               void* workspace, size_t workspace_bytes);
+
+/* float32 form of the whitened conditional (the reference's settings.dtypes.float_type = float32, pdgp.py:13):
+ * Kuf and A = Lm^-1 Kuf are float32 strips, both strip products run on v_mfma_f32_16x16x4_f32; Kmm, Lm, Lm^-1 and all
+ * reductions (sum A^2, A^T q_mu, sum LTA^2) are float64, as are the inputs and outputs.  Same workspace size bound. */
+gp_status gp_conditional_diag_f32(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N,
+                                  const double* z, int32_t M, const double* q_mu, const double* q_sqrt,
+                                  double jitter, double* fmean, double* fvar,
+                                  void* workspace, size_t workspace_bytes);
 
 /* gpflow.kullback_leiblers.gauss_kl(q_mu, q_sqrt, K=None) (pdgp.py:120-121 whitened; :126-129 with
  * K = kern.K(z) + jitter I built internally when kern != NULL).  Result to *out_host (syncs).
@@ -158,6 +171,14 @@ int64_t gp_pdgp_num_params(gp_pdgp_plan p);
 /* offsets into the parameter vector for GP index g in [0, 2P): g < P activation i=g, else component */
 gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t* off_z, int64_t* off_qmu,
                          int64_t* off_qsqrt);
+/* Arithmetic type of the O(M^2 N) part — the reference's `float_type` setting (pdgp.py:13,
+ * matern12_spectral_mixture.py:8-11; BASELINE configs 3 and 5 are quoted at fp32).  bits = 64 (default) or 32:
+ * with 32 the M x N strips Kuf, A = Lm^-1 Kuf and Kuf_bar are stored in float32 and the four strip products
+ * (A = W Kuf, Lq^T A, R (A D), A D A^T) run on v_mfma_f32_16x16x4_f32; parameters, Kuu, its Cholesky factor and inverse,
+ * every reduction over the inducing index or the frames, the likelihood, the KL terms and the gradient vector stay
+ * float64, so the ABI's buffers do not change type.  Whitened models only.  Call before gp_pdgp_workspace_bytes /
+ * gp_pdgp_set_workspace (the workspace is smaller).  Tolerance held against the float64 oracle: tests/test_gpu_f32.py. */
+gp_status gp_pdgp_set_precision(gp_pdgp_plan p, int32_t bits);
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p);
 gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes);
 
@@ -250,6 +271,10 @@ typedef struct {
 gp_status gp_sgpr_create(gp_handle h, const gp_sgpr_config* cfg, gp_sgpr_plan* out);
 gp_status gp_sgpr_destroy(gp_sgpr_plan p);
 int64_t gp_sgpr_num_params(gp_sgpr_plan p);
+/* as gp_pdgp_set_precision: float32 strips (Kuf, A = L^-1 Kuf, Kuf_bar) and float32 matrix-core strip products for
+ * the collapsed bound, its gradient and predict_f; Kuu, B = A A^T + I (accumulated in float64), both Cholesky factors
+ * and the bound's scalars stay float64.  predict_s (exact N x N posterior) is float64 regardless. */
+gp_status gp_sgpr_set_precision(gp_sgpr_plan p, int32_t bits);
 size_t gp_sgpr_workspace_bytes(gp_sgpr_plan p);
 gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes);
 /* SGPRSS.build_likelihood (sgpr_ss.py:29-71), D = 1 output column.  bound_host may be NULL. */

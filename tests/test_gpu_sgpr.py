@@ -9,13 +9,13 @@ pytestmark = pytest.mark.gpu
 from oracle import gpflow05 as orc  # noqa: E402
 
 
-def _model(X, Y, Z, kdicts, noise, handle, reg=False):
+def _model(X, Y, Z, kdicts, noise, handle, reg=False, float_type=None):
     import gpitch_amd
     from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm
     from gpitch_amd.sgpr_ss import SGPRSS
     ks = [MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=d["variance"],
                            lengthscales=d["lengthscales"]) for d in kdicts]
-    m = SGPRSS(X, Y, np.sum(ks), Z, reg=reg, handle=handle)
+    m = SGPRSS(X, Y, np.sum(ks), Z, reg=reg, handle=handle, float_type=float_type)
     m.likelihood.variance = noise
     return m
 
