@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor sheet); a bare VGPR-accumulator MFMA loop measures 70-76
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X FP32 matrix peak (v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD; guide: 155 measured)
 PEAK_HBM_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -29,14 +30,15 @@ def build_model(args, rank):
     import gpitch_amd
     from gpitch_amd.pdgp import Pdgp
     from gpitch_amd.synth import make_problem, pdgp_from_problem
+    ft = np.float32 if args.float_type == "f32" else np.float64
     if args.shard == "pitch":
         # ONE model over all ranks: same problem everywhere, rank r holds pitches p = r (mod world)
         world = int(os.environ.get("WORLD_SIZE", "1"))
         prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=0)
-        model = pdgp_from_problem(prob, shard=(rank, world) if world > 1 else None)
+        model = pdgp_from_problem(prob, shard=(rank, world) if world > 1 else None, float_type=ft)
     else:
         prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=rank)
-        model = pdgp_from_problem(prob)
+        model = pdgp_from_problem(prob, float_type=ft)
     model.za.fixed = True      # as demos/scripts/demo-modgp.py:40-41
     model.zc.fixed = True
     return prob, model
@@ -205,6 +207,10 @@ def main():
     ap.add_argument("--overlap", type=int, choices=[0, 1, 2], default=2,
                     help="gp_pdgp_set_overlap level: 0 one stream (clean single-kernel timings), 1 Kuu-side work on the "
                          "helper stream, 2 (library default) also H = A D A^T next to Kuf_bar")
+    ap.add_argument("--float-type", choices=["f64", "f32"], default="f64",
+                    help="f64 (the headline: the reference's float_type = float64); f32: the M x N strips and the four "
+                         "strip products in float32 (BASELINE configs 3 and 5 are quoted at fp32; tolerance in tests/test_gpu_f32.py)")
+    ap.add_argument("--no-f32-line", action="store_true", help="skip the extra cfg3 (M=256, fp32) measurement")
     ap.add_argument("--no-pitch-line", action="store_true",
                     help="multi-GPU window mode: skip the extra pitch-sharded (strong-scaling) measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -245,6 +251,26 @@ def main():
                        "pitches_per_rank_max": -(-args.P // world), "elbo_final": rp["elbo_final"]}
         del rp
 
+    cfg3 = None
+    if world == 1 and not args.no_f32_line and (args.N, args.M, args.P) == (32768, 512, 12) and args.float_type == "f64":
+        # BASELINE configs[2] at its own precision: 12-pitch transcription model, N=32768, M=256 per pitch, fp32 (an extra
+        # key; the headline above stays float64).  Same step, same timing protocol; float64 beside it.
+        model = res = None
+        torch.cuda.empty_cache()
+        cfg3 = {"workload": "pdgp ELBO step, N=32768 x M=256 x P=12, m=5 partials (BASELINE configs[2])",
+                "tolerance": "ELBO within 2e-4 relative of the float64 oracle (tests/test_gpu_f32.py: 4.7e-5 measured)"}
+        for ft in ("f32", "f64"):
+            a3 = argparse.Namespace(**vars(args))
+            a3.M, a3.partials, a3.float_type = 256, 5, ft
+            r3 = run_timed(a3, "window", rank, None)
+            tm = r3["timers"]
+            gem = sum(tm[k][0] for k in ("cond_A", "cond_LTA", "nt_gemm", "kuf_bar")) / args.steps
+            cfg3[ft] = {"value": args.steps / r3["elapsed"], "unit": "steps/s", "ms_per_step": r3["elapsed"] / args.steps * 1e3,
+                        "strip_gemm_ms_per_step": gem, "elbo_final": r3["elbo_final"]}
+            r3 = None
+            torch.cuda.empty_cache()
+        cfg3["dtype"] = "f32"
+        cfg3["speedup_over_f64"] = cfg3["f32"]["value"] / cfg3["f64"]["value"]
     if rank == 0:
         pitch = args.shard == "pitch" and world > 1
         G, M, N, T = 2 * n_local, args.M, args.N, 8      # latent GPs in this rank's launches
@@ -254,8 +280,15 @@ def main():
         per_launch = {k: (ms / max(n, 1)) for k, (ms, n) in timers.items()}
         dom = max(alg, key=lambda k: timers[k][0])
         dom_ms = per_launch[dom]
-        sym = {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
-               "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"}
+        f32 = args.float_type == "f32"
+        PEAK = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_F64_MFMA_TFLOPS
+        T = 4 if f32 else 8
+        if f32:
+            sym = {"cond_A": "gemm_f32_kernel<1>", "cond_LTA": "gemm_f32_kernel<2>", "nt_gemm": "gemm_f32_kernel<4>",
+                   "kuf_bar": "gemm_f32_kernel<3>"}
+        else:
+            sym = {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
+                   "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"}
         # roofline (by its definition): the dominant kernel's OWN algorithmic flops per launch / its OWN mean launch
         # duration (HIP events on the stream it is launched on).  At overlap level 2 other kernels share the chip with
         # it (the split-K product on the helper stream), which lengthens its launch: that shows up here, undisguised.
@@ -264,13 +297,13 @@ def main():
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (tools/make_traffic_json.py)
             tfile = os.path.join("profiles", "r02", "hbm_traffic.json")
             tj = json.load(open(os.path.join(ROOT, tfile)))
-            if (N, M, G, args.partials) == (32768, 512, 24, 20) and tj.get("overlap_level", 2) == args.overlap:
+            if (N, M, G, args.partials) == (32768, 512, 24, 20) and tj.get("overlap_level", 2) == args.overlap and not f32:
                 traffic = tj["kernels"][sym[dom].replace(" ", "")]["hbm_bytes"]
                 traffic_src = tfile + " (static: rocprofv3 --pmc passes of this command, not measured in this run)"
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK, "unit": "TFLOP/s",
+                "frac": achieved / PEAK, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": sym[dom], "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": alg[dom],
                 "overlap_level": args.overlap}
         # every strip product by the same definition, and the whole step: sum of algorithmic flops / ms_per_step
@@ -278,7 +311,7 @@ def main():
                           "achieved": (alg[k] / (per_launch[k] * 1e-3) / 1e12) if per_launch[k] > 0 else 0.0}
                       for k in alg}
         for v in per_kernel.values():
-            v["frac"] = v["achieved"] / PEAK_F64_MFMA_TFLOPS
+            v["frac"] = v["achieved"] / PEAK
         step_flops = sum(alg[k] * timers[k][1] for k in alg) / float(args.steps)
         step_tf = step_flops / (elapsed / args.steps) / 1e12
         kuf = {}
@@ -296,10 +329,11 @@ def main():
             "n_gpus": world, "backend": (args.backend if world > 1 else None),
             "rccl_ranks": (dist.get_world_size() if (dist is not None and args.backend == "nccl") else 0),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if pitch else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if pitch else "weak", "vs_baseline": None, "dtype": args.float_type, "data": "synthetic",
             "config": {"workload": "pdgp ELBO step (fwd + grad + Adam), N=%d frames x M=%d inducing x P=%d pitches "
-                                   "(2P=%d latent GPs), m=%d partials, float64, full batch; %s"
+                                   "(2P=%d latent GPs), m=%d partials, %s, full batch; %s"
                                    % (N, M, args.P, 2 * args.P, args.partials,
+                                      "float32 strips and strip products (float64 Kuu / reductions)" if f32 else "float64",
                                       "one model pitch-sharded over the GPUs (all-reduce of 3N+1 doubles per step)"
                                       if pitch else "one independent window per GPU"),
                        "N": N, "M": M, "P": args.P, "partials": args.partials, "whiten": True,
@@ -307,7 +341,7 @@ def main():
                        "overlap_level": args.overlap},
             "roofline": roof,
             "mfma_frac_step": {"algorithmic_flops_per_step": step_flops, "achieved": step_tf, "unit": "TFLOP/s",
-                               "peak": PEAK_F64_MFMA_TFLOPS, "frac": step_tf / PEAK_F64_MFMA_TFLOPS},
+                               "peak": PEAK, "frac": step_tf / PEAK},
             "roofline_strips": per_kernel,
             "roofline_kuf_build": kuf,
             "kernel_ms_per_step": {k: ms / args.steps for k, (ms, n) in timers.items()},
@@ -315,6 +349,8 @@ def main():
         }
         if extra_pitch is not None:
             out["pitch_sharded"] = extra_pitch
+        if cfg3 is not None:
+            out["cfg3_fp32"] = cfg3
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
             out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -103,12 +103,12 @@ def kernels_from_problem(prob):
     return [[mk(d) for d in prob["kern_act"]], [mk(d) for d in prob["kern_com"]]]
 
 
-def pdgp_from_problem(prob, whiten=True, minibatch_size=None, nlinfun=None, handle=None, shard=None):
+def pdgp_from_problem(prob, whiten=True, minibatch_size=None, nlinfun=None, handle=None, shard=None, float_type=None):
     import gpitch_amd
     from gpitch_amd.pdgp import Pdgp
     kern = kernels_from_problem(prob)
     m = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kern, whiten=whiten, minibatch_size=minibatch_size,
-             nlinfun=nlinfun or gpitch_amd.logistic_tf, handle=handle, shard=shard)
+             nlinfun=nlinfun or gpitch_amd.logistic_tf, handle=handle, shard=shard, float_type=float_type)
     for i in range(prob["P"]):
         m.q_mu_act[i].value = prob["q_mu_act"][i]
         m.q_mu_com[i].value = prob["q_mu_com"][i]
