@@ -251,6 +251,33 @@ def main():
                        "pitches_per_rank_max": -(-args.P // world), "elbo_final": rp["elbo_final"]}
         del rp
 
+    kuf_m5 = None
+    if world == 1 and (args.N, args.M, args.P) == (32768, 512, 12) and args.partials != 5 and not args.no_f32_line:
+        # the HBM-bound regime of the spectral-mixture Kuf build (m = 5 partials, the demo's size): forward passes only
+        model = res = None
+        torch.cuda.empty_cache()
+        from gpitch_amd.synth import make_problem, pdgp_from_problem
+        m5 = pdgp_from_problem(make_problem(args.N, args.M, args.P, num_partials=5, seed=0))
+        m5._pack()
+        h5 = m5._handle
+        for _ in range(2):
+            m5._elbo(False, sync=False)
+        torch.cuda.synchronize()
+        h5.check(h5.lib.gp_timers_enable(h5.h, 1))
+        h5.check(h5.lib.gp_timers_reset(h5.h))
+        for _ in range(5):
+            m5._elbo(False, sync=False)
+        torch.cuda.synchronize()
+        h5.check(h5.lib.gp_timers_enable(h5.h, 0))
+        ms5, n5 = h5.timers()["kuf_build_sm"]
+        if n5:
+            b5 = args.P * (8 * (float(args.M) * args.N + args.N + args.M) + 8 * 2.0 * 5 * (args.M + args.N))
+            kuf_m5 = {"bound": "hbm", "partials": 5, "achieved": b5 / (ms5 / n5 * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                      "unit": "GB/s", "frac": b5 / (ms5 / n5 * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_launch_ms": ms5 / n5,
+                      "algorithmic_bytes_per_launch": b5, "latent_gps_per_launch": args.P,
+                      "note": "forward-only evaluations of the same model with m = 5 partials"}
+        m5 = None
+        torch.cuda.empty_cache()
     cfg3 = None
     if world == 1 and not args.no_f32_line and (args.N, args.M, args.P) == (32768, 512, 12) and args.float_type == "f64":
         # BASELINE configs[2] at its own precision: 12-pitch transcription model, N=32768, M=256 per pitch, fp32 (an extra
@@ -324,6 +351,17 @@ def main():
                 a = byts / (ms / n * 1e-3) / 1e9
                 kuf[name] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
                              "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": byts, "latent_gps_per_launch": gps}
+        # Kuf build of the spectral-mixture family, both rooflines (HBM-bound only for m <~ 13): the
+        # float64 arithmetic of one entry is 4m (feature dot, on the matrix cores) + ~25 (distance, sqrt, exp) flops
+        if "kuf_build_sm" in kuf:
+            k = kuf["kuf_build_sm"]
+            fl = k["latent_gps_per_launch"] * float(M) * N * (4.0 * args.partials + 25.0)
+            k["partials"] = args.partials
+            k["compute_roofline"] = {"bound": "f64 (vector + matrix share the DP units)", "algorithmic_flops_per_launch": fl,
+                                     "achieved": fl / (k["avg_launch_ms"] * 1e-3) / 1e12, "peak": PEAK_F64_MFMA_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": fl / (k["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+        if kuf_m5 is not None:
+            kuf["kuf_build_sm_m5"] = kuf_m5
         out = {
             "metric": "ELBO-steps/sec", "value": (1 if pitch else world) * args.steps / elapsed, "unit": "steps/s",
             "n_gpus": world, "backend": (args.backend if world > 1 else None),

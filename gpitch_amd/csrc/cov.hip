@@ -16,6 +16,17 @@
 #ifndef GP_COV_NT_STORE
 #define GP_COV_NT_STORE 1
 #endif
+// Pointers that reach a kernel through a descriptor struct in memory are generic to the compiler, which then emits
+// FLAT loads / stores: those count on lgkmcnt as well as vmcnt, so every LDS wait in a row loop (the exp table, the
+// staged features, the transposition tile) would also wait for the covariance stores in flight.  Typed as
+// address-space-1 they become global_load / global_store.
+typedef const double __attribute__((address_space(1))) * cov_gcptr;
+typedef double __attribute__((address_space(1))) * cov_gptr;
+typedef float __attribute__((address_space(1))) * cov_gfptr;
+typedef double cov_d2 __attribute__((ext_vector_type(2)));
+typedef float cov_f2 __attribute__((ext_vector_type(2)));
+typedef cov_d2 __attribute__((address_space(1))) * cov_gptr2;
+typedef cov_f2 __attribute__((address_space(1))) * cov_gfptr2;
 #define COV_THREADS 256
 #define COV_ROWS 32  // rows (inducing points) handled per block
 
@@ -39,13 +50,13 @@ __device__ __forceinline__ double r2_expand(double a, double aa, double b, doubl
 
 // store CPT results of one row as float32 (the strips of a float32 plan; `off` and the leading dimension count floats)
 template <int CPT>
-__device__ __forceinline__ void cov_store_f32(double* out, size_t off, int cols_left, const double* res, int accumulate,
+__device__ __forceinline__ void cov_store_f32(cov_gptr out, size_t off, int cols_left, const double* res, int accumulate,
                                               int vec_ok) {
-  float* o = reinterpret_cast<float*>(out) + off;
+  const cov_gfptr o = (cov_gfptr)out + off;
   if (CPT == 2 && vec_ok && cols_left > 1) {
-    float2 v = make_float2((float)res[0], (float)res[CPT - 1]);
-    if (accumulate) { const float2 old = *reinterpret_cast<float2*>(o); v.x += old.x; v.y += old.y; }
-    *reinterpret_cast<float2*>(o) = v;
+    cov_f2 v = cov_f2{(float)res[0], (float)res[CPT - 1]};
+    if (accumulate) { const cov_f2 old = *(cov_gfptr2)o; v.x += old.x; v.y += old.y; }
+    *(cov_gfptr2)o = v;
   } else {
 #pragma unroll
     for (int c = 0; c < CPT; c++)
@@ -95,6 +106,8 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
     accumulate = it.accumulate; diag_add = it.diag_add; f1 = it.f1; f2 = it.f2; vec_ok = it.vec_ok; f32out = it.f32out;
     if ((int)(blockIdx.y * wg_rows) >= n1) return;       // the grid is sized for the largest item
   }
+  const cov_gcptr gx1 = (cov_gcptr)x1, gx2 = (cov_gcptr)x2, gf1 = (cov_gcptr)f1, gf2 = (cov_gcptr)f2;
+  const cov_gptr gout = (cov_gptr)out;
   extern __shared__ double smem[];  // MODE 1: z-features for this block's rows [COV_ROWS][2m]
   __shared__ double row_a[COV_ROWS];  // x1[i] / lengthscale (the exact quotient, computed once per row, not per entry)
   __shared__ double etab[GP_EXP_TAB];
@@ -110,13 +123,13 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   const int jb0 = blockIdx.x * COV_THREADS * CPT;
   const bool self_cov = (x2 == x1) && (diag_add != 0.0) && (jb0 < i0 + wg_rows) && (jb0 + COV_THREADS * CPT > i0);
 
-  if (threadIdx.x < COV_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / th[1] : 0.0;   // (rows beyond wg_rows unused)
+  if (threadIdx.x < COV_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? gx1[i0 + threadIdx.x] / th[1] : 0.0;   // (rows beyond wg_rows unused)
   if (MODE != 1) __syncthreads();
   if (MODE == 1) {
     // stage this block's row features: smem[(i - i0) * 2*MPAD + q] = f1[q][i]
     for (int t = threadIdx.x; t < COV_ROWS * 2 * MPAD; t += COV_THREADS) {
       int q = t / COV_ROWS, ii = t % COV_ROWS;
-      smem[ii * 2 * MPAD + q] = (ii < wg_rows && i0 + ii < n1) ? f1[(size_t)q * n1 + i0 + ii] : 0.0;
+      smem[ii * 2 * MPAD + q] = (ii < wg_rows && i0 + ii < n1) ? gf1[(size_t)q * n1 + i0 + ii] : 0.0;
     }
     __syncthreads();
   }
@@ -126,7 +139,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
 #pragma unroll
   for (int c = 0; c < CPT; c++) {
     int j = min(j0 + c, n2 - 1);
-    xb[c] = x2[j];
+    xb[c] = gx2[j];
     b[c] = xb[c] / ls;
     bb[c] = __dmul_rn(b[c], b[c]);
   }
@@ -139,7 +152,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
 #pragma unroll
       for (int c = 0; c < CPT; c++) {
         int j = min(j0 + c, n2 - 1);
-        fx[c][q] = f2[(size_t)q * n2 + j];
+        fx[c][q] = gf2[(size_t)q * n2 + j];
       }
     }
     for (int i = i0; i < iend; i++) {
@@ -166,12 +179,12 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
         }
         if (self_cov && i == j0 + c) res[c] += diag_add;
       }
-      if (f32out) { cov_store_f32<CPT>(out, (size_t)i * ld + j0, n2 - j0, res, accumulate, vec_ok); continue; }
-      double* o = out + (size_t)i * ld + j0;
+      if (f32out) { cov_store_f32<CPT>(gout, (size_t)i * ld + j0, n2 - j0, res, accumulate, vec_ok); continue; }
+      const cov_gptr o = gout + (size_t)i * ld + j0;
       if (CPT == 2 && vec_ok && j0 + 1 < n2) {
-        double2 v = make_double2(res[0], res[CPT - 1]);
-        if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
-        *reinterpret_cast<double2*>(o) = v;
+        cov_d2 v = cov_d2{res[0], res[CPT - 1]};
+        if (accumulate) { const cov_d2 old = *(cov_gptr2)o; v.x += old.x; v.y += old.y; }
+        *(cov_gptr2)o = v;
       } else {
 #pragma unroll
         for (int c = 0; c < CPT; c++)
@@ -185,7 +198,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   auto rows = [&](auto diag_tag) {
     constexpr bool DIAG = decltype(diag_tag)::value;
     for (int i = i0; i < iend; i++) {
-      double xa = x1[i];
+      double xa = gx1[i];
       double res[CPT];
       if (MODE == 0) {
         double a = row_a[i - i0], aa = __dmul_rn(a, a);
@@ -211,13 +224,13 @@ __global__ void __launch_bounds__(COV_THREADS) cov_build_kernel(DevKern k, const
   #pragma unroll
       for (int c = 0; c < CPT; c++)
         if (DIAG && i == j0 + c) res[c] += diag_add;
-      if (f32out) { cov_store_f32<CPT>(out, (size_t)i * ld + j0, n2 - j0, res, accumulate, vec_ok); continue; }
-      double* o = out + (size_t)i * ld + j0;
+      if (f32out) { cov_store_f32<CPT>(gout, (size_t)i * ld + j0, n2 - j0, res, accumulate, vec_ok); continue; }
+      const cov_gptr o = gout + (size_t)i * ld + j0;
       if (CPT == 2 && vec_ok && j0 + 1 < n2) {
-        double2 v = make_double2(res[0], res[CPT - 1]);
-        if (accumulate) { double2 old = *reinterpret_cast<double2*>(o); v.x += old.x; v.y += old.y; }
-        if (GP_COV_NT_STORE && !accumulate) { __builtin_nontemporal_store(v.x, o); __builtin_nontemporal_store(v.y, o + 1); }
-        else *reinterpret_cast<double2*>(o) = v;
+        cov_d2 v = cov_d2{res[0], res[CPT - 1]};
+        if (accumulate) { const cov_d2 old = *(cov_gptr2)o; v.x += old.x; v.y += old.y; }
+        if (GP_COV_NT_STORE && !accumulate) __builtin_nontemporal_store(v, (cov_gptr2)o);
+        else *(cov_gptr2)o = v;
       } else {
   #pragma unroll
         for (int c = 0; c < CPT; c++)
@@ -333,74 +346,127 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
 }
 
 // Matrix-core form of the Mercer Kuf strip.  K[i][j] = var phi(r_ij) * sum_f Zf[i][f] Xf[j][f] with 2m features per
-// point: the feature dot product is a (rows x 2m) x (2m x cols) GEMM.  The float64 MFMA peak equals the float64 VALU
-// peak, so this is not about flops: in the VALU kernel every row feature reaches the lanes as a broadcast LDS read
-// (64 lanes x 8 B through the LDS return path per value) and that path co-limits it; here a feature fragment is read
-// once per 16 x 16 outputs and the vector pipe keeps only the envelope (sqrt + exp).  One workgroup owns 64 columns
-// (16 per wave) and walks all rows; Kuf strips only (no diagonal, no accumulation); blockIdx.y = item.
-#define CVM_ROWS 32
+// point: the feature dot product is a (rows x 2m) x (2m x cols) GEMM on v_mfma_f64_16x16x4_f64, the vector pipe keeps
+// only the envelope (distance, sqrt, exp).  One workgroup owns 256 columns (64 per wavefront) and walks all rows in
+// chunks of 32:
+//  - the column (frame) feature fragments of a wavefront's 64 columns do not change over the row loop: they are loaded
+//    once, straight from the feature table, and stay in registers (4 column tiles x 2m/4 k-steps);
+//  - the row (inducing-point) features of a chunk are staged once per workgroup in LDS and each A fragment read feeds
+//    four MFMAs (one per column tile);
+//  - the MFMA result layout puts 16 consecutive columns of FOUR different rows on a wavefront's lanes, so a direct store
+//    writes 4 x 128-byte pieces per instruction (this kernel's first form: 2.1 TB/s).  Results go through a per-wave
+//    LDS tile instead and leave as whole 512-byte row segments, 16 bytes per lane, with non-temporal stores — the
+//    four wavefronts of a workgroup cover 2 KiB of every row.
+// Kuf strips only (no diagonal term, no accumulation); blockIdx.y = item.
+#define CVM_ROWS 32                  // rows per staged chunk (2 row tiles)
+#define CVM_WCOLS 64                 // columns per wavefront
+#define CVM_TS (CVM_WCOLS + 2)       // LDS row stride of the transposition tile (doubles): rows stay 16-byte aligned
+// Measured on MI355X (profiles/r02): direct stores 0.82 ms per 12-GP launch; LDS-transposed 512-byte row stores 0.78;
+// address-space-1 pointers (the descriptor's pointers are generic, so the stores were FLAT and every LDS wait of the
+// row loop waited for them) 0.62.  What is left is arithmetic: the float64 MFMA and the float64 vector pipe do not
+// overlap on this chip (the matrix rate equals the vector rate: the same units), so the 40 MFMAs (2.6 k cycles) and
+// the ~530 vector instructions (2.9 k cycles) of a 16 x 64 tile add up whether one wavefront interleaves them (a
+// software-pipelined form of this loop, sched_barrier-pinned, ran 0.82 ms) or two co-resident wavefronts run them out
+// of phase (splitting the rows over more workgroups to shorten the last round changed nothing either: 0.65 ms).  The row
+// range can be split over blockIdx.z; the launcher does so only when the column blocks alone would not fill the device.
 template <int MPAD, int ENV>
-__global__ void __launch_bounds__(256) cov_mercer_mfma_kernel(const CovItem* __restrict__ items,
-                                                              const double* __restrict__ x2s, int n2s) {
+__global__ void __launch_bounds__(256, 2) cov_mercer_mfma_kernel(const CovItem* __restrict__ items,
+                                                                 const double* __restrict__ x2s, int n2s, int row_seg) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int NF = 2 * MPAD;          // features per point (a multiple of 8)
+  constexpr int KS = NF / 4;            // MFMA k-steps
   constexpr int FS = NF + 1;            // odd LDS stride
+  constexpr int CT = CVM_WCOLS / 16;    // column tiles per wavefront
   const CovItem it = items[blockIdx.y];
-  const double* __restrict__ x1 = it.x1;
+  const cov_gcptr x1 = (cov_gcptr)it.x1;
   const int n1 = it.n1;
-  const double* __restrict__ x2 = (it.n2 >= 0) ? it.x2 : x2s;
+  const cov_gcptr x2 = (cov_gcptr)((it.n2 >= 0) ? it.x2 : x2s);
   const int n2 = (it.n2 >= 0) ? it.n2 : n2s;
-  double* __restrict__ out = it.out;
+  const cov_gptr out = (cov_gptr)it.out;
+  const cov_gcptr gf1 = (cov_gcptr)it.f1, gf2 = (cov_gcptr)it.f2, th = (cov_gcptr)it.k.theta;
   const int64_t ld = it.ld;
-  __shared__ double xf[64 * FS];            // column features of this workgroup's 64 columns
-  __shared__ double zf[CVM_ROWS * FS];      // row features of the current 32-row chunk
+  __shared__ double zf[CVM_ROWS * FS];            // row features of the current 32-row chunk
   __shared__ double rowa[CVM_ROWS];
   __shared__ double etab[GP_EXP_TAB];
+  __shared__ __attribute__((aligned(16))) double tbuf[4][16 * CVM_TS];   // per-wave 16 x 64 transposition tile
   gp_exp_tab_init(etab);
-  const double* th = it.k.theta;
   const double var = th[0], ls = th[1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
-  const int jb = blockIdx.x * 64;
-  if (jb >= n2) return;
-  for (int t = tid; t < 64 * NF; t += 256) {
-    const int f = t / 64, c = t % 64;      // consecutive threads read consecutive points of one feature row
-    xf[c * FS + f] = (jb + c < n2) ? it.f2[(size_t)f * n2 + jb + c] : 0.0;
+  const int jw = blockIdx.x * (4 * CVM_WCOLS) + wave * CVM_WCOLS;   // first column of this wavefront
+  const int rbeg = blockIdx.z * row_seg, rend = min(n1, rbeg + row_seg);   // this workgroup's rows (row_seg % 32 == 0)
+  if ((int)(blockIdx.x * (4 * CVM_WCOLS)) >= n2 || rbeg >= n1) return;
+  // column-side operands, loop-invariant: B fragments B[k = 4 s + kq][j = lc] of each column tile, scaled inputs
+  double bfr[CT][KS], bsc[CT], bb[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    const int j = jw + ct * 16 + lc;
+    const bool on = (j < n2);
+    const int jc = on ? j : n2 - 1;
+#pragma unroll
+    for (int s = 0; s < KS; s++) bfr[ct][s] = on ? gf2[(size_t)(4 * s + kq) * n2 + jc] : 0.0;
+    bsc[ct] = x2[jc] / ls;
+    bb[ct] = __dmul_rn(bsc[ct], bsc[ct]);
   }
-  const int j = jb + wave * 16 + lc;
-  const bool live = (j < n2);
-  const double bsc = x2[live ? j : n2 - 1] / ls, bb = __dmul_rn(bsc, bsc);
-  for (int r0 = 0; r0 < n1; r0 += CVM_ROWS) {
+  double* tw = tbuf[wave];
+  const int srow = lane >> 5, scol = (lane & 31) * 2;      // store phase: 2 rows x 32 column pairs per instruction
+  const bool vec = it.vec_ok && ((jw & 1) == 0);
+  for (int r0 = rbeg; r0 < rend; r0 += CVM_ROWS) {
     __syncthreads();
     for (int t = tid; t < CVM_ROWS * NF; t += 256) {
       const int f = t / CVM_ROWS, ii = t % CVM_ROWS;
-      zf[ii * FS + f] = (r0 + ii < n1) ? it.f1[(size_t)f * n1 + r0 + ii] : 0.0;
+      zf[ii * FS + f] = (r0 + ii < n1) ? gf1[(size_t)f * n1 + r0 + ii] : 0.0;
     }
     if (tid < CVM_ROWS) rowa[tid] = (r0 + tid < n1) ? x1[r0 + tid] / ls : 0.0;
     __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < CVM_ROWS / 16; rt++) {
-      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+      if (r0 + rt * 16 >= n1) break;
+      d4 acc[CT];
 #pragma unroll
-      for (int s = 0; s < NF / 4; s++) {
+      for (int ct = 0; ct < CT; ct++) acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
         const double af = zf[(rt * 16 + lc) * FS + 4 * s + kq];            // A[i = lc][k = kq]
-        const double bf = xf[(wave * 16 + lc) * FS + 4 * s + kq];           // B[k = kq][j = lc]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bfr[ct][s], acc[ct], 0, 0, 0);
       }
-      // element r of acc: row 16 rt + kq + 4 r, column lc
+      // envelope; element r of acc[ct]: row 16 rt + kq + 4 r, column 16 ct + lc of this wavefront's strip
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int li = rt * 16 + kq + 4 * r, i = r0 + li;
-        const double a = rowa[li], aa = __dmul_rn(a, a);
-        const double rr = gp_sqrt_pos(__dadd_rn(__dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, bsc), aa), bb), 1e-12));
-        double env;
-        if (ENV == 0) env = gp_exp_neg(-rr, etab);
-        else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
-        if (live && i < n1) {
-          if (it.f32out) reinterpret_cast<float*>(out)[(size_t)i * ld + j] = (float)(var * env * acc[r]);
-          else out[(size_t)i * ld + j] = var * env * acc[r];
+        const int li = rt * 16 + kq + 4 * r;
+        const double a = rowa[li], aa = __dmul_rn(a, a), m2a = -2.0 * a;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+          // (-2 (a b) + a a) + b b, every operation rounded on its own (scaling by -2 is exact)
+          const double rr = gp_sqrt_pos(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m2a, bsc[ct]), aa), bb[ct]), 1e-12));
+          double env;
+          if (ENV == 0) env = gp_exp_neg(-rr, etab);
+          else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
+          tw[(kq + 4 * r) * CVM_TS + ct * 16 + lc] = var * env * acc[ct][r];
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();          // LDS operations of one wavefront complete in order
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int lr = 2 * q + srow, i = r0 + rt * 16 + lr, j = jw + scol;
+        const cov_d2 v = *reinterpret_cast<const cov_d2*>(tw + lr * CVM_TS + scol);
+        if (i < n1 && j < n2) {
+          if (it.f32out) {
+            const cov_gfptr o = (cov_gfptr)out + (size_t)i * ld + j;
+            if (vec && j + 1 < n2) __builtin_nontemporal_store(cov_f2{(float)v.x, (float)v.y}, (cov_gfptr2)o);
+            else { o[0] = (float)v.x; if (j + 1 < n2) o[1] = (float)v.y; }
+          } else {
+            const cov_gptr o = out + (size_t)i * ld + j;
+            if (vec && j + 1 < n2) __builtin_nontemporal_store(v, (cov_gptr2)o);
+            else { o[0] = v.x; if (j + 1 < n2) o[1] = v.y; }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();          // the tile is rewritten by the next row tile
     }
   }
 }
@@ -441,13 +507,18 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
     if (m < 1 || m > 32) return gp_fail(h, GP_ERR_UNSUPPORTED, "num_partials must be in [1, 32]");
     if (x2_shared && big) {
       // Kuf strips (shared frames, nothing accumulated, no diagonal): matrix-core form
-      dim3 gm((max_n2 + 63) / 64, count);
+      // rows split only while the grid is smaller than the 512 workgroups the device holds (row segments are multiples of 32)
+      const int colblk = (max_n2 + 4 * CVM_WCOLS - 1) / (4 * CVM_WCOLS);
+      int nseg = 1;
+      while (nseg < 8 && (int64_t)colblk * count * nseg < 512 && (max_n1 + nseg * 2 - 1) / (nseg * 2) >= 2 * CVM_ROWS) nseg *= 2;
+      const int row_seg = ((max_n1 + nseg - 1) / nseg + CVM_ROWS - 1) / CVM_ROWS * CVM_ROWS;
+      dim3 gm(colblk, count, (max_n1 + row_seg - 1) / row_seg);
 #define COV_MFMA(MP)                                                                                                   \
       do {                                                                                                             \
         if (type == GP_KERN_MERCER_MATERN12SM)                                                                         \
-          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared); \
+          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else                                                                                                           \
-          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 2>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared); \
+          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 2>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
       } while (0)
       switch (sm_mpad(m)) {
         case 4: COV_MFMA(4); break;
