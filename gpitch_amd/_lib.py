@@ -32,6 +32,8 @@ ABI_SYMBOLS = [
     "gp_overlap_merge", "gp_transform_register_logistic", "gp_transform_forward", "gp_transform_backward", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace", "gp_sgpr_set_precision",
     "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_exchange_doubles", "gp_sgpr_bound_begin", "gp_sgpr_bound_end", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
+    "gp_sgprb_create", "gp_sgprb_destroy", "gp_sgprb_num_params", "gp_sgprb_num_windows", "gp_sgprb_workspace_bytes",
+    "gp_sgprb_set_workspace", "gp_sgprb_bound_grad", "gp_sgprb_set_graphs", "gp_sgprb_eval_counts",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
 ]
 
@@ -151,6 +153,15 @@ def load_library():
         "gp_sgpr_predict_f": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
         "gp_sgpr_predict_source_workspace_bytes": (sz, [i32, i32]),
         "gp_sgpr_predict_source": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, sz]),
+        "gp_sgprb_create": (i32, [vp, C.POINTER(SgprConfig), i32, C.POINTER(vp)]),
+        "gp_sgprb_destroy": (i32, [vp]),
+        "gp_sgprb_num_params": (i64, [vp]),
+        "gp_sgprb_num_windows": (i32, [vp]),
+        "gp_sgprb_workspace_bytes": (sz, [vp]),
+        "gp_sgprb_set_workspace": (i32, [vp, vp, sz]),
+        "gp_sgprb_bound_grad": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
+        "gp_sgprb_set_graphs": (i32, [vp, i32]),
+        "gp_sgprb_eval_counts": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
         "gp_timers_enable": (i32, [vp, i32]),
         "gp_timers_reset": (i32, [vp]),
         "gp_timers_read": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(i64)]),

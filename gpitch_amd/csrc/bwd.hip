@@ -166,7 +166,13 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
                                                                     const double* __restrict__ f1,
                                                                     const double* __restrict__ f2,
                                                                     double* __restrict__ partials,
-                                                                    double* __restrict__ gz_part, int wg_rows, int g32) {
+                                                                    double* __restrict__ gz_part, int wg_rows, int g32,
+                                                                    const HyperItem* __restrict__ items) {
+  if (items) {     // one launch for many contractions (window-batched SGPR plans): blockIdx.z = item
+    const HyperItem it = items[blockIdx.z];
+    k = it.k; x1 = it.x1; n1 = it.n1; x2 = it.x2; n2 = it.n2; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
+    symmetric = it.symmetric; f1 = it.f1; f2 = it.f2; partials = it.partials; gz_part = it.gz;
+  }
   extern __shared__ double smem[];  // [HY_ROWS][2*MPAD] row features | omega[MPAD] | reduction scratch
   const double* th = k.theta;
   const double var = th[0], ls = th[1];
@@ -466,7 +472,13 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
                                                                  const double* __restrict__ alpha,
                                                                  const double* __restrict__ gm, int symmetric,
                                                                  double* __restrict__ partials,
-                                                                 double* __restrict__ gz_part, int wg_rows, int g32) {
+                                                                 double* __restrict__ gz_part, int wg_rows, int g32,
+                                                                 const HyperItem* __restrict__ items) {
+  if (items) {
+    const HyperItem it = items[blockIdx.z];
+    k = it.k; x1 = it.x1; n1 = it.n1; x2 = it.x2; n2 = it.n2; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
+    symmetric = it.symmetric; partials = it.partials; gz_part = it.gz;
+  }
   extern __shared__ double smem[];   // e[m] | omega[m] | reduction scratch [4][max(2+2m, HY_ROWS)]
   const double* th = k.theta;
   const double var = th[0], ls = th[1];
@@ -571,13 +583,14 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
 template <int MPAD, bool SM, int KT = -1>
 static void launch_hyper_t(gp_handle h, dim3 grid, size_t sh, DevKern k, const double* x1, int n1, const double* x2,
                            int n2, const double* G, int64_t ldg, const double* alpha, const double* gm, int symmetric,
-                           const double* f1, const double* f2, double* partials, double* gz, int wg_rows, int g32) {
+                           const double* f1, const double* f2, double* partials, double* gz, int wg_rows, int g32,
+                           const HyperItem* items = nullptr) {
   if (gz)
     hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, true, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2,
-                       n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows, g32);
+                       n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows, g32, items);
   else
     hipLaunchKernelGGL((hyper_contract_kernel<MPAD, SM, false, KT>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1,
-                       x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows, g32);
+                       x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz, wg_rows, g32, items);
 }
 
 gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
@@ -593,10 +606,10 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     const size_t sh = (2 * (size_t)k.m + 4 * (size_t)redw) * sizeof(double);
     if (gz_partials)
       hipLaunchKernelGGL((hyper_m12sm_kernel<true>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                         alpha, gm, symmetric, partials, gz_partials, wg_rows, g32);
+                         alpha, gm, symmetric, partials, gz_partials, wg_rows, g32, (const HyperItem*)nullptr);
     else
       hipLaunchKernelGGL((hyper_m12sm_kernel<false>), grid, dim3(HY_THREADS), sh, h->stream, k, x1, n1, x2, n2, G, ldg,
-                         alpha, gm, symmetric, partials, gz_partials, wg_rows, g32);
+                         alpha, gm, symmetric, partials, gz_partials, wg_rows, g32, (const HyperItem*)nullptr);
     GP_HIP_CHECK(h, hipGetLastError());
     if (nparts) *nparts = grid.x * grid.y;
     return GP_OK;
@@ -708,13 +721,6 @@ gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, in
 
 // One launch for all latent GPs: block (s, item) adds the Kuf-side and the Kuu-side partial sums (and the Kdiag term)
 // of entry s of that GP's theta gradient; the remaining blocks do the same for its inducing-input gradient.
-struct HyperFinishItem {
-  DevKern k;
-  const double* p_uf; const double* p_uu; const double* gv_sum;
-  double* g_theta; const double* gz_uf; const double* gz_uu; double* g_z;
-  int np_uf, np_uu, cb_uf, cb_uu, n1, pad;
-};
-
 size_t hyper_finish_item_bytes() { return sizeof(HyperFinishItem); }
 
 __global__ void __launch_bounds__(256) hyper_finish_items_kernel(const HyperFinishItem* __restrict__ items) {
@@ -754,6 +760,65 @@ __global__ void __launch_bounds__(256) hyper_finish_items_kernel(const HyperFini
       it.g_z[i] += a;
     }
   }
+}
+
+gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items, int count, int maxblocks) {
+  if (count <= 0) return GP_OK;
+  hipLaunchKernelGGL(hyper_finish_items_kernel, dim3(maxblocks, (unsigned)count), dim3(256), 0, h->stream, d_items);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
+// Many contractions of one kernel family (same type and partial count, same n1 x n2) in one launch: the generic
+// (vector-pipe) kernels with an item array.  *nparts = partial records each item leaves.
+gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
+                                      int with_gz, int* nparts) {
+  if (count <= 0) return GP_OK;
+  GpTimerScope ts(h, GP_TIMER_HYPER);
+  const int wg_rows = hy_rows_for(n1, n2);
+  dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + wg_rows - 1) / wg_rows, count);
+  const int ns = 2 + 2 * m;
+  const int redw = ns > HY_ROWS ? ns : HY_ROWS;
+  DevKern k0{type, m, nullptr};
+  if (gp_kern_is_broadcast(type)) {
+    const size_t sh = (2 * (size_t)m + 4 * (size_t)redw) * sizeof(double);
+    if (with_gz)
+      hipLaunchKernelGGL((hyper_m12sm_kernel<true>), grid, dim3(HY_THREADS), sh, h->stream, k0, (const double*)nullptr, 0,
+                         (const double*)nullptr, 0, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
+                         (const double*)nullptr, 0, (double*)nullptr, (double*)nullptr, wg_rows, 0, d_items);
+    else
+      hipLaunchKernelGGL((hyper_m12sm_kernel<false>), grid, dim3(HY_THREADS), sh, h->stream, k0, (const double*)nullptr, 0,
+                         (const double*)nullptr, 0, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
+                         (const double*)nullptr, 0, (double*)nullptr, (double*)nullptr, wg_rows, 0, d_items);
+  } else {
+    const bool sm = gp_kern_is_mercer(type);
+    const int mp = sm ? sm_mpad(m) : 0;
+    const size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
+    double* gzflag = with_gz ? (double*)(uintptr_t)8 : nullptr;     // only its null-ness selects the kernel variant
+#define HYI_ARGS grid, sh, k0, (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)nullptr, (int64_t)0, \
+                 (const double*)nullptr, (const double*)nullptr, 0, (const double*)nullptr, (const double*)nullptr,      \
+                 (double*)nullptr, gzflag, wg_rows, 0, d_items
+    if (!sm) switch (type) {
+      case GP_KERN_MATERN12: launch_hyper_t<1, false, GP_KERN_MATERN12>(h, HYI_ARGS); break;
+      case GP_KERN_MATERN32: launch_hyper_t<1, false, GP_KERN_MATERN32>(h, HYI_ARGS); break;
+      case GP_KERN_MATERN52: launch_hyper_t<1, false, GP_KERN_MATERN52>(h, HYI_ARGS); break;
+      default: launch_hyper_t<1, false, GP_KERN_RBF>(h, HYI_ARGS); break;
+    }
+    else switch (mp) {
+      case 4: launch_hyper_t<4, true>(h, HYI_ARGS); break;
+      case 8: launch_hyper_t<8, true>(h, HYI_ARGS); break;
+      case 12: launch_hyper_t<12, true>(h, HYI_ARGS); break;
+      case 16: launch_hyper_t<16, true>(h, HYI_ARGS); break;
+      case 20: launch_hyper_t<20, true>(h, HYI_ARGS); break;
+      case 24: launch_hyper_t<24, true>(h, HYI_ARGS); break;
+      case 28: launch_hyper_t<28, true>(h, HYI_ARGS); break;
+      default: launch_hyper_t<32, true>(h, HYI_ARGS); break;
+    }
+#undef HYI_ARGS
+  }
+  GP_HIP_CHECK(h, hipGetLastError());
+  if (nparts) *nparts = grid.x * grid.y;
+  return GP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -51,14 +51,21 @@ __device__ __forceinline__ void pivot_sqrt_recip(double x, double& s, double& ri
 
 // Factor the 32 x 32 diagonal block at (k0, k0) entirely in the registers of ONE wavefront (lane i holds row i;
 // pivots / columns are broadcast with v_readlane), write L_kk to global and its inverse to Dinv (LDS).
-__device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t ld, int M, int k0, int lane,
+// PT: the matrix pointer type.  Generic `double*` for the LDS-resident form (chol_inverse_lds_kernel hands LDS
+// addresses); address-space-1 for matrices in device memory — a pointer fetched from a device array is generic to the
+// compiler and its accesses become FLAT, which count on lgkmcnt too: every LDS wait of the factorisation then also waits
+// for the matrix loads / stores in flight.
+typedef double __attribute__((address_space(1))) * ch_gptr;
+typedef const double __attribute__((address_space(1))) * ch_gcptr;
+template <typename PT>
+__device__ __forceinline__ void chol_diag_block(PT A, int64_t ld, int M, int k0, int lane,
                                                 double (*Dinv)[CH_NB + 1], int* __restrict__ status, int b, int pbase) {
   const int nb = min(CH_NB, M - k0);
   double row[CH_NB];
   double rinv[CH_NB];   // 1 / L_jj, wave-uniform (lives in SGPRs)
   const int i = lane & 31;
   // unconditional loads from clamped (always valid) addresses, then select: no divergent branches
-  const double* arow = A + (int64_t)(k0 + min(i, nb - 1)) * ld + k0;
+  const auto arow = A + (int64_t)(k0 + min(i, nb - 1)) * ld + k0;
 #pragma unroll
   for (int c = 0; c < CH_NB; c++) {
     const double v = arow[min(c, nb - 1)];
@@ -116,7 +123,8 @@ __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int64_t 
 }
 
 // Cholesky of one matrix by one workgroup (body shared by chol_kernel and chol_inverse_kernel)
-__device__ __forceinline__ void chol_body(double* __restrict__ A, const int M, const int64_t ld, int* __restrict__ status,
+template <typename PT>
+__device__ __forceinline__ void chol_body(PT A, const int M, const int64_t ld, int* __restrict__ status,
                                           const int b, const int panel_rows_cap, const int pivot_base) {
   extern __shared__ __attribute__((aligned(16))) double chol_smem[];
   // [ D: 2 x 32 x 33 (inverse of the current / next diagonal factor) | P: panel X, (M-32) x 33 when it fits ]
@@ -242,12 +250,13 @@ __global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restr
                                                           double* single_mat, int single_M, int single_ld, int panel_rows_cap,
                                                           int pivot_base) {
   const int b = blockIdx.x;
-  chol_body(mats ? mats[b] : single_mat, mats ? Ms[b] : single_M, mats ? (int64_t)lds_[b] : (int64_t)single_ld, status, b,
+  chol_body((ch_gptr)(mats ? mats[b] : single_mat), mats ? Ms[b] : single_M, mats ? (int64_t)lds_[b] : (int64_t)single_ld, status, b,
             panel_rows_cap, pivot_base);
 }
 
 // W = L^-1 (lower) of one matrix by one workgroup (body shared by tri_inverse_kernel and chol_inverse_kernel).
-__device__ __forceinline__ void tri_inverse_body(const double* L, double* W, const int M, const int64_t ld) {
+template <typename CPT, typename PT>
+__device__ __forceinline__ void tri_inverse_body(CPT L, PT W, const int M, const int64_t ld) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int T = (M + CH_NB - 1) / CH_NB;
 
@@ -265,7 +274,7 @@ __device__ __forceinline__ void tri_inverse_body(const double* L, double* W, con
     const int nb = min(CH_NB, M - d0);
     const int i = lane & 31;
     double lrow[CH_NB];  // lane i: row i of the diagonal block of L (identity-padded)
-    const double* lsrc = L + (int64_t)(d0 + min(i, nb - 1)) * ld + d0;   // clamped: loads are unconditional
+    const auto lsrc = L + (int64_t)(d0 + min(i, nb - 1)) * ld + d0;   // clamped: loads are unconditional
 #pragma unroll
     for (int c = 0; c < CH_NB; c++) {
       const double v = lsrc[min(c, nb - 1)];
@@ -365,7 +374,7 @@ __global__ void __launch_bounds__(CH_THREADS) tri_inverse_kernel(const double* c
                                                                  const int* __restrict__ lds_, const double* single_L,
                                                                  double* single_W, int single_M, int single_ld) {
   const int b = blockIdx.x;
-  tri_inverse_body(Ls ? Ls[b] : single_L, Ws ? Ws[b] : single_W, Ls ? Ms[b] : single_M,
+  tri_inverse_body((ch_gcptr)(Ls ? Ls[b] : single_L), (ch_gptr)(Ws ? Ws[b] : single_W), Ls ? Ms[b] : single_M,
                    Ls ? (int64_t)lds_[b] : (int64_t)single_ld);
 }
 
@@ -383,10 +392,10 @@ __global__ void __launch_bounds__(CH_THREADS) chol_inverse_kernel(double* const*
   double* W = mats ? Ws[b] : single_W;
   const int M = mats ? Ms[b] : single_M;
   const int64_t ld = mats ? (int64_t)lds_[b] : (int64_t)single_ld;
-  chol_body(A, M, ld, status, b, panel_rows_cap, 0);
+  chol_body((ch_gptr)A, M, ld, status, b, panel_rows_cap, 0);
   __threadfence();
   __syncthreads();
-  tri_inverse_body(A, W, M, ld);
+  tri_inverse_body((ch_gcptr)A, (ch_gptr)W, M, ld);
 }
 
 // Matrices of at most 64 rows (the window-sized SGPR problems, small inducing sets): the whole factor + inverse runs on
@@ -418,7 +427,7 @@ __global__ void __launch_bounds__(CH_THREADS) chol_inverse_lds_kernel(double* co
   chol_body(Al, M, CHS_LD, status, b, CHS_M - CH_NB, 0);
   __threadfence_block();
   __syncthreads();
-  tri_inverse_body(Al, Wl, M, CHS_LD);
+  tri_inverse_body((const double*)Al, Wl, M, CHS_LD);
   __threadfence_block();
   __syncthreads();
   for (int idx = threadIdx.x; idx < M * M; idx += CH_THREADS) {

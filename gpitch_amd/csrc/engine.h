@@ -35,6 +35,22 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
 gp_status launch_hyper_finish(gp_handle h, DevKern k, const double* partials, int nparts, const double* gv_sum,
                               double* g_theta, const double* gz_partials, int ncolblocks, int n1, double* g_z);
 int hyper_num_sums(int m);
+// item forms (one launch for many contractions / finishes: the window-batched SGPR plan)
+struct HyperItem {
+  DevKern k;
+  const double* x1; const double* x2; const double* G; const double* alpha; const double* gm;
+  const double* f1; const double* f2; double* partials; double* gz;
+  int64_t ldg; int n1, n2, symmetric, pad;
+};
+struct HyperFinishItem {
+  DevKern k;
+  const double* p_uf; const double* p_uu; const double* gv_sum;
+  double* g_theta; const double* gz_uf; const double* gz_uu; double* g_z;
+  int np_uf, np_uu, cb_uf, cb_uu, n1, pad;
+};
+gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
+                                      int with_gz, int* nparts);
+gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items, int count, int maxblocks);
 size_t hyper_finish_item_bytes();
 // partial records the Kuf-side contraction of an M x N strip may write (the largest over its kernel variants)
 size_t hyper_kuf_records(int N, int M);

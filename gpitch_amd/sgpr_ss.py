@@ -251,9 +251,10 @@ class SGPRSS(Parameterized):
         sig = 1. / (1. + np.exp(-x))
         y = np.where(kind == 1, np.logaddexp(0., x) + lo, np.where(kind == 2, lo + span * sig, x))
         dy = np.where(kind == 1, sig, np.where(kind == 2, span * sig * (1. - sig), 1.))
-        for j, tr in st["other"].items():
-            y[j] = tr.forward(np.array([x[j]]))[0]
-            dy[j] = tr.dforward(np.array([x[j]]))[0]
+        for j, tr in st["other"].items():       # (x may be one free vector or a (windows, n) stack of them)
+            col = np.atleast_1d(x[..., j])
+            y[..., j] = np.array([tr.forward(np.array([v]))[0] for v in col]).reshape(np.shape(x[..., j]))
+            dy[..., j] = np.array([tr.dforward(np.array([v]))[0] for v in col]).reshape(np.shape(x[..., j]))
         return y, dy
 
     def _objective(self, x_free):

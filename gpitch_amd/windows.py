@@ -92,3 +92,159 @@ def fit_windows(make_model, windows, maxiter=10, num_streams=4, reset=default_re
     if errors:
         raise errors[0]
     return results
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# device-batched form: W windows per launch sequence (include/gpitch_abi.h gp_sgprb_*), scipy's L-BFGS-B per window
+# driven in reverse communication (lbfgsb_batch.py)
+class SgprWindowBatch(object):
+    """Device side of a batch of W SGPRSS windows that share N, M and the kernel structure of `template` (an SGPRSS):
+    bound and gradient of all of them from one launch sequence."""
+
+    def __init__(self, template, num_windows, N, M, handle=None):
+        import ctypes as C
+        from . import _lib
+        self.h = h = handle or template._handle or _lib.default_handle()
+        kl = template.kern.kern_list
+        P = len(kl)
+        i32 = C.c_int32 * P
+        self._keep = (i32(*[k.type_code for k in kl]), i32(*[int(k.num_partials) for k in kl]))
+        cfg = _lib.SgprConfig(P, int(N), int(M), self._keep[0], self._keep[1], 1e-6, int(bool(template.reg)))
+        plan = C.c_void_p()
+        h.check(h.lib.gp_sgprb_create(h.h, C.byref(cfg), int(num_windows), C.byref(plan)))
+        self.plan = plan
+        self.W, self.N, self.M = int(num_windows), int(N), int(M)
+        self.nparams = int(h.lib.gp_sgprb_num_params(plan))
+        self._ws = h.workspace(h.lib.gp_sgprb_workspace_bytes(plan))
+        h.check(h.lib.gp_sgprb_set_workspace(plan, self._ws.data_ptr(), self._ws.numel()))
+        t = h.torch
+        self.X, self.Y, self.Z = h.zeros(self.W, self.N), h.zeros(self.W, self.N), h.zeros(self.W, self.M)
+        self.params, self.grad, self.bound = h.zeros(self.W, self.nparams), h.zeros(self.W, self.nparams), h.zeros(self.W)
+        # pinned staging: parameter upload / result download without a pageable-memory synchronisation each round
+        self._p_host = t.zeros(self.W, self.nparams, dtype=t.float64).pin_memory()
+        self._g_host = t.zeros(self.W, self.nparams, dtype=t.float64).pin_memory()
+        self._b_host = t.zeros(self.W, dtype=t.float64).pin_memory()
+
+    def load(self, xs, ys, zs):
+        """put `len(xs)` windows into the first slots (the others keep whatever they held: still valid problems)"""
+        t = self.h.torch
+        n = len(xs)
+        self.X[:n].copy_(t.as_tensor(np.stack([np.asarray(x, dtype=np.float64).reshape(-1) for x in xs])))
+        self.Y[:n].copy_(t.as_tensor(np.stack([np.asarray(y, dtype=np.float64).reshape(-1) for y in ys])))
+        self.Z[:n].copy_(t.as_tensor(np.stack([np.asarray(z, dtype=np.float64).reshape(-1) for z in zs])))
+        self.count = n
+
+    def evaluate(self, params_host, with_grad=True):
+        """params_host: (count, nparams) constrained parameter vectors -> (bound (count,), grad (count, nparams))"""
+        h = self.h
+        n = self.count
+        self._p_host[:n].copy_(h.torch.as_tensor(params_host))
+        self.params[:n].copy_(self._p_host[:n], non_blocking=True)
+        h.check(h.lib.gp_sgprb_bound_grad(self.plan, self.params.data_ptr(), self.X.data_ptr(), self.Y.data_ptr(),
+                                          self.Z.data_ptr(), n, self.bound.data_ptr(),
+                                          self.grad.data_ptr() if with_grad else None))
+        self._b_host[:n].copy_(self.bound[:n], non_blocking=True)
+        if with_grad:
+            self._g_host[:n].copy_(self.grad[:n], non_blocking=True)
+        h.torch.cuda.current_stream(h.device).synchronize()
+        h.check(h.lib.gp_sync(h.h))
+        return self._b_host[:n].numpy().copy(), (self._g_host[:n].numpy().copy() if with_grad else None)
+
+    def close(self):
+        if self.plan is not None:
+            self.h.sync()
+            self.h.lib.gp_sgprb_destroy(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default_reset, handle=None, rank=0,
+                        world_size=1, params0=None):
+    """fit_windows with the device work batched: `batch` windows go through every bound + gradient evaluation together
+    (one launch sequence, gp_sgprb_bound_grad), each window driven by its own instance of scipy's L-BFGS-B routine
+    (lbfgsb_batch.LbfgsbRC: the iterates of `model.optimize(maxiter=maxiter)` exactly, given the same f and g).
+
+    Every window starts from the parameter values of make_model(handle) after `reset(model, x, y, z)` (unit noise and
+    kernel variances by default, transcription.py:253-263) — i.e. carry_kernel_state=False of fit_windows — or from
+    params0[i] (constrained vector [noise | theta_0 | ...]) when given.  All windows must share N and M.
+    Returns a list over windows of dicts: bound, nfev, nit, variances, noise, params."""
+    from . import _lib, lbfgsb_batch
+    from .dist import window_assignment
+    from .sgpr_ss import SGPRSS
+    if not lbfgsb_batch.available():
+        raise RuntimeError("fit_windows_batched needs scipy >= 1.15 (its reverse-communication L-BFGS-B routine); "
+                           "use fit_windows")
+    mine = window_assignment(len(windows), world_size, rank)
+    results = [None] * len(windows)
+    if not mine:
+        return results
+    if handle is None:
+        # a stream of its own: the launch sequence of an evaluation is recorded into a hipGraph and replayed, which the
+        # legacy null stream cannot do
+        import torch
+        dev0 = _lib.default_handle().device
+        s = torch.cuda.Stream(device=dev0)
+        with torch.cuda.stream(s):
+            hs = _lib.Handle(dev0.index, stream=s)
+            try:
+                return fit_windows_batched(make_model, windows, maxiter=maxiter, batch=batch, reset=reset, handle=hs,
+                                           rank=rank, world_size=world_size, params0=params0)
+            finally:
+                s.synchronize()
+                hs.close()
+    h = handle
+    model = make_model(h)
+    x0w, y0w, z0w = windows[mine[0]][:3]
+    reset(model, x0w, y0w, z0w)
+    st = model._objective_setup()
+    ps, free_idx = st["ps"], st["free_idx"]
+    vals0 = st["vals0"]
+    N, M = int(np.asarray(x0w).size), int(np.asarray(z0w).size)
+    for i in mine:
+        if np.asarray(windows[i][0]).size != N or np.asarray(windows[i][2]).size != M:
+            raise ValueError("fit_windows_batched: all windows must have the same number of frames and inducing points")
+    B = max(1, min(int(batch), len(mine)))
+    dev = SgprWindowBatch(model, B, N, M, handle=h)
+    back = np.array([ps[i].transform.backward(np.atleast_1d(vals0[i]))[0] for i in free_idx])
+    var_idx = [int(o) for o in np.cumsum([1] + [2 + 2 * int(k.num_partials) for k in model.kern.kern_list])[:-1]]
+    for b0 in range(0, len(mine), B):
+        ids = mine[b0:b0 + B]
+        n = len(ids)
+        dev.load([windows[i][0] for i in ids], [windows[i][1] for i in ids], [windows[i][2] for i in ids])
+        base = np.tile(vals0, (n, 1))
+        if params0 is not None:
+            base = np.stack([np.asarray(params0[i], dtype=np.float64) for i in ids])
+            x0s = [np.array([ps[j].transform.backward(np.atleast_1d(base[r, j]))[0] for j in free_idx]) for r in range(n)]
+        else:
+            x0s = [back.copy() for _ in range(n)]
+        runs = [lbfgsb_batch.LbfgsbRC(x0, maxiter=maxiter) for x0 in x0s]
+        Xf = np.stack(x0s)
+        active = list(range(n))
+        last_bound = np.zeros(n)
+        while active:
+            y, dy = SGPRSS._free_to_params(st, Xf)
+            pv = base.copy()
+            pv[:, free_idx] = y
+            bound, grad = dev.evaluate(pv)
+            nxt = []
+            for r in active:
+                g = -(grad[r, free_idx] * dy[r])
+                runs[r].give(-bound[r], g)
+                if runs[r].step():
+                    Xf[r] = runs[r].x
+                    nxt.append(r)
+            active = nxt
+        yfin, _ = SGPRSS._free_to_params(st, np.stack([r.x for r in runs]))
+        pfin = base.copy()
+        pfin[:, free_idx] = yfin
+        for r, i in enumerate(ids):
+            results[i] = {"bound": -runs[r].fun, "nfev": runs[r].nfev, "nit": runs[r].nit,
+                          "variances": pfin[r, var_idx].copy(), "noise": float(pfin[r, 0]), "params": pfin[r].copy()}
+    dev.close()
+    model._destroy()
+    return results

@@ -73,6 +73,7 @@ typedef struct {
 typedef struct gp_handle_s* gp_handle;
 typedef struct gp_pdgp_plan_s* gp_pdgp_plan;
 typedef struct gp_sgpr_plan_s* gp_sgpr_plan;
+typedef struct gp_sgprb_plan_s* gp_sgprb_plan;
 
 /* ---- runtime -------------------------------------------------------------------------------- */
 /* replaces gpitch.init_settings / the global TF session (gpitch/methods.py:155-180).
@@ -318,6 +319,26 @@ size_t gp_sgpr_predict_source_workspace_bytes(int32_t N, int32_t n);
 gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const double* X, const double* Y,
                                  int32_t N, const double* Xnew, int32_t n, double* mean, double* var,
                                  void* workspace, size_t workspace_bytes);
+
+/* ---- many independent SGPRSS windows per launch sequence -------------------------------------------------------
+ * replaces the window loop of AMT.optimize / SoSp.optimize (gpitch/transcription.py:265-288, gpitch/separation.py:279-313):
+ * for each window, reset_model then model.optimize(maxiter) = a dozen-odd evaluations of SGPRSS.build_likelihood
+ * (sgpr_ss.py:29-71) and its gradient.  Windows are independent; this plan evaluates W of them with one sequence of
+ * launches (every kernel runs over a window index), so that N = 2001-frame windows fill the device.
+ * All windows share max_N (= N), M and the kernel structure of `cfg`; contiguous layouts:
+ *   params [W][gp_sgprb_num_params], X [W][N], Y [W][N], Z [W][M], bound_dev [W], grad [W][num_params] (may be NULL).
+ * `count` <= W windows (the first `count` slots) are evaluated.  Asynchronous on the handle's stream; from the second
+ * call with the same buffers the sequence is replayed from a hipGraph.  M <= 256. */
+gp_status gp_sgprb_create(gp_handle h, const gp_sgpr_config* cfg, int32_t num_windows, gp_sgprb_plan* out);
+gp_status gp_sgprb_destroy(gp_sgprb_plan p);
+int64_t gp_sgprb_num_params(gp_sgprb_plan p);
+int32_t gp_sgprb_num_windows(gp_sgprb_plan p);
+size_t gp_sgprb_workspace_bytes(gp_sgprb_plan p);
+gp_status gp_sgprb_set_workspace(gp_sgprb_plan p, void* workspace, size_t bytes);
+gp_status gp_sgprb_bound_grad(gp_sgprb_plan p, const double* params, const double* X, const double* Y, const double* Z,
+                              int32_t count, double* bound_dev, double* grad);
+gp_status gp_sgprb_set_graphs(gp_sgprb_plan p, int32_t enable);
+gp_status gp_sgprb_eval_counts(gp_sgprb_plan p, int64_t* eager, int64_t* captured, int64_t* replayed);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * HIP-event timing of the dominant kernels on the handle's own stream.  Returns the accumulated time of

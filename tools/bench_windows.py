@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--maxiter", type=int, default=10)
     ap.add_argument("--streams", type=int, nargs="+", default=[1, 2, 4, 8])
+    ap.add_argument("--batches", type=int, nargs="+", default=[32, 64, 128, 256], help="windows per batched evaluation")
+    ap.add_argument("--nwin-batched", type=int, default=512)
+    ap.add_argument("--json", default=None, help="write the measurements here")
     args = ap.parse_args()
     import torch
     from gpitch_amd import _lib
@@ -66,14 +69,32 @@ def main():
         time_eval(hs, "own stream, hipGraph replay")
         hs.close()
 
-    from gpitch_amd.windows import fit_windows
+    out = {"config": {"ws": args.ws, "M": args.M, "kernels": args.P, "partials": args.m, "maxiter": args.maxiter},
+           "streams": {}, "batched": {}}
+    from gpitch_amd.windows import fit_windows, fit_windows_batched
+    # device-batched fits (gp_sgprb_*): W windows per launch sequence, scipy's L-BFGS-B per window in reverse communication
+    wins_b = make_windows(args.nwin_batched, args.ws, args.M, args.P, args.m, seed=1000)
+    data_b = [(w[0], w[1], w[2]) for w in wins_b]
+    for B in args.batches:
+        fit_windows_batched(lambda hh: build_model(wins_b[0][3], hh), data_b[:B], maxiter=2, batch=B)   # warm-up
+        t0 = time.perf_counter()
+        res = fit_windows_batched(lambda hh: build_model(wins_b[0][3], hh), data_b, maxiter=args.maxiter, batch=B)
+        dt = time.perf_counter() - t0
+        nfev = sum(r["nfev"] for r in res)
+        print("batched B=%d: %d windows in %.3f s = %.1f windows/s; nfev total %d (%.1f per window); bound[0]=%.6f"
+              % (B, len(res), dt, len(res) / dt, nfev, nfev / float(len(res)), res[0]["bound"]), flush=True)
+        out["batched"][str(B)] = {"windows": len(res), "seconds": dt, "windows_per_s": len(res) / dt, "nfev": nfev}
     for ns in args.streams:
         t0 = time.perf_counter()
         res = fit_windows(lambda hh: build_model(wins[0][3], hh), [(w[0], w[1], w[2]) for w in wins],
                           maxiter=args.maxiter, num_streams=ns)
         dt = time.perf_counter() - t0
         print("streams=%d: %d windows in %.3f s = %.1f windows/s; nfev total %d; bound[0]=%.6f"
-              % (ns, args.nwin, dt, args.nwin / dt, sum(r["nfev"] for r in res), res[0]["bound"]))
+              % (ns, args.nwin, dt, args.nwin / dt, sum(r["nfev"] for r in res), res[0]["bound"]), flush=True)
+        out["streams"][str(ns)] = {"windows": args.nwin, "seconds": dt, "windows_per_s": args.nwin / dt}
+    if args.json:
+        import json
+        json.dump(out, open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
