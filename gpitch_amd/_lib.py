@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpitch_hip.so")
+# GPITCH_AMD_LIB: another build of the same library (same-box A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("GPITCH_AMD_LIB") or os.path.join(_HERE, "libgpitch_hip.so")
 
 GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_HIP, GP_ERR_NO_DEVICE, GP_ERR_WORKSPACE, GP_ERR_UNSUPPORTED = range(7)
 

@@ -68,6 +68,41 @@ gp_status gp_aux_join(gp_handle h) {
   return GP_OK;
 }
 
+bool gp_side_begin(gp_handle h) {
+  if (h->side_active || h->side_pending) return false;
+  if (!h->side_stream) {
+    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) { h->side_stream = nullptr; return false; }
+    if (hipEventCreateWithFlags(&h->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_side_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr;
+      return false;
+    }
+  }
+  if (hipEventRecord(h->ev_side_fork, h->stream) != hipSuccess) return false;
+  if (hipStreamWaitEvent(h->side_stream, h->ev_side_fork, 0) != hipSuccess) return false;
+  h->side_saved = h->stream;
+  h->stream = h->side_stream;
+  h->side_active = true;
+  return true;
+}
+
+gp_status gp_side_end(gp_handle h) {
+  if (!h->side_active) return GP_OK;
+  hipError_t e = hipEventRecord(h->ev_side_join, h->side_stream);
+  h->stream = h->side_saved;
+  h->side_active = false;
+  h->side_pending = true;
+  if (e != hipSuccess) return gp_fail(h, GP_ERR_HIP, "hipEventRecord on the side stream failed");
+  return GP_OK;
+}
+
+gp_status gp_side_join(gp_handle h) {
+  if (!h->side_pending) return GP_OK;
+  h->side_pending = false;
+  GP_HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_side_join, 0));
+  return GP_OK;
+}
+
 static gp_status drain_timers(gp_handle h) {
   for (auto& r : h->pending) {
     GP_HIP_CHECK(h, hipEventSynchronize(r.e1));
@@ -115,6 +150,7 @@ gp_status gp_destroy(gp_handle h) {
   for (auto& r : h->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
   if (h->ev_era) (void)hipEventDestroy(h->ev_era);
   if (h->ev_kuu) (void)hipEventDestroy(h->ev_kuu);
@@ -131,6 +167,7 @@ gp_status gp_sync(gp_handle h) {
   // the helper stream is normally joined into the handle's stream before an entry point returns; the one exception is
   // work prefetched for a backward pass that was never asked for (gp_pdgp_elbo_begin without _end)
   if (h->aux_stream) GP_HIP_CHECK(h, hipStreamSynchronize(h->aux_stream));
+  if (h->side_stream) GP_HIP_CHECK(h, hipStreamSynchronize(h->side_stream));
   GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
   return GP_OK;
 }

@@ -14,6 +14,7 @@
 // analytic kernel derivatives, evaluated on the fly.
 #include "pdgp_plan.h"
 #include <string.h>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // small batched vector / matrix kernels (problem fields reused; see each kernel)
@@ -136,6 +137,11 @@ gp_status launch_matvec_batched(gp_handle h, const GemmProblem* d, int batch, in
 __device__ __forceinline__ double hy_ld(const double* __restrict__ p, int64_t idx, int g32) {
   return g32 ? (double)reinterpret_cast<const float*>(p)[idx] : p[idx];
 }
+typedef const double __attribute__((address_space(1))) * hy_gcptr;
+typedef const float __attribute__((address_space(1))) * hy_gcfptr;
+__device__ __forceinline__ double hy_ldg(hy_gcptr p, int64_t idx, int g32) {
+  return g32 ? (double)((hy_gcfptr)p)[idx] : p[idx];
+}
 
 int hyper_num_sums(int m) { return 2 + 2 * m; }
 // rows of x1 per workgroup: HY_ROWS for the strips; small contractions (window-sized problems, the Kuu side) get
@@ -170,8 +176,9 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
                                                                     const HyperItem* __restrict__ items) {
   if (items) {     // one launch for many contractions (window-batched SGPR plans): blockIdx.z = item
     const HyperItem it = items[blockIdx.z];
-    k = it.k; x1 = it.x1; n1 = it.n1; x2 = it.x2; n2 = it.n2; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
-    symmetric = it.symmetric; f1 = it.f1; f2 = it.f2; partials = it.partials; gz_part = it.gz;
+    k = it.k; x1 = it.x1; n1 = it.n1; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
+    if (it.x2) { x2 = it.x2; n2 = it.n2; }      // null: the launch's shared x2 / n2 (the frames of the batch)
+    symmetric = it.symmetric; f1 = it.f1; f2 = it.f2; partials = it.partials; gz_part = it.gz; g32 = it.g32;
   }
   extern __shared__ double smem[];  // [HY_ROWS][2*MPAD] row features | omega[MPAD] | reduction scratch
   const double* th = k.theta;
@@ -333,7 +340,18 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
                                                             const double* __restrict__ Kuf, int64_t ldk,
                                                             const double* __restrict__ f1,
                                                             const double* __restrict__ f2,
-                                                            double* __restrict__ partials, int g32) {
+                                                            double* __restrict__ partials, int g32,
+                                                            const HyperItem* __restrict__ items) {
+  if (items) {     // one launch for a whole kernel family: blockIdx.y = item (latent GP)
+    const HyperItem it = items[blockIdx.y];
+    k = it.k; x1 = it.x1; n1 = it.n1; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
+    if (it.x2) { x2 = it.x2; n2 = it.n2; }
+    Kuf = it.kvals; ldk = it.ldk; f1 = it.f1; f2 = it.f2; partials = it.partials; g32 = it.g32;
+  }
+  // address-space-1 views: pointers that came out of an item struct are generic, and FLAT loads would tie every LDS wait
+  // of the row loop to the operand prefetch in flight (the batched launch ran 30 % slower than twelve single ones)
+  const hy_gcptr gG = (hy_gcptr)G, gK = (hy_gcptr)Kuf, gx1 = (hy_gcptr)x1, gx2 = (hy_gcptr)x2, galpha = (hy_gcptr)alpha,
+                 ggm = (hy_gcptr)gm, gf1 = (hy_gcptr)f1, gf2 = (hy_gcptr)f2;
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int NF = 2 * MPAD;                 // features per row: cos block, then sin block
   constexpr int NT = (NF + 15) / 16;           // 16-row MFMA tiles of the feature dimension
@@ -343,7 +361,7 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
   __shared__ double etab[GP_EXP_TAB];
   __shared__ double red[4][2 + 2 * 32];
   gp_exp_tab_init(etab);
-  const double* th = k.theta;
+  const hy_gcptr th = (hy_gcptr)k.theta;
   const double var = th[0], ls = th[1];
   const int m = k.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -351,9 +369,9 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
   const int j = (blockIdx.x * 4 + wave) * 16 + lc;       // this lane's column
   const bool live = (j < n2);
   const int jc = live ? j : n2 - 1;
-  const double xb = x2[jc];
+  const double xb = gx2[jc];
   const double bsc = xb / ls, bb = __dmul_rn(bsc, bsc);
-  const double gmj = live ? gm[jc] : 0.0;
+  const double gmj = live ? ggm[jc] : 0.0;
   const double inv_ls = 1.0 / ls;
   const bool m12 = (k.type == GP_KERN_MERCER_MATERN12SM);
   d4 accE[NT], accD[NT];
@@ -370,8 +388,8 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
     for (int ks = 0; ks < KS; ks++) {
       const int i = r0 + ks * 4 + kq;
       const bool on = live && (i < n1);
-      g[ks] = on ? hy_ld(G, (int64_t)i * ldg + j, g32) : 0.0;
-      kk[ks] = on ? hy_ld(Kuf, (int64_t)i * ldk + j, g32) : 0.0;
+      g[ks] = on ? hy_ldg(gG, (int64_t)i * ldg + j, g32) : 0.0;
+      kk[ks] = on ? hy_ldg(gK, (int64_t)i * ldk + j, g32) : 0.0;
     }
   };
   fetch(0, gw, kvv);
@@ -379,12 +397,12 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
     __syncthreads();     // the previous chunk's fragments have been read
     for (int t = tid; t < HYM_ROWS * NT * 16; t += 256) {
       const int ii = t / (NT * 16), f = t % (NT * 16);
-      zf[ii * FS + f] = (r0 + ii < n1 && f < NF) ? f1[(size_t)f * n1 + r0 + ii] : 0.0;
+      zf[ii * FS + f] = (r0 + ii < n1 && f < NF) ? gf1[(size_t)f * n1 + r0 + ii] : 0.0;
     }
     if (tid < HYM_ROWS) {
       const bool ok = (r0 + tid < n1);
-      const double xv = ok ? x1[r0 + tid] : 0.0;
-      rowx[tid] = xv; rowa[tid] = xv / ls; rowal[tid] = ok ? alpha[r0 + tid] : 0.0;
+      const double xv = ok ? gx1[r0 + tid] : 0.0;
+      rowx[tid] = xv; rowa[tid] = xv / ls; rowal[tid] = ok ? galpha[r0 + tid] : 0.0;
     }
     fetch(r0 + HYM_ROWS, gw_n, kv_n);      // next chunk (all-false predicates past the last row)
     __syncthreads();
@@ -438,8 +456,8 @@ __global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const dou
       double se = 0.0, sd = 0.0;
       if (f < NF && live) {
         const int fp = (f < MPAD) ? f + MPAD : f - MPAD;
-        se = f2[(size_t)f * n2 + jc] * accE[t][r];
-        sd = f2[(size_t)fp * n2 + jc] * accD[t][r];
+        se = gf2[(size_t)f * n2 + jc] * accE[t][r];
+        sd = gf2[(size_t)fp * n2 + jc] * accD[t][r];
       }
       // reduce over the 16 columns of this lane group (lanes sharing kq)
 #pragma unroll
@@ -476,8 +494,9 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_m12sm_kernel(DevKern k, cons
                                                                  const HyperItem* __restrict__ items) {
   if (items) {
     const HyperItem it = items[blockIdx.z];
-    k = it.k; x1 = it.x1; n1 = it.n1; x2 = it.x2; n2 = it.n2; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
-    symmetric = it.symmetric; partials = it.partials; gz_part = it.gz;
+    k = it.k; x1 = it.x1; n1 = it.n1; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
+    if (it.x2) { x2 = it.x2; n2 = it.n2; }
+    symmetric = it.symmetric; partials = it.partials; gz_part = it.gz; g32 = it.g32;
   }
   extern __shared__ double smem[];   // e[m] | omega[m] | reduction scratch [4][max(2+2m, HY_ROWS)]
   const double* th = k.theta;
@@ -626,7 +645,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     // Kuf side with the covariance strip still in memory: the matrix-core form (hyper_sm_mfma_kernel)
     dim3 gridm((n2 + 63) / 64);
 #define HY_MFMA(MP) hipLaunchKernelGGL((hyper_sm_mfma_kernel<MP>), gridm, dim3(256), 0, h->stream, k, x1, n1, x2, n2, G, ldg, \
-                                     alpha, gm, kvals, ldk, f1, f2, partials, g32)
+                                     alpha, gm, kvals, ldk, f1, f2, partials, g32, (const HyperItem*)nullptr)
     switch (mp) {
       case 4: HY_MFMA(4); break;
       case 8: HY_MFMA(8); break;
@@ -772,9 +791,31 @@ gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items,
 // Many contractions of one kernel family (same type and partial count, same n1 x n2) in one launch: the generic
 // (vector-pipe) kernels with an item array.  *nparts = partial records each item leaves.
 gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
-                                      int with_gz, int* nparts) {
+                                      int with_gz, int* nparts, int use_mfma, const double* x2_shared) {
   if (count <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_HYPER);
+  if (use_mfma && gp_kern_is_mercer(type) && !with_gz) {
+    dim3 gridm((n2 + 63) / 64, count);
+    DevKern k0{type, m, nullptr};
+#define HYI_MFMA(MP) hipLaunchKernelGGL((hyper_sm_mfma_kernel<MP>), gridm, dim3(256), 0, h->stream, k0, (const double*)nullptr, 0, \
+                                      x2_shared, n2, (const double*)nullptr, (int64_t)0, (const double*)nullptr,                  \
+                                      (const double*)nullptr, (const double*)nullptr, (int64_t)0, (const double*)nullptr,         \
+                                      (const double*)nullptr, (double*)nullptr, 0, d_items)
+    switch (sm_mpad(m)) {
+      case 4: HYI_MFMA(4); break;
+      case 8: HYI_MFMA(8); break;
+      case 12: HYI_MFMA(12); break;
+      case 16: HYI_MFMA(16); break;
+      case 20: HYI_MFMA(20); break;
+      case 24: HYI_MFMA(24); break;
+      case 28: HYI_MFMA(28); break;
+      default: HYI_MFMA(32); break;
+    }
+#undef HYI_MFMA
+    GP_HIP_CHECK(h, hipGetLastError());
+    if (nparts) *nparts = gridm.x;
+    return GP_OK;
+  }
   const int wg_rows = hy_rows_for(n1, n2);
   dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + wg_rows - 1) / wg_rows, count);
   const int ns = 2 + 2 * m;
@@ -784,18 +825,18 @@ gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperI
     const size_t sh = (2 * (size_t)m + 4 * (size_t)redw) * sizeof(double);
     if (with_gz)
       hipLaunchKernelGGL((hyper_m12sm_kernel<true>), grid, dim3(HY_THREADS), sh, h->stream, k0, (const double*)nullptr, 0,
-                         (const double*)nullptr, 0, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
+                         x2_shared, n2, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
                          (const double*)nullptr, 0, (double*)nullptr, (double*)nullptr, wg_rows, 0, d_items);
     else
       hipLaunchKernelGGL((hyper_m12sm_kernel<false>), grid, dim3(HY_THREADS), sh, h->stream, k0, (const double*)nullptr, 0,
-                         (const double*)nullptr, 0, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
+                         x2_shared, n2, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
                          (const double*)nullptr, 0, (double*)nullptr, (double*)nullptr, wg_rows, 0, d_items);
   } else {
     const bool sm = gp_kern_is_mercer(type);
     const int mp = sm ? sm_mpad(m) : 0;
     const size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
     double* gzflag = with_gz ? (double*)(uintptr_t)8 : nullptr;     // only its null-ness selects the kernel variant
-#define HYI_ARGS grid, sh, k0, (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)nullptr, (int64_t)0, \
+#define HYI_ARGS grid, sh, k0, (const double*)nullptr, 0, x2_shared, n2, (const double*)nullptr, (int64_t)0, \
                  (const double*)nullptr, (const double*)nullptr, 0, (const double*)nullptr, (const double*)nullptr,      \
                  (double*)nullptr, gzflag, wg_rows, 0, d_items
     if (!sm) switch (type) {
@@ -904,6 +945,45 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     { GemmProblem& r = P(S_T3); r.A = t.W; r.B = b.T2; r.C = b.H; }
     { GemmProblem& r = P(S_S); r.A = b.H; r.B = t.W; r.C = b.E; }
     if (kneed) kslot++;
+  }
+  // Kuf-side contractions, one launch per kernel family (same type and partial count): item array in kgps order inside
+  // each family.  x2 stays null in the items: the frames of the batch come with the launch (their pointer may change
+  // from step to step without a descriptor upload).
+  p->off_hy_items = p->off_fin_items + gp_align_up((size_t)G * hyper_finish_item_bytes(), 256);
+  p->hy_fams.clear();
+  for (size_t s = 0; s < p->kgps.size(); s++) {
+    const int g = p->kgps[s];
+    const PdgpGP& q = p->gps[g];
+    const int key_m = gp_kern_has_partials(q.ktype) ? q.m : 0;
+    int fi = -1;
+    for (size_t f = 0; f < p->hy_fams.size(); f++)
+      if (p->hy_fams[f].type == q.ktype && p->hy_fams[f].m == key_m) fi = (int)f;
+    if (fi < 0) { gp_pdgp_plan_s::HyFamily nf; nf.type = q.ktype; nf.m = key_m; nf.M = q.M; nf.batched = true; p->hy_fams.push_back(nf); fi = (int)p->hy_fams.size() - 1; }
+    gp_pdgp_plan_s::HyFamily& fam = p->hy_fams[fi];
+    fam.gps.push_back(g);
+    if (q.M != fam.M || q.need_z || !q.need_theta) fam.batched = false;   // the per-GP path handles those
+  }
+  {
+    HyperItem* items = (HyperItem*)(p->h_misc.data() + p->off_hy_items);
+    int pos = 0;
+    for (auto& fam : p->hy_fams) {
+      fam.first = pos; fam.count = (int)fam.gps.size();
+      fam.mfma = (gp_kern_is_mercer(fam.type) && fam.batched) ? 1 : 0;
+      for (int g : fam.gps) {
+        const PdgpGP& q = p->gps[g];
+        const CondTask& t = p->cb.tasks[g];
+        const BwdBufs& bb = p->bw[g];
+        HyperItem& it = items[pos++];
+        memset(&it, 0, sizeof(it));
+        it.k = t.kern; it.x1 = params + q.off_z; it.n1 = q.M; it.x2 = nullptr; it.n2 = n; it.G = bb.G; it.ldg = ldN;
+        it.alpha = bb.alpha; it.gm = p->gFmu + (size_t)g * n; it.symmetric = 0; it.partials = bb.hyp_part; it.gz = nullptr;
+        it.kvals = t.Kuf; it.ldk = ldN; it.g32 = p->f32;
+        if (gp_kern_is_mercer(q.ktype) && t.feat) {
+          it.f1 = t.feat;
+          it.f2 = t.feat + gp_align_up((size_t)2 * sm_mpad(q.m) * q.M, 32);
+        }
+      }
+    }
   }
   return GP_OK;
 }
@@ -1055,24 +1135,27 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       if (st == GP_OK) st = s2;
       GP_CHECK(st);
     }
-    // Kuf_bar (dense part) = R (A diag(2 gv))
-    f = GemmFlags(); f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
-    if (f32) GP_CHECK(launch_gemm_f32_role(h, D(S_G), nK, maxM, n, f));
-    else GP_CHECK(launch_gemm_batched(h, D(S_G), nK, maxM, n, f));
-    if (!forked) {
-      if (early_fork) { GP_CHECK(h_chain_head()); GP_CHECK(wbar_chain()); }   // (no helper stream to be had)
-      GP_CHECK(kuu_side());
-    }
-    if (!white) {
-      GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));
-      f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;
-      GP_CHECK(launch_gemm_batched(h, D(S_GQ_L), G, maxM, maxM, f));
-    }
-    // Kuf side of the hyper-parameter and inducing-input gradients.  The stationary kernels' contractions are short
-    // and latency-bound: with a fork pending they go to the helper stream (which is idle by now) while the main stream
-    // does the spectral-mixture ones; their finish kernels follow the join.
+    // Kuf_bar (dense part) = R (A diag(2 gv)), and its contraction with dK/dtheta over all frames.
+    // The contractions are one launch per kernel family (item arrays built at bind time).  With exactly two families —
+    // the transcription model: stationary activations, spectral-mixture components — whose GPs sit in contiguous runs
+    // of the compacted batch, the product is issued family by family, the spectral-mixture family first: its contraction
+    // (the long one: 40 % of it matrix-core work) then runs on the side stream UNDERNEATH the second family's product
+    // instead of after it, and only the stationary family's short, HBM-bound contraction is left behind the product.
     std::vector<int> np_uf(p->G, 0);
-    auto kuf_contract = [&](int g) -> gp_status {
+    auto fam_slot0 = [&](const gp_pdgp_plan_s::HyFamily& fam) -> int {    // first slot in the compacted batch, -1 if scattered
+      int s0 = -1;
+      for (size_t s = 0; s < p->kgps.size(); s++) if (p->kgps[s] == fam.gps[0]) s0 = (int)s;
+      for (size_t i = 0; i < fam.gps.size(); i++)
+        if (s0 < 0 || s0 + (int)i >= (int)p->kgps.size() || p->kgps[s0 + i] != fam.gps[i]) return -1;
+      return s0;
+    };
+    auto kuf_bar = [&](int slot0, int count) -> gp_status {
+      GemmFlags f;
+      f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
+      if (f32) return launch_gemm_f32_role(h, D(S_G) + slot0, count, maxM, n, f);
+      return launch_gemm_batched(h, D(S_G) + slot0, count, maxM, n, f);
+    };
+    auto kuf_contract = [&](int g) -> gp_status {      // one GP (inducing-input gradients, mixed sizes)
       const PdgpGP& q = p->gps[g];
       const CondTask& t = p->cb.tasks[g];
       const BwdBufs& bb = p->bw[g];
@@ -1082,19 +1165,58 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       return launch_hyper_contract(h, t.kern, z, q.M, x, n, bb.G, ldN, bb.alpha, gm, 0, t.feat, bb.hyp_part, &np_uf[g], gz_uf,
                                    t.Kuf, ldN, f32);
     };
-    const bool split = forked && p->overlap >= 2 && gp_aux_resume(h);
-    if (split) {
-      gp_status st2 = GP_OK;
-      for (int g : p->kgps)
-        if (st2 == GP_OK && !gp_kern_has_partials(p->gps[g].ktype)) st2 = kuf_contract(g);
-      gp_status s3 = gp_aux_end(h);
-      if (st2 == GP_OK) st2 = s3;
-      GP_CHECK(st2);
+    auto contract_family = [&](const gp_pdgp_plan_s::HyFamily& fam) -> gp_status {
+      if (!fam.batched) { for (int g : fam.gps) GP_CHECK(kuf_contract(g)); return GP_OK; }
+      int np = 0;
+      GP_CHECK(launch_hyper_contract_items(h, fam.type, fam.m, (const HyperItem*)(p->d_misc + p->off_hy_items) + fam.first,
+                                           fam.count, fam.M, n, 0, &np, fam.mfma, x));
+      for (int g : fam.gps) np_uf[g] = np;
+      return GP_OK;
+    };
+    int sm_fam = -1, other_fam = -1, sm_slot = -1, other_slot = -1;
+    static const int split_mode = getenv("GP_KUFBAR_SPLIT") ? atoi(getenv("GP_KUFBAR_SPLIT")) : 0;   // A/B switch (profiles/r02)
+    if (split_mode == 1 && p->hy_fams.size() == 2 && forked && p->overlap >= 2) {
+      for (int fi = 0; fi < 2; fi++) {
+        if (p->hy_fams[fi].mfma) sm_fam = fi; else other_fam = fi;
+      }
+      if (sm_fam >= 0 && other_fam >= 0) { sm_slot = fam_slot0(p->hy_fams[sm_fam]); other_slot = fam_slot0(p->hy_fams[other_fam]); }
     }
-    for (int g : p->kgps) {
-      if (split && !gp_kern_has_partials(p->gps[g].ktype)) continue;
-      GP_CHECK(kuf_contract(g));
+    if (sm_slot >= 0 && other_slot >= 0) {
+      const auto& fs = p->hy_fams[sm_fam];
+      const auto& fo = p->hy_fams[other_fam];
+      GP_CHECK(kuf_bar(sm_slot, fs.count));
+      const bool side = gp_side_begin(h);              // the side stream picks up once that product is through
+      if (side) {
+        gp_status st2 = contract_family(fs);
+        gp_status s3 = gp_side_end(h);
+        GP_CHECK(st2); GP_CHECK(s3);
+      }
+      GP_CHECK(kuf_bar(other_slot, fo.count));
+      if (!side) GP_CHECK(contract_family(fs));
+      GP_CHECK(contract_family(fo));
+    } else {
+      GP_CHECK(kuf_bar(0, nK));
+      if (!forked) {
+        if (early_fork) { GP_CHECK(h_chain_head()); GP_CHECK(wbar_chain()); }   // (no helper stream to be had)
+        GP_CHECK(kuu_side());
+      }
+      // the families' contractions side by side: the matrix-core ones on this stream, the others (short, HBM-bound) on
+      // the side stream
+      const bool side = (p->hy_fams.size() > 1) && forked && p->overlap >= 2 && gp_side_begin(h);
+      if (side) {
+        gp_status st2 = GP_OK;
+        for (const auto& fam : p->hy_fams) if (!fam.mfma && st2 == GP_OK) st2 = contract_family(fam);
+        gp_status s3 = gp_side_end(h);
+        GP_CHECK(st2); GP_CHECK(s3);
+      }
+      for (const auto& fam : p->hy_fams) if (!side || fam.mfma) GP_CHECK(contract_family(fam));
     }
+    if (!white) {
+      GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));
+      f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER; f.triC = TRI_LOWER;
+      GP_CHECK(launch_gemm_batched(h, D(S_GQ_L), G, maxM, maxM, f));
+    }
+    GP_CHECK(gp_side_join(h));
     GP_CHECK(gp_aux_join(h));
     // all partial sums (Kuf side, Kuu side) are in: ONE finish launch adds them into the gradient vector (48 tiny
     // launches at the end of every step otherwise).  The item array is re-uploaded only when it changes.

@@ -26,6 +26,10 @@ struct gp_handle_s {
   // while the Kuf builds stream over the rest): created on first use, joined through events
   hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_era = nullptr, ev_kuu = nullptr;
   hipStream_t main_stream_saved = nullptr; bool aux_active = false, aux_pending = false;
+  // second helper stream ("side"): one more independent piece of a step (the spectral-mixture Kuf-side contractions
+  // underneath the second half of the Kuf_bar product); gp_side_begin / _end / _join
+  hipStream_t side_stream = nullptr; hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
+  hipStream_t side_saved = nullptr; bool side_active = false, side_pending = false;
   // timers
   bool timers_on = false;
   struct TimerRec { hipEvent_t e0, e1; int which; };
@@ -129,6 +133,11 @@ bool gp_aux_fork(gp_handle h);
 bool gp_aux_resume(gp_handle h);
 gp_status gp_aux_end(gp_handle h);
 gp_status gp_aux_join(gp_handle h);
+// the same for the second helper stream: between gp_side_begin (true on success) and gp_side_end the launchers target it;
+// the work there starts after everything enqueued on the current stream so far; gp_side_join makes the current stream wait
+bool gp_side_begin(gp_handle h);
+gp_status gp_side_end(gp_handle h);
+gp_status gp_side_join(gp_handle h);
 
 struct GpTimerScope {
   gp_handle h;

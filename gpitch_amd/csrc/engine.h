@@ -40,7 +40,8 @@ struct HyperItem {
   DevKern k;
   const double* x1; const double* x2; const double* G; const double* alpha; const double* gm;
   const double* f1; const double* f2; double* partials; double* gz;
-  int64_t ldg; int n1, n2, symmetric, pad;
+  const double* kvals;            // the covariance strip itself (Mercer Kuf side, matrix-core form), or null
+  int64_t ldg, ldk; int n1, n2, symmetric, g32;
 };
 struct HyperFinishItem {
   DevKern k;
@@ -48,8 +49,9 @@ struct HyperFinishItem {
   double* g_theta; const double* gz_uf; const double* gz_uu; double* g_z;
   int np_uf, np_uu, cb_uf, cb_uu, n1, pad;
 };
+// use_mfma: Mercer family, every item has kvals and no inducing-input gradient -> hyper_sm_mfma_kernel over the items
 gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
-                                      int with_gz, int* nparts);
+                                      int with_gz, int* nparts, int use_mfma = 0, const double* x2_shared = nullptr);
 gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items, int count, int maxblocks);
 size_t hyper_finish_item_bytes();
 // partial records the Kuf-side contraction of an M x N strip may write (the largest over its kernel variants)

@@ -33,7 +33,10 @@ typedef const dbl2 __attribute__((address_space(1))) * gcptr2;
 // Threads per workgroup: 4 wavefronts (1 x 4 on the 128-tiles, each 128 x 32; 2 x 2 on the 64-tiles), except the
 // Lq^T A strip product (TAG 2), which measures 5 % faster with 8 (2 x 4, each 64 x 32, <= 128 VGPRs: four
 // wavefronts per SIMD); the other roles lose more to the extra LDS reads and staging than they gain.
-constexpr int gemm_threads(int BM, int TAG) { return (BM == 128 && TAG == 2) ? 512 : 256; }
+#ifndef GP_GEMM_8W_TAG
+#define GP_GEMM_8W_TAG 2      // a second role to build with 8 wavefronts (same-box A/B builds only)
+#endif
+constexpr int gemm_threads(int BM, int TAG) { return (BM == 128 && (TAG == 2 || TAG == GP_GEMM_8W_TAG)) ? 512 : 256; }
 #define GEMM_BK 16
 #ifndef GP_MFMA_PRIO
 #define GP_MFMA_PRIO 2

@@ -68,6 +68,7 @@ gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* o
 
 gp_status gp_pdgp_destroy(gp_pdgp_plan p) {
   if (p && p->h && p->h->aux_stream) (void)hipStreamSynchronize(p->h->aux_stream);   // nothing of this plan still in flight
+  if (p && p->h && p->h->side_stream) (void)hipStreamSynchronize(p->h->side_stream);
   delete p;
   return GP_OK;
 }
@@ -109,7 +110,7 @@ gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t*
 
 static size_t pdgp_misc_bytes(const gp_pdgp_plan_s* p) {
   return 2 * pdgp_kl_region_bytes(p->G) + 24 * gp_align_up(p->G * sizeof(GemmProblem), 256) +
-         gp_align_up(p->G * hyper_finish_item_bytes(), 256);
+         gp_align_up(p->G * hyper_finish_item_bytes(), 256) + gp_align_up(p->G * sizeof(HyperItem), 256);
 }
 
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {

@@ -62,6 +62,10 @@ struct gp_pdgp_plan_s {
   size_t off_kl_items = 0;
   size_t off_bwd[24] = {0};
   size_t off_fin_items = 0; std::vector<char> h_fin_items;   // batched hyper-gradient finish (bwd.hip)
+  // Kuf-side contractions grouped by kernel family: one launch per family over an item array (bwd.hip)
+  size_t off_hy_items = 0;
+  struct HyFamily { int type = 0, m = 0, first = 0, count = 0, M = 0, mfma = 0; bool batched = false; std::vector<int> gps; };
+  std::vector<HyFamily> hy_fams;
   size_t off_kl2 = 0;         // unwhitened backward: KL items of the equivalent whitened state
   double* qw_block = nullptr; size_t qw_doubles = 0;   // [q' | grad q'] of all GPs, contiguous (one memset)
   double* kl_dummy = nullptr;
