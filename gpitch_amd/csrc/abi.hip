@@ -149,6 +149,7 @@ gp_status gp_destroy(gp_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& r : h->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
+  if (h->poll_host) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->poll_host); (void)hipEventDestroy(h->ev_poll); }
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
@@ -447,6 +448,40 @@ gp_status gp_transform_backward(gp_handle h, const double* params, const uint8_t
   if (!fs || !tcode || !params || n < 0) return gp_fail(h, GP_ERR_BAD_ARG, "gp_transform_backward: bad argument");
   return launch_transform_backward(h, params, tcode, n, fs);
 }
+// Blocking form: drains the handle's streams, then GP_ERR_NOT_PD (pivot index via gp_last_not_pd_index) if a Cholesky has
+// failed since the flag was last cleared; clears the flag.
+gp_status gp_check_not_pd(gp_handle h) {
+  if (!h) return GP_ERR_BAD_ARG;
+  GP_CHECK(gp_sync(h));
+  h->poll_inflight = false;
+  if (h->poll_host) h->poll_host[0] = 0;
+  return check_not_pd(h);
+}
+
+// Non-blocking look at the not-positive-definite flag: copies the device status word into pinned host memory behind
+// everything enqueued so far and reports what the PREVIOUS poll's copy (complete by now or not yet) showed.  *flag = 1
+// once a poll has seen a failed Cholesky; gp_check_not_pd / any host-scalar call then returns GP_ERR_NOT_PD as usual.
+gp_status gp_poll_not_pd(gp_handle h, int32_t* flag) {
+  if (!h || !flag) return GP_ERR_BAD_ARG;
+  *flag = 0;
+  if (!h->poll_host) {
+    GP_HIP_CHECK(h, hipHostMalloc((void**)&h->poll_host, 4 * sizeof(int32_t), hipHostMallocDefault));
+    memset(h->poll_host, 0, 4 * sizeof(int32_t));
+    GP_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming));
+    h->poll_inflight = false;
+  }
+  if (h->poll_inflight) {
+    const hipError_t q = hipEventQuery(h->ev_poll);
+    if (q == hipSuccess) { h->poll_inflight = false; if (h->poll_host[0] != 0) { *flag = 1; return GP_OK; } }
+    else if (q != hipErrorNotReady) { GP_HIP_CHECK(h, q); }
+    else return GP_OK;          // the previous copy has not landed yet: nothing new to say, nothing new to enqueue
+  }
+  GP_HIP_CHECK(h, hipMemcpyAsync(h->poll_host, h->d_status, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  GP_HIP_CHECK(h, hipEventRecord(h->ev_poll, h->stream));
+  h->poll_inflight = true;
+  return GP_OK;
+}
+
 gp_status gp_adam_step(gp_handle h, double* fs, double* params, const double* grad, const uint8_t* tcode, double* m,
                        double* v, int64_t n, int64_t t, double lr, double beta1, double beta2, double eps) {
   if (!h) return GP_ERR_BAD_ARG;

@@ -30,6 +30,8 @@ struct gp_handle_s {
   // underneath the second half of the Kuf_bar product); gp_side_begin / _end / _join
   hipStream_t side_stream = nullptr; hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
   hipStream_t side_saved = nullptr; bool side_active = false, side_pending = false;
+  // gp_poll_not_pd: pinned landing zone of the status word, event behind its copy
+  int32_t* poll_host = nullptr; hipEvent_t ev_poll = nullptr; bool poll_inflight = false;
   // timers
   bool timers_on = false;
   struct TimerRec { hipEvent_t e0, e1; int which; };

@@ -39,7 +39,12 @@ __global__ void __launch_bounds__(256) transform_bwd_kernel(const double* __rest
 __global__ void __launch_bounds__(256) adam_kernel(double* __restrict__ fs, double* __restrict__ params,
                                                    const double* __restrict__ grad, const uint8_t* __restrict__ tc,
                                                    double* __restrict__ m, double* __restrict__ v, int64_t n, double lr_t,
-                                                   double b1, double b2, double eps, GpLogisticTable T) {
+                                                   double b1, double b2, double eps, GpLogisticTable T,
+                                                   const int32_t* __restrict__ status) {
+  // a Cholesky of this evaluation hit a non-positive pivot (chol_diag_block carried on with a substitute): the gradient
+  // is garbage and the reference would have raised here (TF InvalidArgumentError) — leave the state untouched, the
+  // host sees the flag at its next poll
+  if (status && status[0] != 0) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint8_t t = tc[i];
     if (t == 2) continue;
@@ -80,7 +85,7 @@ gp_status launch_adam(gp_handle h, double* fs, double* params, const double* gra
   if (n <= 0) return GP_OK;
   const double lr_t = lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, fs, params, grad, tc, m, v, n, lr_t, b1,
-                     b2, eps, h->logistic);
+                     b2, eps, h->logistic, (const int32_t*)h->d_status);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }

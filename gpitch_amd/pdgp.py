@@ -325,6 +325,7 @@ class Pdgp(Parameterized):
         self._pack()
         h = self._handle
         if isinstance(method, AdamOptimizer):
+            flag = C.c_int32(0)
             for it in range(maxiter):
                 self._elbo(True, sync=False)
                 self._adam_t += 1
@@ -332,8 +333,14 @@ class Pdgp(Parameterized):
                                            self._tcode.data_ptr(), self._adam_m.data_ptr(), self._adam_v.data_ptr(),
                                            self._nparams, self._adam_t, method.learning_rate, method.beta1,
                                            method.beta2, method.epsilon))
+                # a failed Cholesky freezes the optimiser state on the device (gp_adam_step); the loop itself stops at
+                # the next poll that has seen the flag — no host synchronisation per step
+                h.check(h.lib.gp_poll_not_pd(h.h, C.byref(flag)))
+                if flag.value:
+                    h.check(h.lib.gp_check_not_pd(h.h))     # raises NotPositiveDefiniteError with the pivot index
                 if callback is not None:
                     callback(self._free.cpu().numpy())
+            h.check(h.lib.gp_check_not_pd(h.h))             # a failure in the last few steps, not polled yet
             # GPflow evaluates the returned `fun`/`jac` on a fresh minibatch (demo_modgp.ipynb:140-146)
             x_final = self._free.cpu().numpy()
             f, g = self._objective(x_final)

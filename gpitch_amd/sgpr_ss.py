@@ -28,8 +28,11 @@ class SGPRSS(Parameterized):
         built with the full X, Y; it uploads only its contiguous slice, and each bound / gradient evaluation
         exchanges one all-reduce of M^2 + M + 2 doubles (plus one of the small gradient vector): see
         include/gpitch_abi.h gp_sgpr_bound_begin / _end.  Predictions need the whole window on one GPU."""
-        if mean_function is not None:
-            raise NotImplementedError("only the zero mean function is used on the gpitch path")
+        # mean_function (sgpr_ss.py:14,25): a fixed function of the inputs, subtracted from Y in the bound (:40) and in
+        # the exact posterior (:90), added back to predicted means (:95); see mean_functions.py
+        if mean_function is not None and not callable(mean_function):
+            raise TypeError("mean_function must be callable on an (n, 1) array (gpitch_amd.mean_functions)")
+        object.__setattr__(self, "mean_function", mean_function)
         if not isinstance(kern, Add):
             kern = Add([kern])
         if reg:
@@ -124,7 +127,10 @@ class SGPRSS(Parameterized):
         fr = self._frames()
         self._dev("_params", host)
         self._dev("_Xd", self.X._array[fr])
-        self._dev("_Yd", self.Y._array[fr])
+        yv = self.Y._array[fr]
+        if self.mean_function is not None:          # err = Y - mean_function(X)
+            yv = yv - np.asarray(self.mean_function(self.X._array[fr]), dtype=np.float64).reshape(yv.shape)
+        self._dev("_Yd", yv)
         self._dev("_Zd", self.Z._array)
         object.__setattr__(self, "_n_local", fr.stop - fr.start)
         object.__setattr__(self, "_obj_state", None)      # Param values / .fixed flags may have changed
@@ -181,7 +187,10 @@ class SGPRSS(Parameterized):
         h.check(h.lib.gp_sgpr_predict_f(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
                                         self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(), n, mean.data_ptr(),
                                         var.data_ptr()))
-        return mean.cpu().numpy().reshape(-1, 1), var.cpu().numpy().reshape(-1, 1)
+        mu = mean.cpu().numpy().reshape(-1, 1)
+        if self.mean_function is not None:          # SGPR.build_predict: + mean_function(Xnew)
+            mu = mu + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(-1, 1)
+        return mu, var.cpu().numpy().reshape(-1, 1)
 
     def build_predict_source(self, Xnew, full_cov=False):
         """p(source* | Y): exact GP on the N training frames, one posterior per kernel in kern_list
@@ -202,6 +211,8 @@ class SGPRSS(Parameterized):
                                              self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(), var.data_ptr(),
                                              ws.data_ptr(), ws.numel()))
         m, v = mean.cpu().numpy(), var.cpu().numpy()
+        if self.mean_function is not None:          # sgpr_ss.py:95 adds it to EVERY source's mean
+            m = m + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(1, -1)
         return [m[i].reshape(-1, 1) for i in range(P)], [v[i].reshape(-1, 1) for i in range(P)]
 
     def predict_s(self, Xnew):

@@ -254,6 +254,13 @@ gp_status gp_transform_backward(gp_handle h, const double* params, const uint8_t
                                 double* free_state);
 /* One Adam step maximising the ELBO: g_free = -(grad * dparams/dfree); TF-1.2 update rule; then
  * params = transform(free).  t is the 1-based step count. */
+/* A failed Cholesky inside an asynchronous evaluation (sync-free training loops) sets a device flag; while it is set
+ * gp_adam_step leaves the free state, the parameters and the moments untouched, so a training loop cannot walk on from
+ * garbage gradients (the reference's TF session raises at the offending step).  gp_poll_not_pd looks at the flag without
+ * blocking (pinned copy + event): *flag = 1 once a failure has been observed; gp_check_not_pd (drains the streams; or any
+ * call that returns a host scalar) then gives GP_ERR_NOT_PD with the pivot index and clears the flag. */
+gp_status gp_poll_not_pd(gp_handle h, int32_t* flag);
+gp_status gp_check_not_pd(gp_handle h);
 gp_status gp_adam_step(gp_handle h, double* free_state, double* params, const double* grad,
                        const uint8_t* tcode, double* m, double* v, int64_t n, int64_t t, double lr,
                        double beta1, double beta2, double eps);

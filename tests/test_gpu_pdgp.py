@@ -517,3 +517,30 @@ def test_overlap_levels_give_identical_results(gp_handle, N, M, P):
                 assert np.array_equal(a[1], b[1]), level
     with pytest.raises(Exception):
         gp_handle.check(gp_handle.lib.gp_pdgp_set_overlap(m._plan, 3))
+
+
+def test_adam_stops_at_a_failed_cholesky_and_leaves_the_state_alone(gp_handle):
+    """GPflow / TF raise InvalidArgumentError at the step whose tf.cholesky fails.  The sync-free Adam loop polls a
+    device flag instead: gp_adam_step freezes free state, parameters and moments while it is set, and the loop raises
+    at the next poll that has seen it (well before maxiter)."""
+    import gpitch_amd
+    from gpitch_amd import _lib
+    from gpitch_amd.param import transforms
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(4096, 32, 1, num_partials=2, seed=4)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model.kern_act[0].variance.transform = transforms.Identity()
+    model.kern_act[0].variance = -1.0             # Kuu = -K: the first pivot is negative
+    model.za.fixed = True
+    model.zc.fixed = True
+    model._pack()
+    before = model._free.cpu().numpy().copy()
+    calls = []
+    with pytest.raises(_lib.NotPositiveDefiniteError):
+        model.optimize(method=gpitch_amd.train.AdamOptimizer(0.01), maxiter=400, callback=lambda x: calls.append(1))
+    assert len(calls) < 400                      # stopped inside the loop, not at its end
+    np.testing.assert_array_equal(model._free.cpu().numpy(), before)     # no update from the garbage gradients
+    assert np.all(model._adam_m.cpu().numpy() == 0)
+    # the handle is usable again afterwards
+    model.kern_act[0].variance = 1.0
+    assert np.isfinite(model.compute_log_likelihood())

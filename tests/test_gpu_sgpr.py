@@ -252,3 +252,33 @@ def test_frame_sharded_window_matches_unsharded(gp_handle, world, reg):
         m = shards[0]
         h.check(h.lib.gp_sgpr_bound_end(m._plan, m._params.data_ptr(), m._Xd.data_ptr(), m._Yd.data_ptr(), m._n_local, 1101,
                                         m._Zd.data_ptr(), total.data_ptr(), m._bound_dev.data_ptr(), None, None, 1))
+
+
+def test_sgprss_mean_function(gp_handle):
+    """SGPRSS(mean_function=...) (sgpr_ss.py:14,40,90,95): bound and gradients are those of the data with the mean
+    subtracted; predicted means get it back (each source's too, as the reference does)."""
+    from gpitch_amd.mean_functions import Constant, Linear, Zero
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm
+    from gpitch_amd.sgpr_ss import SGPRSS
+    X, Y, Z, kl = _problem(1200, 40, 2, 11)
+    for mf in (Zero(), Constant(0.37), Linear(2.0, -0.1), lambda x: 0.2 * np.sin(40. * x)):
+        ks = [MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=d["variance"],
+                               lengthscales=d["lengthscales"]) for d in kl]
+        m = SGPRSS(X, Y, np.sum(ks), Z, mean_function=mf, handle=gp_handle)
+        m.likelihood.variance = 0.3
+        shift = np.asarray(mf(X)).reshape(-1, 1)
+        ref = orc.sgpr_bound(X, Y - shift, Z, kl, 0.3)
+        got = m.build_likelihood()
+        assert abs(got - ref) <= 1e-9 * abs(ref), (got, ref)
+        plain = _model(X, Y - shift, Z, kl, 0.3, gp_handle)
+        xs = X[::7]
+        mu, var = m.predict_f(xs)
+        mu0, var0 = plain.predict_f(xs)
+        np.testing.assert_allclose(mu, mu0 + np.asarray(mf(xs)).reshape(-1, 1), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(var, var0, rtol=0, atol=1e-12)
+        ms, vs = m.predict_s(xs)
+        ms0, vs0 = plain.predict_s(xs)
+        for a, b in zip(ms, ms0):
+            np.testing.assert_allclose(a, b + np.asarray(mf(xs)).reshape(-1, 1), rtol=0, atol=1e-11)
+    with pytest.raises(TypeError):
+        SGPRSS(X, Y, np.sum(ks), Z, mean_function=3.0, handle=gp_handle)
