@@ -92,18 +92,30 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
   const int triB = RoleCfg<TAG>::triB >= 0 ? RoleCfg<TAG>::triB : f.triB;
   const int scale_mode = RoleCfg<TAG>::scale >= 0 ? RoleCfg<TAG>::scale : f.scale_mode;
 
-  const GemmProblem p = probs[blockIdx.z];
+  // XCD-aware renumbering.  The hardware deals workgroups to the 8 XCDs round-robin in dispatch order (x fastest, then
+  // the batch index z), so blocks b and b + 8 of the FLATTENED grid share an XCD (and its L2).  Each XCD is given a
+  // contiguous range of logical (tile, batch) indices.  The split-K grid (tiles x slices = 90 per GP at the bench
+  // shape) is not a multiple of 8 per batch entry, and renumbering x alone left its ten tiles of a K-slice on eight
+  // different L2s: every tile fetched both its operand strips from HBM (13 GB per launch for 3.2 GB of operands).
+  int bid = blockIdx.x, bz = blockIdx.z;
+  {
+    const int nx = gridDim.x, total = nx * (int)gridDim.z;
+    if ((total & 7) == 0) {
+      const int lin = bz * nx + bid;
+      const int log = (lin & 7) * (total >> 3) + (lin >> 3);
+      bz = log / nx; bid = log - bz * nx;
+    }
+  }
+  const GemmProblem p = probs[bz];
   const gcptr gA = (gcptr)p.A, gB = (gcptr)p.B, gv0 = (gcptr)p.v0, gv1 = (gcptr)p.v1;
   const gptr gC = (gptr)p.C, go0 = (gptr)p.o0, go1 = (gptr)p.o1, go2 = (gptr)p.o2;
-  int bid = blockIdx.x;
   int tm, tn, ksl = 0;
   if (f.ksplit > 1) {
     // split-K.  With a symmetric (lower) output only the tilesM(tilesM+1)/2 tiles on or below the diagonal are
-    // enumerated, so every launched workgroup has work.  Order: XCD-contiguous ranges, and inside a range the
-    // OUTPUT TILE varies fastest, so the workgroups resident together on one XCD work on the same K-slice of
-    // different tiles and share its operand strips in that XCD's L2 (each strip is used by tilesM+1 tiles).
+    // enumerated, so every launched workgroup has work.  Inside an XCD's range the OUTPUT TILE varies fastest, so the
+    // workgroups resident together on one XCD work on the same K-slice of different tiles and share its operand
+    // strips in that XCD's L2 (each strip is used by tilesM+1 tiles).
     const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ntl = (f.triC == TRI_LOWER) ? f.tilesM * (f.tilesM + 1) / 2 : f.tilesM * f.tilesN;
     ksl = bid / ntl;
     const int t = bid % ntl;
@@ -116,10 +128,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
       tm = t % f.tilesM; tn = t / f.tilesM;
     }
   } else {
-    // XCD-aware renumbering: blocks b and b+8 share an XCD; give each XCD a contiguous range of logical
-    // tiles so that the row-blocks that read the same B strip hit the same L2.
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    // (XCD-contiguous logical order from above: the row-blocks that read the same B strip hit the same L2)
     // Row-blocks of a triangular product differ ~7x in work and the hardware deals consecutive workgroups
     // to the shader engines round-robin, so a fixed (bid % tilesM) would pin all the heavy row-blocks on
     // one engine; rotating by the strip index keeps a strip's row-blocks adjacent but cycles who gets which.
@@ -338,14 +347,22 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
     for (int b = 0; b < TN; b++) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
   const int rowbase = i0 + wr * WM;
+  // K order.  Lq^T A (TAG 2, upper-triangular op(A)): row-block r needs k in [128 r, M).  Walking k UPWARDS, the four
+  // row-blocks of a column strip start at four different places and never meet: each fetched its own copy of the B
+  // strip (8.5 GB per launch for 3.2 GB of operands, exactly (4+3+2+1)/4 x).  Walking DOWN from the common end they
+  // run in step through the part they share and the strip leaves HBM once.
+  constexpr bool KDOWN = (TAG == 2);
   auto run_k_loop = [&](auto fast_tag) {
-    load_tiles(kbeg, fast_tag);
-    store_tiles(0, kbeg);
+    const int nkt = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    const int kfirst = KDOWN ? kbeg + (nkt - 1) * GEMM_BK : kbeg;
+    const int kstep = KDOWN ? -GEMM_BK : GEMM_BK;
+    load_tiles(kfirst, fast_tag);
+    store_tiles(0, kfirst);
     __syncthreads();
     int buf = 0;
-    for (int kt = kbeg; kt < kend; kt += GEMM_BK) {
-      const bool more = (kt + GEMM_BK < kend);
-      if (more) load_tiles(kt + GEMM_BK, fast_tag);
+    for (int it = 0, kt = kfirst; it < nkt; it++, kt += kstep) {
+      const bool more = (it + 1 < nkt);
+      if (more) load_tiles(kt + kstep, fast_tag);
       const double* As = smem + buf * S::STAGE;
       const double* Bs = As + S::A_ELEMS;
       // K-tiles strictly inside the non-zero part of a triangular op(A) run the straight-line body; only
@@ -409,7 +426,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
         }
         __builtin_amdgcn_s_setprio(0);
       }
-      if (more) store_tiles(buf ^ 1, kt + GEMM_BK);
+      if (more) store_tiles(buf ^ 1, kt + kstep);
       __syncthreads();
       buf ^= 1;
     }

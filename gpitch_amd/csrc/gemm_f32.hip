@@ -62,18 +62,23 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   extern __shared__ __attribute__((aligned(16))) float smem32[];
 
-  const GemmProblem p = probs[blockIdx.z];
+  // XCD-contiguous ranges of logical (tile, batch) indices over the flattened grid (see gemm.hip)
+  int bid = blockIdx.x, bz = blockIdx.z;
+  {
+    const int nx = gridDim.x, total = nx * (int)gridDim.z;
+    if ((total & 7) == 0) {
+      const int lin = bz * nx + bid;
+      const int log = (lin & 7) * (total >> 3) + (lin >> 3);
+      bz = log / nx; bid = log - bz * nx;
+    }
+  }
+  const GemmProblem p = probs[bz];
   const gcptr gA64 = (gcptr)p.A; const gcfptr gA32 = (gcfptr)(const void*)p.A;
   const gcfptr gB = (gcfptr)(const void*)p.B;
   const gfptr gC = (gfptr)(void*)p.C;
   const gcptr gv0 = (gcptr)p.v0, gv1 = (gcptr)p.v1, gv2 = (gcptr)p.v2;
   const gptr go0 = (gptr)p.o0, go1 = (gptr)p.o1, go2 = (gptr)p.o2;
 
-  int bid = blockIdx.x;
-  {
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous ranges of logical tiles
-  }
   int tm, tn, ksl = 0;
   if (TAG == 4) {
     const int ntl = f.sym ? f.tilesM * (f.tilesM + 1) / 2 : f.tilesM * f.tilesN;
@@ -268,14 +273,18 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
 #pragma unroll
     for (int b = 0; b < TN; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr bool KDOWN = (TAG == 2);      // the row-blocks of a strip walk down from their common end (gemm.hip)
   auto run_k_loop = [&](auto fast_tag) {
-    load_tiles(kbeg, fast_tag);
-    store_tiles(0, kbeg);
+    const int nkt = (kend - kbeg + F32_BK - 1) / F32_BK;
+    const int kfirst = KDOWN ? kbeg + (nkt - 1) * F32_BK : kbeg;
+    const int kstep = KDOWN ? -F32_BK : F32_BK;
+    load_tiles(kfirst, fast_tag);
+    store_tiles(0, kfirst);
     __syncthreads();
     int buf = 0;
-    for (int kt = kbeg; kt < kend; kt += F32_BK) {
-      const bool more = (kt + F32_BK < kend);
-      if (more) load_tiles(kt + F32_BK, fast_tag);
+    for (int it = 0, kt = kfirst; it < nkt; it++, kt += kstep) {
+      const bool more = (it + 1 < nkt);
+      if (more) load_tiles(kt + kstep, fast_tag);
       const float* As = smem32 + buf * STAGE;
       const float* Bs = As + A_ELEMS;
       bool full = true;
@@ -312,7 +321,7 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
         }
       }
       __builtin_amdgcn_s_setprio(0);
-      if (more) store_tiles(buf ^ 1, kt + F32_BK);
+      if (more) store_tiles(buf ^ 1, kt + kstep);
       __syncthreads();
       buf ^= 1;
     }
