@@ -33,6 +33,9 @@ typedef const dbl2 __attribute__((address_space(1))) * gcptr2;
 // Threads per workgroup: 4 wavefronts (1 x 4 on the 128-tiles, each 128 x 32; 2 x 2 on the 64-tiles), except the
 // Lq^T A strip product (TAG 2), which measures 5 % faster with 8 (2 x 4, each 64 x 32, <= 128 VGPRs: four
 // wavefronts per SIMD); the other roles lose more to the extra LDS reads and staging than they gain.
+#ifndef GP_GEMM_NT_STORE
+#define GP_GEMM_NT_STORE 0
+#endif
 #ifndef GP_GEMM_8W_TAG
 #define GP_GEMM_8W_TAG 2      // a second role to build with 8 wavefronts (same-box A/B builds only)
 #endif
@@ -471,7 +474,8 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
             gptr c = gC + (int64_t)i * p.ldc + j;
             if (f.beta != 0.0) v += f.beta * (*c);
             if (f.triC == TRI_LOWER && j > i) v = 0.0;
-            *c = v;
+            if (GP_GEMM_NT_STORE && (TAG == 1 || TAG == 3)) __builtin_nontemporal_store(v, c);   // strips: read again only after the whole launch
+            else *c = v;
           }
         }
   }
