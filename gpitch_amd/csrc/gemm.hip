@@ -33,6 +33,9 @@ typedef const dbl2 __attribute__((address_space(1))) * gcptr2;
 // Threads per workgroup: 4 wavefronts (1 x 4 on the 128-tiles, each 128 x 32; 2 x 2 on the 64-tiles), except the
 // Lq^T A strip product (TAG 2), which measures 5 % faster with 8 (2 x 4, each 64 x 32, <= 128 VGPRs: four
 // wavefronts per SIMD); the other roles lose more to the extra LDS reads and staging than they gain.
+#ifndef GP_GEMM_NOSKIP
+#define GP_GEMM_NOSKIP 0
+#endif
 #ifndef GP_GEMM_NT_STORE
 #define GP_GEMM_NT_STORE 0
 #endif
@@ -373,6 +376,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
       bool full = true;
       if (triA == TRI_LOWER) full = (kt <= rowbase);
       if (triA == TRI_UPPER) full = (kt >= rowbase + 16 * TM - 16);
+      if (GP_GEMM_NOSKIP) full = true;       // experiment: no skipping inside the diagonal block (operands are masked)
       if (full) {
         __builtin_amdgcn_s_setprio(GP_MFMA_PRIO);
 #pragma unroll

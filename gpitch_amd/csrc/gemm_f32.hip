@@ -51,12 +51,18 @@ struct Gemm32Flags {
 
 // TAG: 1 cond_A (A = W lower, float64 in memory, k-contiguous), 2 cond_LTA (A = Lq^T, upper, float64, row-contiguous),
 //      3 kuf_bar (A = R dense, float64, k-contiguous), 4 nt (A, B float32 strips, both k-contiguous, split-K)
-template <int TAG>
-__global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProblem* __restrict__ probs, Gemm32Flags f) {
+// W8: 8 wavefronts per workgroup (2 x 4: each 64 rows x 32 columns, <= 128 VGPRs, four wavefronts per SIMD) instead of
+// 4 (1 x 4: each 128 x 32).  A float32 MFMA K-tile is half as long as a float64 one against the same staging work, so
+// with two wavefronts per SIMD the matrix pipe idles whenever both are staging (0.68 busy on the dense product).
+template <int TAG, bool W8>
+__global__ void __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) gemm_f32_kernel(const GemmProblem* __restrict__ probs, Gemm32Flags f) {
+  constexpr int NTHREADS = W8 ? 512 : 256;
+  constexpr int WAVES_M = W8 ? 2 : 1;
   constexpr bool A_RC = (TAG == 2);          // A tile row-contiguous ([k][i]) instead of k-contiguous ([i][k])
   constexpr bool B_KC = (TAG == 4);          // B tile k-contiguous ([n][k]) instead of row-contiguous ([k][n])
   constexpr bool A_F64 = (TAG != 4);
-  constexpr int TM = 8, TN = 2;              // 16 x 16 MFMA tiles per wave: 128 rows x 32 columns
+  constexpr int TM = 8 / WAVES_M, TN = 2;    // 16 x 16 MFMA tiles per wave: 128 (or 64) rows x 32 columns
+  constexpr int EPT = 4096 / NTHREADS;       // staged elements per thread and tile (16 or 8)
   constexpr int A_ELEMS = A_RC ? F32_RC_ELEMS : F32_KC_ELEMS;
   constexpr int B_ELEMS = B_KC ? F32_KC_ELEMS : F32_RC_ELEMS;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
@@ -108,7 +114,9 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
     kbeg = b0;
   }
 
-  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave & 3, wr = wave >> 2;       // wave column (32 columns each) and wave row
+  const int wrow0 = wr * (16 * TM);              // first row of this wave inside the tile
   const int lc = lane & 15, kq = lane >> 4;
   // column tiles of this wave; the symmetric product pairs tile wc with 7 - wc so that on a diagonal output tile every
   // wave skips the same number of upper MFMA tiles
@@ -119,24 +127,28 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
   const bool diag_sym = PERM && f.sym && (tm == tn);
   int cmin[TN];
 #pragma unroll
-  for (int b = 0; b < TN; b++) cmin[b] = diag_sym ? __builtin_amdgcn_readfirstlane(ctile[b]) : 0;
+  for (int b = 0; b < TN; b++)
+    cmin[b] = diag_sym ? max(0, __builtin_amdgcn_readfirstlane(ctile[b]) - __builtin_amdgcn_readfirstlane(wr) * TM) : 0;
 
   // ---- staging maps -----------------------------------------------------------------------------------------
   // k-contiguous tile: thread t holds 16 consecutive k of row t / 2; row-contiguous tile: thread t holds 4 consecutive
   // columns (t & 31) * 4 of the four k-rows (t >> 5) + 8 e
-  const int kc_r = tid >> 1, kc_k = (tid & 1) * 16;
+  // k-contiguous tile: EPT consecutive k of one row per thread; row-contiguous tile: 4 consecutive columns of EPT / 4 k-rows
+  constexpr int KC_TPR = 32 / EPT;               // threads per row of a k-contiguous tile
+  constexpr int RC_E = EPT / 4, RC_STRIDE = NTHREADS / 32;
+  const int kc_r = tid / KC_TPR, kc_k = (tid % KC_TPR) * EPT;
   const int rc_k = tid >> 5, rc_c = (tid & 31) * 4;
-  double ra64[A_F64 ? 16 : 1];
-  float ra32[A_F64 ? 1 : 16];
-  float rb[16];
-  float rs[16];       // per-element scale of B (role 3: by column, fetched once; role 4: by k)
+  double ra64[A_F64 ? EPT : 1];
+  float ra32[A_F64 ? 1 : EPT];
+  float rb[EPT];
+  float rs[EPT];      // per-element scale of B (role 3: by column, fetched once; role 4: by k)
   const bool rowdot = (TAG == 4) && (p.v2 != nullptr) && (tn == 0);
-  double udot = 0.0, rg[(TAG == 4) ? 16 : 1];
+  double udot = 0.0, rg[(TAG == 4) ? EPT : 1];
   const bool scale = (TAG == 3) || (TAG == 4 && f.scale && p.v1 != nullptr);
 
   if (TAG == 3) {
 #pragma unroll
-    for (int e = 0; e < 4; e++)
+    for (int e = 0; e < RC_E; e++)
 #pragma unroll
       for (int c = 0; c < 4; c++) { const int n = j0 + rc_c + c; rs[e * 4 + c] = (n < p.N) ? (float)gv1[n] : 0.f; }
   }
@@ -150,8 +162,8 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
     // ---- A ----
     if constexpr (A_RC) {           // TAG 2: A_op[i][k] = Lq[k][i]; memory rows are k
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int k = kt + rc_k + 8 * e, i = i0 + rc_c;
+      for (int e = 0; e < RC_E; e++) {
+        const int k = kt + rc_k + RC_STRIDE * e, i = i0 + rc_c;
         const gcptr src = gA64 + (int64_t)k * p.lda + i;
         if (FAST) {
           const dbl2 u = *(gcptr2)(src), v = *(gcptr2)(src + 2);
@@ -166,25 +178,25 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
       const gcptr src = gA64 + (int64_t)i * p.lda + k;
       if (FAST) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) { const dbl2 v = *(gcptr2)(src + e); ra64[e] = v.x; ra64[e + 1] = v.y; }
+        for (int e = 0; e < EPT; e += 2) { const dbl2 v = *(gcptr2)(src + e); ra64[e] = v.x; ra64[e + 1] = v.y; }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; e++) ra64[e] = (i < p.M && k + e < kend) ? src[e] : 0.0;
+        for (int e = 0; e < EPT; e++) ra64[e] = (i < p.M && k + e < kend) ? src[e] : 0.0;
       }
     } else {              // TAG 4: X[i][k] float32 strip
       const int i = i0 + kc_r, k = kt + kc_k;
       const gcfptr src = gA32 + (int64_t)i * p.lda + k;
       if (FAST) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 4) { const f4 v = *(gcfptr4)(src + e); ra32[e] = v.x; ra32[e + 1] = v.y; ra32[e + 2] = v.z; ra32[e + 3] = v.w; }
+        for (int e = 0; e < EPT; e += 4) { const f4 v = *(gcfptr4)(src + e); ra32[e] = v.x; ra32[e + 1] = v.y; ra32[e + 2] = v.z; ra32[e + 3] = v.w; }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; e++) ra32[e] = (i < p.M && k + e < kend) ? src[e] : 0.f;
+        for (int e = 0; e < EPT; e++) ra32[e] = (i < p.M && k + e < kend) ? src[e] : 0.f;
       }
       if constexpr (TAG == 4) {
         if (rowdot) {
 #pragma unroll
-          for (int e = 0; e < 16; e++) rg[e] = (FAST || k + e < kend) ? gv2[k + e] : 0.0;
+          for (int e = 0; e < EPT; e++) rg[e] = (FAST || k + e < kend) ? gv2[k + e] : 0.0;
         }
       }
     }
@@ -194,19 +206,19 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
       const gcfptr src = gB + (int64_t)n * p.ldb + k;
       if (FAST) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 4) { const f4 v = *(gcfptr4)(src + e); rb[e] = v.x; rb[e + 1] = v.y; rb[e + 2] = v.z; rb[e + 3] = v.w; }
+        for (int e = 0; e < EPT; e += 4) { const f4 v = *(gcfptr4)(src + e); rb[e] = v.x; rb[e + 1] = v.y; rb[e + 2] = v.z; rb[e + 3] = v.w; }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; e++) rb[e] = (n < p.N && k + e < kend) ? src[e] : 0.f;
+        for (int e = 0; e < EPT; e++) rb[e] = (n < p.N && k + e < kend) ? src[e] : 0.f;
       }
       if (scale) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) rs[e] = (FAST || k + e < kend) ? (float)gv1[k + e] : 0.f;
+        for (int e = 0; e < EPT; e++) rs[e] = (FAST || k + e < kend) ? (float)gv1[k + e] : 0.f;
       }
     } else {              // TAG 1, 2, 3: B[k][n], n contiguous
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int k = kt + rc_k + 8 * e, n = j0 + rc_c;
+      for (int e = 0; e < RC_E; e++) {
+        const int k = kt + rc_k + RC_STRIDE * e, n = j0 + rc_c;
         const gcfptr src = gB + (int64_t)k * p.ldb + n;
         if (FAST) {
           const f4 v = *(gcfptr4)(src);
@@ -225,20 +237,20 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
     float* Bs = As + A_ELEMS;
     if constexpr (A_RC) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int k = kt + rc_k + 8 * e;
+      for (int e = 0; e < RC_E; e++) {
+        const int k = kt + rc_k + RC_STRIDE * e;
         f4 v;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const int i = i0 + rc_c + c;
           v[c] = (k < i) ? 0.f : (float)ra64[e * 4 + c];          // Lq^T: non-zero iff k >= i
         }
-        *reinterpret_cast<f4*>(As + (rc_k + 8 * e) * F32_SRC + rc_c) = v;
+        *reinterpret_cast<f4*>(As + (rc_k + RC_STRIDE * e) * F32_SRC + rc_c) = v;
       }
     } else {
       const int i = i0 + kc_r;
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) {
+      for (int e = 0; e < EPT; e += 2) {
         float v0, v1;
         if constexpr (A_F64) { v0 = (float)ra64[e]; v1 = (float)ra64[e + 1]; } else { v0 = ra32[e]; v1 = ra32[e + 1]; }
         if (TAG == 1) {                                            // W lower: non-zero iff k <= i
@@ -251,18 +263,18 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
     }
     if constexpr (B_KC) {
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) {
+      for (int e = 0; e < EPT; e += 2) {
         float v0 = rb[e], v1 = rb[e + 1];
         if (scale) { v0 *= rs[e]; v1 *= rs[e + 1]; }
         *reinterpret_cast<float2*>(Bs + kc_r * F32_SKC + kc_k + e) = make_float2(v0, v1);
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
+      for (int e = 0; e < RC_E; e++) {
         f4 v;
 #pragma unroll
         for (int c = 0; c < 4; c++) v[c] = (TAG == 3) ? rb[e * 4 + c] * rs[e * 4 + c] : rb[e * 4 + c];
-        *reinterpret_cast<f4*>(Bs + (rc_k + 8 * e) * F32_SRC + rc_c) = v;
+        *reinterpret_cast<f4*>(Bs + (rc_k + RC_STRIDE * e) * F32_SRC + rc_c) = v;
       }
     }
   };
@@ -288,8 +300,8 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
       const float* As = smem32 + buf * STAGE;
       const float* Bs = As + A_ELEMS;
       bool full = true;
-      if (TAG == 1) full = (kt + F32_BK - 1 <= i0 + 15);
-      if (TAG == 2) full = (kt >= i0 + F32_BT - 16);
+      if (TAG == 1) full = (kt + F32_BK - 1 <= i0 + wrow0 + 15);
+      if (TAG == 2) full = (kt >= i0 + wrow0 + 16 * TM - 16);
       __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int ks = 0; ks < F32_BK / 4; ks++) {
@@ -297,8 +309,8 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
         int a_lo = 0, a_hi = TM;
         if (!full) {
           const int kg = kt + ks * 4;
-          if (TAG == 1) a_lo = max(0, (kg - i0) >> 4);                 // need i0 + 16 a + 15 >= kg
-          if (TAG == 2) a_hi = min(TM, ((kg + 3 - i0) >> 4) + 1);      // need i0 + 16 a <= kg + 3
+          if (TAG == 1) a_lo = max(0, (kg - i0 - wrow0) >> 4);                 // need rowbase + 16 a + 15 >= kg
+          if (TAG == 2) a_hi = min(TM, ((kg + 3 - i0 - wrow0) >> 4) + 1);      // need rowbase + 16 a <= kg + 3
         }
         float af[TM], bf[TN];
 #pragma unroll
@@ -308,7 +320,7 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
         }
 #pragma unroll
         for (int a = 0; a < TM; a++) {
-          const int i = a * 16 + lc;
+          const int i = wrow0 + a * 16 + lc;
           af[a] = A_RC ? As[k * F32_SRC + i] : As[i * F32_SKC + k];
         }
 #pragma unroll
@@ -340,12 +352,13 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
       for (int b = 0; b < TN; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = i0 + a * 16 + kq * 4 + r, j = j0 + ctile[b] * 16 + lc;
+          const int i = i0 + wrow0 + a * 16 + kq * 4 + r, j = j0 + ctile[b] * 16 + lc;
           if (i < p.M && j < p.N) slab[(int64_t)i * p.N + j] = (double)acc[a][b][r];
         }
     if (rowdot) {
-      udot += __shfl_xor(udot, 1, 64);           // the two threads of a row hold its two k-halves
-      if ((tid & 1) == 0 && i0 + kc_r < p.M) go1[(int64_t)ksl * p.M + i0 + kc_r] = udot;
+#pragma unroll
+      for (int o = 1; o < KC_TPR; o <<= 1) udot += __shfl_xor(udot, o, 64);   // the threads of a row hold disjoint k-ranges
+      if ((tid % KC_TPR) == 0 && i0 + kc_r < p.M) go1[(int64_t)ksl * p.M + i0 + kc_r] = udot;
     }
     return;
   }
@@ -357,11 +370,14 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
       for (int b = 0; b < TN; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = i0 + a * 16 + kq * 4 + r, j = j0 + ctile[b] * 16 + lc;
+          const int i = i0 + wrow0 + a * 16 + kq * 4 + r, j = j0 + ctile[b] * 16 + lc;
           if (i < p.M && j < p.N) gC[(int64_t)i * p.ldc + j] = alpha * acc[a][b][r];
         }
   }
   if (f.epi & 6) {
+    float* red_f = smem32;                          // reused as [2 kinds][2 wave rows][128] doubles when W8
+    double* red = reinterpret_cast<double*>(red_f);
+    if (W8) __syncthreads();                        // every wavefront is past its last LDS fragment read
 #pragma unroll
     for (int b = 0; b < TN; b++) {
       double s2 = 0.0, sd = 0.0;
@@ -369,24 +385,44 @@ __global__ void __launch_bounds__(F32_THREADS, 2) gemm_f32_kernel(const GemmProb
       for (int a = 0; a < TM; a++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int i = i0 + a * 16 + kq * 4 + r;
+          const int i = i0 + wrow0 + a * 16 + kq * 4 + r;
           const double v = (double)(alpha * acc[a][b][r]);      // rows >= M hold exact zeros
           s2 = fma(v, v, s2);
           if (f.epi & 4) sd = fma(v, (i < p.M) ? gv0[i] : 0.0, sd);
         }
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
-      const int j = j0 + ctile[b] * 16 + lc;
-      if (kq == 0 && j < p.N) {
-        if (f.epi & 2) go0[(int64_t)tm * p.N + j] = s2;
-        if (f.epi & 4) go1[(int64_t)tm * p.N + j] = sd;
+      const int n = ctile[b] * 16 + lc;
+      if (!W8) {
+        const int j = j0 + n;
+        if (kq == 0 && j < p.N) {
+          if (f.epi & 2) go0[(int64_t)tm * p.N + j] = s2;
+          if (f.epi & 4) go1[(int64_t)tm * p.N + j] = sd;
+        }
+      } else if (kq == 0) {
+        red[(0 * 2 + wr) * F32_BT + n] = s2;
+        red[(1 * 2 + wr) * F32_BT + n] = sd;
+      }
+    }
+    if (W8) {
+      __syncthreads();
+      if (tid < F32_BT) {
+        const int j = j0 + tid;
+        if (j < p.N) {
+          if (f.epi & 2) go0[(int64_t)tm * p.N + j] = red[(0 * 2 + 0) * F32_BT + tid] + red[(0 * 2 + 1) * F32_BT + tid];
+          if (f.epi & 4) go1[(int64_t)tm * p.N + j] = red[(1 * 2 + 0) * F32_BT + tid] + red[(1 * 2 + 1) * F32_BT + tid];
+        }
       }
     }
   }
 }
 
+#ifndef GP_F32_W8_MASK
+#define GP_F32_W8_MASK 15     // bit (role - 1): that role runs with 8 wavefronts per workgroup (same-box A/B, overlap 0: cond_A 3.02 -> 2.53 ms, Lq^T A 2.34 -> 2.24, A D A^T 2.90 -> 2.56, Kuf_bar 4.03 -> 3.60)
+#endif
 template <int TAG>
 static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, Gemm32Flags f) {
+  constexpr bool W8 = ((GP_F32_W8_MASK >> (TAG - 1)) & 1) != 0;
   constexpr int A_ELEMS = (TAG == 2) ? F32_RC_ELEMS : F32_KC_ELEMS;
   constexpr int B_ELEMS = (TAG == 4) ? F32_KC_ELEMS : F32_RC_ELEMS;
   constexpr size_t BYTES = (size_t)2 * (A_ELEMS + B_ELEMS) * sizeof(float);
@@ -397,10 +433,10 @@ static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, 
   static std::atomic<int> attr_dev_mask{0};     // per instantiation; one bit per device (LDS limit is a per-device attribute)
   const int bit = 1 << (h->device & 31);
   if (!(attr_dev_mask.load(std::memory_order_acquire) & bit)) {
-    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f32_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES));
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f32_kernel<TAG, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES));
     attr_dev_mask.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<TAG>), dim3(ntiles, 1, batch), dim3(F32_THREADS), BYTES, h->stream, d_probs, f);
+  hipLaunchKernelGGL((gemm_f32_kernel<TAG, W8>), dim3(ntiles, 1, batch), dim3(W8 ? 512 : 256), BYTES, h->stream, d_probs, f);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
