@@ -151,7 +151,7 @@ static int hy_rows_for(int n1, int n2) { return ((int64_t)n1 * n2 >= (1 << 20)) 
 // partial records one contraction of an M x N problem can leave (any N' <= N: the plan is sized for its largest batch)
 size_t hyper_kuf_records(int N, int M) {
   const size_t generic = ((size_t)(N + HY_THREADS - 1) / HY_THREADS + 1) * ((size_t)(M + HY_ROWS - 1) / HY_ROWS + 1);
-  const size_t mfma = (size_t)(N + 63) / 64 + 1;       // hyper_sm_mfma_kernel: one record per 64 columns
+  const size_t mfma = (size_t)(M + 15) / 16 * 8 + 1;   // hyper_sm_rows_kernel: row tiles x <= 8 column segments
   // small form: only while M * N' < 2^20
   const int64_t nsmall = (M > 0) ? (((int64_t)1 << 20) + M - 1) / M : 0;
   const int64_t ncap = nsmall < N ? nsmall : N;
@@ -322,161 +322,237 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
 // Kuf side of a Mercer spectral-mixture kernel when the covariance values K themselves are still in memory (the
 // forward pass's Kuf strip) and no inducing-input gradient is wanted.  Two identities remove the per-entry cosine
 // sums:   sum_q e_q cos(w_q d) = K / (var phi(r))   (the variance / lengthscale terms become sums of w K ...), and
-//         sum_i c_i (zc_iq fxc_q + zs_iq fxs_q) = fxc_q sum_i c_i zc_iq + fxs_q sum_i c_i zs_iq
-// (the column features leave the row loop).  With c_ij = w_ij var phi(r_ij) and d_ij = c_ij (z_i - x_j), the
-// per-partial sums are then two small GEMMs over the inducing rows,
-//     PE[f][j] = sum_i Zf[i][f] c_ij ,   PD[f][j] = sum_i Zf[i][f] d_ij        (Zf = [cos | sin] row features, 2m wide)
-// followed by a dot with the column features.  The float64 MFMA has the same peak as the float64 VALU, so this is
-// not about flops: it takes the 4 x 2m multiply-adds per entry and — more to the point — the broadcast LDS reads of
-// the row features off the vector pipe (each A fragment is read once per 64 entries).  One workgroup owns 64
-// columns (16 per wave) and walks ALL rows, so it leaves a single partial record.
-#define HYM_ROWS 32        // rows staged in LDS per chunk
-template <int MPAD>
-__global__ void __launch_bounds__(256) hyper_sm_mfma_kernel(DevKern k, const double* __restrict__ x1, int n1,
-                                                            const double* __restrict__ x2, int n2,
-                                                            const double* __restrict__ G, int64_t ldg,
-                                                            const double* __restrict__ alpha,
-                                                            const double* __restrict__ gm,
-                                                            const double* __restrict__ Kuf, int64_t ldk,
-                                                            const double* __restrict__ f1,
-                                                            const double* __restrict__ f2,
-                                                            double* __restrict__ partials, int g32,
-                                                            const HyperItem* __restrict__ items) {
+//         sum_j c_ij (zc_iq fxc_jq + zs_iq fxs_jq) = zc_iq sum_j c_ij fxc_jq + zs_iq sum_j c_ij fxs_jq
+// (the row features leave the frame loop).  With c_ij = w_ij var phi(r_ij) and d_ij = c_ij (z_i - x_j) the per-partial
+// sums are two small GEMMs over the frames,
+//     TE[i][f] = sum_j c_ij F[f][j] ,   TD[i][f] = sum_j d_ij F[f][j]        (F = column features, 2m wide)
+// followed by a dot with the row features Zf[i][f].  The float64 MFMA has the same peak as the float64 VALU, so this
+// is not about flops: it takes the 4 x 2m multiply-adds per entry off the vector pipe.
+// Row-streaming layout: a WAVEFRONT owns 16 rows (lane = row, as the MFMA A operand wants it) and streams along the
+// frames, so
+//  - the row-side quantities (z_i, z_i / l, alpha_i) are per-lane constants: no LDS, no barrier in the loop;
+//  - G and Kuf are read as 64-byte pieces per row (16 bytes per lane, 4 lanes per row);
+//  - A = c or d is computed by the very lane that must supply it, B = the column features;
+//  - the feature index is interleaved (f even: cos of partial f / 2, odd: its sin), so the "partner" feature the
+//    frequency gradient needs (sin <-> cos) is the neighbouring lane: one DPP swap on the final tile.
+// The 16 columns of a block are dealt to the four k-lanes of a row in 16-byte pairs (columns 8 s + 2 kq + u): any
+// consistent assignment of columns to MFMA k-slots gives the same sums, and this one makes every load a 64-byte row
+// piece.  One partial record per (row tile, column segment).
+// (Round 1's form gave a workgroup 64 columns and walked the rows in 32-row chunks restaged through LDS: 2.42 vs 2.34 ms
+// for all contractions of a step run alone, the same step time — the step is bound by the float64 units)
+#define HYR_COLSEG_MIN 1024
+__device__ __forceinline__ double hyr_swap1(double v) {      // value of the neighbouring lane (lane ^ 1)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int NT, bool M52, bool G32>      // feature tiles (16 wide), Matern-5/2 envelope (else Matern-1/2), float32 strips
+__global__ void __launch_bounds__(256, 2) hyper_sm_rows_kernel(DevKern k, const double* __restrict__ x1, int n1,
+                                                               const double* __restrict__ x2, int n2,
+                                                               const double* __restrict__ G, int64_t ldg,
+                                                               const double* __restrict__ alpha,
+                                                               const double* __restrict__ gm,
+                                                               const double* __restrict__ Kuf, int64_t ldk,
+                                                               const double* __restrict__ f1,
+                                                               const double* __restrict__ f2,
+                                                               double* __restrict__ partials, int g32, int col_seg,
+                                                               const HyperItem* __restrict__ items) {
   if (items) {     // one launch for a whole kernel family: blockIdx.y = item (latent GP)
     const HyperItem it = items[blockIdx.y];
     k = it.k; x1 = it.x1; n1 = it.n1; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
     if (it.x2) { x2 = it.x2; n2 = it.n2; }
-    Kuf = it.kvals; ldk = it.ldk; f1 = it.f1; f2 = it.f2; partials = it.partials; g32 = it.g32;
+    Kuf = it.kvals; ldk = it.ldk; f1 = it.f1; f2 = it.f2; partials = it.partials;
   }
-  // address-space-1 views: pointers that came out of an item struct are generic, and FLAT loads would tie every LDS wait
-  // of the row loop to the operand prefetch in flight (the batched launch ran 30 % slower than twelve single ones)
-  const hy_gcptr gG = (hy_gcptr)G, gK = (hy_gcptr)Kuf, gx1 = (hy_gcptr)x1, gx2 = (hy_gcptr)x2, galpha = (hy_gcptr)alpha,
-                 ggm = (hy_gcptr)gm, gf1 = (hy_gcptr)f1, gf2 = (hy_gcptr)f2;
   typedef double d4 __attribute__((ext_vector_type(4)));
-  constexpr int NF = 2 * MPAD;                 // features per row: cos block, then sin block
-  constexpr int NT = (NF + 15) / 16;           // 16-row MFMA tiles of the feature dimension
-  constexpr int FS = NT * 16 + 1;              // LDS row stride (odd: the 4 rows of a k-step hit different banks)
-  __shared__ double zf[HYM_ROWS * FS];         // row features of the current chunk (zero-padded to NT * 16)
-  __shared__ double rowx[HYM_ROWS], rowa[HYM_ROWS], rowal[HYM_ROWS];
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  typedef const d2v __attribute__((address_space(1))) * pd2v;
+  typedef const f2v __attribute__((address_space(1))) * pf2v;
+  const int mpad = ((k.m + 3) / 4) * 4;        // = sm_mpad(m): the feature tables hold 2 mpad rows (cos rows, sin rows)
+  const int NF = 2 * mpad;                     // features: phi = 2 q (cos of partial q), 2 q + 1 (sin); NF <= 16 NT
+  const hy_gcptr gG = (hy_gcptr)G, gK = (hy_gcptr)Kuf, gx1 = (hy_gcptr)x1, gx2 = (hy_gcptr)x2, galpha = (hy_gcptr)alpha,
+                 ggm = (hy_gcptr)gm, gf1 = (hy_gcptr)f1, gf2 = (hy_gcptr)f2, th = (hy_gcptr)k.theta;
   __shared__ double etab[GP_EXP_TAB];
-  __shared__ double red[4][2 + 2 * 32];
+  __shared__ double red[4][2 + 2 * NT * 16];
   gp_exp_tab_init(etab);
-  const hy_gcptr th = (hy_gcptr)k.theta;
+  __syncthreads();
   const double var = th[0], ls = th[1];
   const int m = k.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
-  const int j = (blockIdx.x * 4 + wave) * 16 + lc;       // this lane's column
-  const bool live = (j < n2);
-  const int jc = live ? j : n2 - 1;
-  const double xb = gx2[jc];
-  const double bsc = xb / ls, bb = __dmul_rn(bsc, bsc);
-  const double gmj = live ? ggm[jc] : 0.0;
+  const int i0 = blockIdx.x * 16;
+  if (i0 >= n1) return;                        // (uniform per workgroup: the grid is sized for the largest item)
+  const int row = i0 + lc;
+  const bool rowok = (row < n1);
+  const int rowc = rowok ? row : n1 - 1;
+  const double zi = gx1[rowc], a = zi / ls, aa = __dmul_rn(a, a), m2a = -2.0 * a, al = galpha[rowc];
   const double inv_ls = 1.0 / ls;
-  const bool m12 = (k.type == GP_KERN_MERCER_MATERN12SM);
-  d4 accE[NT], accD[NT];
+  // table row of feature phi = 16 t + lc (B operand side: this lane supplies feature lc of every tile)
+  int frow[NT]; bool fok[NT];
 #pragma unroll
-  for (int t = 0; t < NT; t++) { accE[t] = d4{0.0, 0.0, 0.0, 0.0}; accD[t] = d4{0.0, 0.0, 0.0, 0.0}; }
+  for (int t = 0; t < NT; t++) {
+    const int phi = 16 * t + lc, q = phi >> 1;
+    fok[t] = (phi < NF);
+    frow[t] = fok[t] ? ((phi & 1) ? mpad + q : q) : 0;
+  }
+  d4 TE[NT], TD[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) { TE[t] = d4{0.0, 0.0, 0.0, 0.0}; TD[t] = d4{0.0, 0.0, 0.0, 0.0}; }
   double acc_v = 0.0, acc_l = 0.0;
-  // The global operands of a chunk (this lane's 8 entries of G and Kuf) are fetched one chunk AHEAD: a dependent load
-  // per k-step left every wave waiting out a full HBM round trip eight times per chunk (the kernel ran at the same
-  // speed whether the partial sums were done on the VALU or on the matrix cores: it was latency-bound).
-  constexpr int KS = HYM_ROWS / 4;
-  double gw[KS], kvv[KS], gw_n[KS], kv_n[KS];
-  auto fetch = [&](int r0, double* g, double* kk) {
+  const int cb = blockIdx.z * col_seg, ce = min(n2, cb + col_seg);
+  const int wseg = col_seg / 4;                // per wavefront; a multiple of 32
+  const int cw0 = cb + wave * wseg, cw1 = min(ce, cw0 + wseg);
+  const bool vec_ok = ((n2 & 1) == 0) && ((ldg & 1) == 0) && ((ldk & 1) == 0);
+  // Whole 32-column stretches run from two register buffers in turn, the loads of block b + 1 issued before the
+  // arithmetic of block b (two wavefronts per SIMD do not hide an HBM round trip per 16 columns by themselves), with
+  // 16-byte loads and no column predicates; what is left (ragged ends, odd strides) goes block by block, checked.
+  struct Blk { double g[4], k[4], x[4], gm[4], bf[NT][4]; };
+  const int64_t rowg = (int64_t)rowc * ldg, rowk = (int64_t)rowc * ldk;
+  unsigned foff[NT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      const int i = r0 + ks * 4 + kq;
-      const bool on = live && (i < n1);
-      g[ks] = on ? hy_ldg(gG, (int64_t)i * ldg + j, g32) : 0.0;
-      kk[ks] = on ? hy_ldg(gK, (int64_t)i * ldk + j, g32) : 0.0;
+  for (int t = 0; t < NT; t++) foff[t] = (unsigned)frow[t] * (unsigned)n2;
+  auto load_fast = [&](int jb, Blk& B) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      const int c = jb + 8 * s2 + 2 * kq;      // this lane's pair of columns in sub-block s2
+      if (G32) {
+        const f2v g = *(pf2v)((hy_gcfptr)gG + rowg + c), kk = *(pf2v)((hy_gcfptr)gK + rowk + c);
+        B.g[2 * s2] = g.x; B.g[2 * s2 + 1] = g.y; B.k[2 * s2] = kk.x; B.k[2 * s2 + 1] = kk.y;
+      } else {
+        const d2v g = *(pd2v)(gG + rowg + c), kk = *(pd2v)(gK + rowk + c);
+        B.g[2 * s2] = g.x; B.g[2 * s2 + 1] = g.y; B.k[2 * s2] = kk.x; B.k[2 * s2 + 1] = kk.y;
+      }
+      const d2v xx = *(pd2v)(gx2 + c), gg = *(pd2v)(ggm + c);
+      B.x[2 * s2] = xx.x; B.x[2 * s2 + 1] = xx.y; B.gm[2 * s2] = gg.x; B.gm[2 * s2 + 1] = gg.y;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const d2v b = *(pd2v)(gf2 + (foff[t] + (unsigned)c));
+        B.bf[t][2 * s2] = fok[t] ? b.x : 0.0; B.bf[t][2 * s2 + 1] = fok[t] ? b.y : 0.0;
+      }
     }
   };
-  fetch(0, gw, kvv);
-  for (int r0 = 0; r0 < n1; r0 += HYM_ROWS) {
-    __syncthreads();     // the previous chunk's fragments have been read
-    for (int t = tid; t < HYM_ROWS * NT * 16; t += 256) {
-      const int ii = t / (NT * 16), f = t % (NT * 16);
-      zf[ii * FS + f] = (r0 + ii < n1 && f < NF) ? gf1[(size_t)f * n1 + r0 + ii] : 0.0;
-    }
-    if (tid < HYM_ROWS) {
-      const bool ok = (r0 + tid < n1);
-      const double xv = ok ? gx1[r0 + tid] : 0.0;
-      rowx[tid] = xv; rowa[tid] = xv / ls; rowal[tid] = ok ? galpha[r0 + tid] : 0.0;
-    }
-    fetch(r0 + HYM_ROWS, gw_n, kv_n);      // next chunk (all-false predicates past the last row)
-    __syncthreads();
+  auto load_checked = [&](int jb, Blk& B) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      const int li = ks * 4 + kq;             // row of this lane's B entry inside the chunk
-      const int i = r0 + li;
-      const bool on = live && (i < n1);
-      const double w = on ? fma(rowal[li], gmj, gw[ks]) : 0.0;
-      const double kv = on ? kvv[ks] : 0.0;
-      const double a = rowa[li], aa = __dmul_rn(a, a);
-      const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(a, bsc), aa), bb);
-      double r, rinv;     // r and 1 / r from one rsq (no float64 division in the row loop of the Matern-1/2 profile)
+    for (int e = 0; e < 4; e++) {
+      const int c = jb + 8 * (e >> 1) + 2 * kq + (e & 1);
+      const bool on = (c < cw1);
+      const int cc = on ? c : cw0;
+      B.g[e] = on ? hy_ldg(gG, rowg + cc, G32) : 0.0;
+      B.k[e] = on ? hy_ldg(gK, rowk + cc, G32) : 0.0;
+      B.x[e] = on ? gx2[cc] : 0.0; B.gm[e] = on ? ggm[cc] : 0.0;
+#pragma unroll
+      for (int t = 0; t < NT; t++) B.bf[t][e] = (on && fok[t]) ? gf2[foff[t] + (unsigned)cc] : 0.0;
+    }
+  };
+  auto compute = [&](int jb, const Blk& B, bool checked) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = jb + 8 * (e >> 1) + 2 * kq + (e & 1);
+      const bool on = rowok && (!checked || c < cw1);
+      const double xb = B.x[e];
+      const double w = on ? fma(al, B.gm[e], B.g[e]) : 0.0;
+      const double kv = B.k[e];
+      const double bsc = xb * inv_ls, bb = __dmul_rn(bsc, bsc);
+      const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(m2a, bsc), aa), bb);
+      double r, rinv;
       gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), r, rinv);
       double E, nratio;   // phi(r) and -phi'(r)/phi(r)
-      if (m12) { E = gp_exp_neg(-r, etab); nratio = 1.0; }
+      if (!M52) { E = gp_exp_neg(-r, etab); nratio = 1.0; }
       else {
         const double s5 = 2.23606797749979, poly = 1.0 + s5 * r + (5.0 / 3.0) * r * r;
         E = poly * gp_exp_neg(-s5 * r, etab);
         nratio = (5.0 / 3.0) * r * (1.0 + s5 * r) / poly;
       }
-      const double wvE = w * var * E, wd = wvE * (rowx[li] - xb);
+      const double wvE = w * var * E, wd = wvE * (zi - xb);
       const double wk = w * kv;
       acc_v += wk;
       acc_l = fma(wk * nratio, (r2 * inv_ls) * rinv, acc_l);
-      // A fragment of tile t: A[f = 16 t + lc][k = kq] = zf[row ks*4 + kq][16 t + lc]
 #pragma unroll
       for (int t = 0; t < NT; t++) {
-        const double af = zf[li * FS + t * 16 + lc];
-        accE[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, wvE, accE[t], 0, 0, 0);
-        accD[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, wd, accD[t], 0, 0, 0);
+        TE[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wvE, B.bf[t][e], TE[t], 0, 0, 0);
+        TD[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wd, B.bf[t][e], TD[t], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) { gw[ks] = gw_n[ks]; kvv[ks] = kv_n[ks]; }
+  };
+  int jb = cw0;
+  if (vec_ok && cw1 - cw0 >= 32) {
+    const int cfast = cw0 + ((cw1 - cw0) / 32) * 32;
+    Blk b0, b1;
+    load_fast(cw0, b0);
+    for (; jb < cfast; jb += 32) {
+      load_fast(jb + 16, b1);
+      compute(jb, b0, false);
+      load_fast(min(jb + 32, cfast - 16), b0);      // (the last one re-reads a block and is dropped)
+      compute(jb + 16, b1, false);
+    }
   }
-  // accumulator element r of tile t: feature f = 16 t + kq + 4 r, column j (this lane's).  Dot with the column
-  // features: SE[f] = sum_j f2[f][j] PE[f][j];  SD[f] = sum_j f2[partner(f)][j] PD[f][j], partner = the sin (cos)
-  // feature of the same partial.  Then  d/d e_q ~ SE[q] + SE[MPAD + q],  d/d f_q ~ SD[MPAD + q] - SD[q].
+  for (; jb < cw1; jb += 16) {
+    Blk b;
+    load_checked(jb, b);
+    compute(jb, b, true);
+  }
+  // ---- finish: dot with the row features, reduce over the wavefront's k-lanes, then over the four wavefronts -------
+  // element r of a tile: row kq + 4 r, feature phi = 16 t + lc.  SE[phi] = sum_i Zf[i][phi] TE[i][phi];
+  // SD[phi] = sum_i Zf[i][phi] TD[i][phi ^ 1]  (partner feature = neighbouring lane)
   const int ns = 2 + 2 * m;
   auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
-  for (int t = lane; t < ns; t += 64) red[wave][t] = 0.0;
+  for (int t = lane; t < 2 + 2 * NT * 16; t += 64) red[wave][t] = 0.0;
   const double rv = wred(acc_v / var), rl = wred(acc_l);
-  if (lane == 0) { red[wave][0] = rv; red[wave][1] = rl; }
-  __syncthreads();
 #pragma unroll
   for (int t = 0; t < NT; t++) {
+    double se = 0.0, sd = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int f = 16 * t + kq + 4 * r;
-      double se = 0.0, sd = 0.0;
-      if (f < NF && live) {
-        const int fp = (f < MPAD) ? f + MPAD : f - MPAD;
-        se = gf2[(size_t)f * n2 + jc] * accE[t][r];
-        sd = gf2[(size_t)fp * n2 + jc] * accD[t][r];
-      }
-      // reduce over the 16 columns of this lane group (lanes sharing kq)
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); sd += __shfl_xor(sd, o, 64); }
-      if (lc == 0 && f < NF) {
-        const int q = (f < MPAD) ? f : f - MPAD;
-        if (q < m) {
-          // each (wave, feature) pair is written by exactly one lane group; cos and sin halves land in the same slots
-          atomicAdd(&red[wave][2 + q], se / th[2 + q]);
-          atomicAdd(&red[wave][2 + m + q], -6.283185307179586 * ((f < MPAD) ? -sd : sd));
-        }
-      }
+      const int ri = i0 + kq + 4 * r;
+      const double zf = (ri < n1 && fok[t]) ? gf1[(size_t)frow[t] * n1 + ri] : 0.0;
+      se = fma(zf, TE[t][r], se);
+      sd = fma(zf, hyr_swap1(TD[t][r]), sd);
     }
+    se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+    sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
+    if (kq == 0) { red[wave][2 + 16 * t + lc] = se; red[wave][2 + NT * 16 + 16 * t + lc] = sd; }
   }
+  if (lane == 0) { red[wave][0] = rv; red[wave][1] = rl; }
   __syncthreads();
   if (tid < ns) {
-    const double s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    partials[(int64_t)blockIdx.x * ns + tid] = s;
+    double out;
+    auto tot = [&](int idx) { return (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]); };
+    if (tid < 2) out = tot(tid);
+    else if (tid < 2 + m) {           // d / d e_q ~ (SE[cos_q] + SE[sin_q]) / e_q
+      const int q = tid - 2;
+      out = (tot(2 + 2 * q) + tot(2 + 2 * q + 1)) / th[2 + q];
+    } else {                          // d / d f_q ~ -2 pi (SD[sin_q] - SD[cos_q])
+      const int q = tid - 2 - m;
+      out = -6.283185307179586 * (tot(2 + NT * 16 + 2 * q + 1) - tot(2 + NT * 16 + 2 * q));
+    }
+    partials[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * ns + tid] = out;
   }
+}
+
+#define HYR_DISPATCH_ENV(L, NT_, m52, g32)                                             \
+  do {                                                                                  \
+    if (m52) { if (g32) L(NT_, true, true); else L(NT_, true, false); }                 \
+    else { if (g32) L(NT_, false, true); else L(NT_, false, false); }                   \
+  } while (0)
+#define HYR_DISPATCH(L, nt, m52, g32)                                                   \
+  do {                                                                                  \
+    switch (nt) {                                                                       \
+      case 1: HYR_DISPATCH_ENV(L, 1, m52, g32); break;                                  \
+      case 2: HYR_DISPATCH_ENV(L, 2, m52, g32); break;                                  \
+      case 3: HYR_DISPATCH_ENV(L, 3, m52, g32); break;                                  \
+      default: HYR_DISPATCH_ENV(L, 4, m52, g32); break;                                 \
+    }                                                                                   \
+  } while (0)
+
+// grid of the row-streaming contraction: row tiles x column segments (a multiple of 128 columns each)
+static void hyr_geometry(int n1, int n2, int count, int* col_seg, int* nseg) {
+  const int rows16 = (n1 + 15) / 16;
+  int segs = 1;
+  while (segs < 8 && (int64_t)rows16 * count * segs < 1024 && (n2 + segs * 2 - 1) / (segs * 2) >= HYR_COLSEG_MIN) segs *= 2;
+  int cs = ((n2 + segs - 1) / segs + 127) / 128 * 128;
+  *col_seg = cs;
+  *nseg = (n2 + cs - 1) / cs;
 }
 
 // Broadcast-form kernels Matern12sm (matern12_spectral_mixture.py:38-56) and Matern32sm (kernels.py:204-258):
@@ -642,23 +718,17 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
   const int redw = ns > HY_ROWS ? ns : HY_ROWS;
   size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
   if (sm && kvals && !gz_partials && !symmetric && alpha && gm) {
-    // Kuf side with the covariance strip still in memory: the matrix-core form (hyper_sm_mfma_kernel)
-    dim3 gridm((n2 + 63) / 64);
-#define HY_MFMA(MP) hipLaunchKernelGGL((hyper_sm_mfma_kernel<MP>), gridm, dim3(256), 0, h->stream, k, x1, n1, x2, n2, G, ldg, \
-                                     alpha, gm, kvals, ldk, f1, f2, partials, g32, (const HyperItem*)nullptr)
-    switch (mp) {
-      case 4: HY_MFMA(4); break;
-      case 8: HY_MFMA(8); break;
-      case 12: HY_MFMA(12); break;
-      case 16: HY_MFMA(16); break;
-      case 20: HY_MFMA(20); break;
-      case 24: HY_MFMA(24); break;
-      case 28: HY_MFMA(28); break;
-      default: HY_MFMA(32); break;
-    }
+    // Kuf side with the covariance strip still in memory: the matrix-core form (hyper_sm_rows_kernel)
+    int col_seg = 0, nseg = 0;
+    hyr_geometry(n1, n2, 1, &col_seg, &nseg);
+    dim3 gridm((n1 + 15) / 16, 1, nseg);
+#define HY_MFMA(NT_, M52_, G32_) hipLaunchKernelGGL((hyper_sm_rows_kernel<NT_, M52_, G32_>), gridm, dim3(256), 0, h->stream, k, x1, \
+                                                  n1, x2, n2, G, ldg, alpha, gm, kvals, ldk, f1, f2, partials, g32, col_seg,    \
+                                                  (const HyperItem*)nullptr)
+    HYR_DISPATCH(HY_MFMA, (2 * mp + 15) / 16, k.type != GP_KERN_MERCER_MATERN12SM, g32 != 0);
 #undef HY_MFMA
     GP_HIP_CHECK(h, hipGetLastError());
-    if (nparts) *nparts = gridm.x;
+    if (nparts) *nparts = gridm.x * gridm.z;
     return GP_OK;
   }
 #define HY_ARGS grid, sh, k, x1, n1, x2, n2, G, ldg, alpha, gm, symmetric, f1, f2, partials, gz_partials, wg_rows, g32
@@ -791,29 +861,23 @@ gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items,
 // Many contractions of one kernel family (same type and partial count, same n1 x n2) in one launch: the generic
 // (vector-pipe) kernels with an item array.  *nparts = partial records each item leaves.
 gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
-                                      int with_gz, int* nparts, int use_mfma, const double* x2_shared) {
+                                      int with_gz, int* nparts, int use_mfma, const double* x2_shared, int g32_items) {
   if (count <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_HYPER);
   if (use_mfma && gp_kern_is_mercer(type) && !with_gz) {
-    dim3 gridm((n2 + 63) / 64, count);
+    int col_seg = 0, nseg = 0;
+    hyr_geometry(n1, n2, count, &col_seg, &nseg);
+    dim3 gridm((n1 + 15) / 16, count, nseg);
     DevKern k0{type, m, nullptr};
-#define HYI_MFMA(MP) hipLaunchKernelGGL((hyper_sm_mfma_kernel<MP>), gridm, dim3(256), 0, h->stream, k0, (const double*)nullptr, 0, \
-                                      x2_shared, n2, (const double*)nullptr, (int64_t)0, (const double*)nullptr,                  \
-                                      (const double*)nullptr, (const double*)nullptr, (int64_t)0, (const double*)nullptr,         \
-                                      (const double*)nullptr, (double*)nullptr, 0, d_items)
-    switch (sm_mpad(m)) {
-      case 4: HYI_MFMA(4); break;
-      case 8: HYI_MFMA(8); break;
-      case 12: HYI_MFMA(12); break;
-      case 16: HYI_MFMA(16); break;
-      case 20: HYI_MFMA(20); break;
-      case 24: HYI_MFMA(24); break;
-      case 28: HYI_MFMA(28); break;
-      default: HYI_MFMA(32); break;
-    }
+#define HYI_MFMA(NT_, M52_, G32_) hipLaunchKernelGGL((hyper_sm_rows_kernel<NT_, M52_, G32_>), gridm, dim3(256), 0, h->stream, k0, \
+                                                   (const double*)nullptr, 0, x2_shared, n2, (const double*)nullptr, (int64_t)0, \
+                                                   (const double*)nullptr, (const double*)nullptr, (const double*)nullptr,       \
+                                                   (int64_t)0, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, \
+                                                   0, col_seg, d_items)
+    HYR_DISPATCH(HYI_MFMA, (2 * sm_mpad(m) + 15) / 16, type != GP_KERN_MERCER_MATERN12SM, g32_items != 0);
 #undef HYI_MFMA
     GP_HIP_CHECK(h, hipGetLastError());
-    if (nparts) *nparts = gridm.x;
+    if (nparts) *nparts = gridm.x * gridm.z;
     return GP_OK;
   }
   const int wg_rows = hy_rows_for(n1, n2);
@@ -1169,7 +1233,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       if (!fam.batched) { for (int g : fam.gps) GP_CHECK(kuf_contract(g)); return GP_OK; }
       int np = 0;
       GP_CHECK(launch_hyper_contract_items(h, fam.type, fam.m, (const HyperItem*)(p->d_misc + p->off_hy_items) + fam.first,
-                                           fam.count, fam.M, n, 0, &np, fam.mfma, x));
+                                           fam.count, fam.M, n, 0, &np, fam.mfma, x, f32));
       for (int g : fam.gps) np_uf[g] = np;
       return GP_OK;
     };
