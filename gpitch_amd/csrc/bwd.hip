@@ -1046,6 +1046,12 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
           it.f1 = t.feat;
           it.f2 = t.feat + gp_align_up((size_t)2 * sm_mpad(q.m) * q.M, 32);
         }
+        // its Kuu-side twin (contraction of Kuu_bar = E with dK(z, z)): G entries further on
+        HyperItem& iu = items[G + pos - 1];
+        memset(&iu, 0, sizeof(iu));
+        iu.k = t.kern; iu.x1 = params + q.off_z; iu.n1 = q.M; iu.x2 = iu.x1; iu.n2 = q.M; iu.G = bb.E; iu.ldg = q.M;
+        iu.symmetric = 1; iu.partials = bb.hyp_part_uu;
+        if (gp_kern_is_mercer(q.ktype) && t.feat) { iu.f1 = t.feat; iu.f2 = t.feat; }
       }
     }
   }
@@ -1180,7 +1186,19 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       GP_CHECK(launch_gemm_batched(h, D(S_T3), nK, maxM, maxM, f));
       f = GemmFlags(); f.triB = TRI_LOWER;
       GP_CHECK(launch_gemm_batched(h, D(S_S), nK, maxM, maxM, f));
-      for (int g : p->kgps) {   // contraction of Kuu_bar with dK(z, z)/d(theta, z): partial sums only
+      // contraction of Kuu_bar with dK(z, z)/d(theta, z), partial sums only: one launch per kernel family (24 launches of
+      // a few workgroups each otherwise: 2.6 ms at the end of the helper stream's chain), per GP where a family is mixed
+      for (const auto& fam : p->hy_fams) {
+        if (!fam.batched) continue;
+        int np = 0;
+        GP_CHECK(launch_hyper_contract_items(h, fam.type, fam.m, (const HyperItem*)(p->d_misc + p->off_hy_items) + p->G + fam.first,
+                                             fam.count, fam.M, fam.M, 0, &np));
+        for (int g : fam.gps) np_uu[g] = np;
+      }
+      for (int g : p->kgps) {
+        bool in_batch = false;
+        for (const auto& fam : p->hy_fams) if (fam.batched) for (int gg : fam.gps) if (gg == g) in_batch = true;
+        if (in_batch) continue;
         const PdgpGP& q = p->gps[g];
         const CondTask& t = p->cb.tasks[g];
         const BwdBufs& bb = p->bw[g];
@@ -1238,14 +1256,29 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       return GP_OK;
     };
     int sm_fam = -1, other_fam = -1, sm_slot = -1, other_slot = -1;
-    static const int split_mode = getenv("GP_KUFBAR_SPLIT") ? atoi(getenv("GP_KUFBAR_SPLIT")) : 0;   // A/B switch (profiles/r02)
-    if (split_mode == 1 && p->hy_fams.size() == 2 && forked && p->overlap >= 2) {
+    static const int split_mode = getenv("GP_KUFBAR_SPLIT") ? atoi(getenv("GP_KUFBAR_SPLIT")) : 2;   // 0 / 1: A/B switches
+    if (split_mode >= 1 && p->hy_fams.size() == 2 && forked && p->overlap >= 2) {
       for (int fi = 0; fi < 2; fi++) {
         if (p->hy_fams[fi].mfma) sm_fam = fi; else other_fam = fi;
       }
       if (sm_fam >= 0 && other_fam >= 0) { sm_slot = fam_slot0(p->hy_fams[sm_fam]); other_slot = fam_slot0(p->hy_fams[other_fam]); }
     }
-    if (sm_slot >= 0 && other_slot >= 0) {
+    if (sm_slot >= 0 && other_slot >= 0 && split_mode == 2) {
+      // the stationary family first: its contraction (an HBM read, next to no arithmetic) goes underneath the
+      // spectral-mixture family's product, and the long contraction has the device to itself afterwards
+      const auto& fs = p->hy_fams[sm_fam];
+      const auto& fo = p->hy_fams[other_fam];
+      GP_CHECK(kuf_bar(other_slot, fo.count));
+      const bool side = gp_side_begin(h);
+      if (side) {
+        gp_status st2 = contract_family(fo);
+        gp_status s3 = gp_side_end(h);
+        GP_CHECK(st2); GP_CHECK(s3);
+      }
+      GP_CHECK(kuf_bar(sm_slot, fs.count));
+      if (!side) GP_CHECK(contract_family(fo));
+      GP_CHECK(contract_family(fs));
+    } else if (sm_slot >= 0 && other_slot >= 0) {
       const auto& fs = p->hy_fams[sm_fam];
       const auto& fo = p->hy_fams[other_fam];
       GP_CHECK(kuf_bar(sm_slot, fs.count));

@@ -110,7 +110,7 @@ gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t*
 
 static size_t pdgp_misc_bytes(const gp_pdgp_plan_s* p) {
   return 2 * pdgp_kl_region_bytes(p->G) + 24 * gp_align_up(p->G * sizeof(GemmProblem), 256) +
-         gp_align_up(p->G * hyper_finish_item_bytes(), 256) + gp_align_up(p->G * sizeof(HyperItem), 256);
+         gp_align_up(p->G * hyper_finish_item_bytes(), 256) + gp_align_up(2 * p->G * sizeof(HyperItem), 256);
 }
 
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {

@@ -62,7 +62,8 @@ struct gp_pdgp_plan_s {
   size_t off_kl_items = 0;
   size_t off_bwd[24] = {0};
   size_t off_fin_items = 0; std::vector<char> h_fin_items;   // batched hyper-gradient finish (bwd.hip)
-  // Kuf-side contractions grouped by kernel family: one launch per family over an item array (bwd.hip)
+  // Kuf-side and Kuu-side contractions grouped by kernel family: one launch per family and side over an item array
+  // (bwd.hip; G Kuf-side items, then G Kuu-side items, same order)
   size_t off_hy_items = 0;
   struct HyFamily { int type = 0, m = 0, first = 0, count = 0, M = 0, mfma = 0; bool batched = false; std::vector<int> gps; };
   std::vector<HyFamily> hy_fams;
