@@ -151,7 +151,7 @@ static int hy_rows_for(int n1, int n2) { return ((int64_t)n1 * n2 >= (1 << 20)) 
 // partial records one contraction of an M x N problem can leave (any N' <= N: the plan is sized for its largest batch)
 size_t hyper_kuf_records(int N, int M) {
   const size_t generic = ((size_t)(N + HY_THREADS - 1) / HY_THREADS + 1) * ((size_t)(M + HY_ROWS - 1) / HY_ROWS + 1);
-  const size_t mfma = (size_t)(M + 15) / 16 * 8 + 1;   // hyper_sm_rows_kernel: row tiles x <= 8 column segments
+  const size_t mfma = (size_t)(M + 63) / 64 * 32 + 1;  // hyper_sm_rows_kernel: groups of four row tiles x <= 32 column segments
   // small form: only while M * N' < 2^20
   const int64_t nsmall = (M > 0) ? (((int64_t)1 << 20) + M - 1) / M : 0;
   const int64_t ncap = nsmall < N ? nsmall : N;
@@ -340,7 +340,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
 // piece.  One partial record per (row tile, column segment).
 // (Round 1's form gave a workgroup 64 columns and walked the rows in 32-row chunks restaged through LDS: 2.42 vs 2.34 ms
 // for all contractions of a step run alone, the same step time — the step is bound by the float64 units)
-#define HYR_COLSEG_MIN 1024
+#define HYR_COLSEG_MIN 512
+#define HYR_MAX_SEGS 32
 __device__ __forceinline__ double hyr_swap1(double v) {      // value of the neighbouring lane (lane ^ 1)
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]
@@ -381,8 +382,12 @@ __global__ void __launch_bounds__(256, 2) hyper_sm_rows_kernel(DevKern k, const 
   const int m = k.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
-  const int i0 = blockIdx.x * 16;
-  if (i0 >= n1) return;                        // (uniform per workgroup: the grid is sized for the largest item)
+  // a workgroup = four adjacent row tiles walking the SAME columns: the column features each wavefront streams are in
+  // the L1 / L2 the other three have just filled (one tile per workgroup, columns in quarters: 1.4x the algorithmic HBM
+  // fetch from feature re-reads alone)
+  if (blockIdx.x * 64 >= n1) return;           // (uniform per workgroup: the grid is sized for the largest item)
+  const int i0 = (blockIdx.x * 4 + wave) * 16;
+  const bool tile_on = (i0 < n1);              // a whole wavefront past the last row: no columns, joins the final sum
   const int row = i0 + lc;
   const bool rowok = (row < n1);
   const int rowc = rowok ? row : n1 - 1;
@@ -400,9 +405,7 @@ __global__ void __launch_bounds__(256, 2) hyper_sm_rows_kernel(DevKern k, const 
 #pragma unroll
   for (int t = 0; t < NT; t++) { TE[t] = d4{0.0, 0.0, 0.0, 0.0}; TD[t] = d4{0.0, 0.0, 0.0, 0.0}; }
   double acc_v = 0.0, acc_l = 0.0;
-  const int cb = blockIdx.z * col_seg, ce = min(n2, cb + col_seg);
-  const int wseg = col_seg / 4;                // per wavefront; a multiple of 32
-  const int cw0 = cb + wave * wseg, cw1 = min(ce, cw0 + wseg);
+  const int cw0 = blockIdx.z * col_seg, cw1 = tile_on ? min(n2, cw0 + col_seg) : cw0;
   const bool vec_ok = ((n2 & 1) == 0) && ((ldg & 1) == 0) && ((ldk & 1) == 0);
   // Whole 32-column stretches run from two register buffers in turn, the loads of block b + 1 issued before the
   // arithmetic of block b (two wavefronts per SIMD do not hide an HBM round trip per 16 columns by themselves), with
@@ -547,10 +550,10 @@ __global__ void __launch_bounds__(256, 2) hyper_sm_rows_kernel(DevKern k, const 
 
 // grid of the row-streaming contraction: row tiles x column segments (a multiple of 128 columns each)
 static void hyr_geometry(int n1, int n2, int count, int* col_seg, int* nseg) {
-  const int rows16 = (n1 + 15) / 16;
+  const int rows64 = (n1 + 63) / 64;
   int segs = 1;
-  while (segs < 8 && (int64_t)rows16 * count * segs < 1024 && (n2 + segs * 2 - 1) / (segs * 2) >= HYR_COLSEG_MIN) segs *= 2;
-  int cs = ((n2 + segs - 1) / segs + 127) / 128 * 128;
+  while (segs < HYR_MAX_SEGS && (int64_t)rows64 * count * segs < 1024 && (n2 + segs * 2 - 1) / (segs * 2) >= HYR_COLSEG_MIN) segs *= 2;
+  int cs = ((n2 + segs - 1) / segs + 31) / 32 * 32;
   *col_seg = cs;
   *nseg = (n2 + cs - 1) / cs;
 }
@@ -721,7 +724,7 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     // Kuf side with the covariance strip still in memory: the matrix-core form (hyper_sm_rows_kernel)
     int col_seg = 0, nseg = 0;
     hyr_geometry(n1, n2, 1, &col_seg, &nseg);
-    dim3 gridm((n1 + 15) / 16, 1, nseg);
+    dim3 gridm((n1 + 63) / 64, 1, nseg);
 #define HY_MFMA(NT_, M52_, G32_) hipLaunchKernelGGL((hyper_sm_rows_kernel<NT_, M52_, G32_>), gridm, dim3(256), 0, h->stream, k, x1, \
                                                   n1, x2, n2, G, ldg, alpha, gm, kvals, ldk, f1, f2, partials, g32, col_seg,    \
                                                   (const HyperItem*)nullptr)
@@ -867,7 +870,7 @@ gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperI
   if (use_mfma && gp_kern_is_mercer(type) && !with_gz) {
     int col_seg = 0, nseg = 0;
     hyr_geometry(n1, n2, count, &col_seg, &nseg);
-    dim3 gridm((n1 + 15) / 16, count, nseg);
+    dim3 gridm((n1 + 63) / 64, count, nseg);
     DevKern k0{type, m, nullptr};
 #define HYI_MFMA(NT_, M52_, G32_) hipLaunchKernelGGL((hyper_sm_rows_kernel<NT_, M52_, G32_>), gridm, dim3(256), 0, h->stream, k0, \
                                                    (const double*)nullptr, 0, x2_shared, n2, (const double*)nullptr, (int64_t)0, \
