@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_exchange_doubles", "gp_sgpr_bound_begin", "gp_sgpr_bound_end", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
     "gp_sgprb_create", "gp_sgprb_destroy", "gp_sgprb_num_params", "gp_sgprb_num_windows", "gp_sgprb_workspace_bytes",
     "gp_sgprb_set_workspace", "gp_sgprb_bound_grad", "gp_sgprb_set_graphs", "gp_sgprb_eval_counts",
+    "gp_sgprb_predict_f", "gp_sgprb_predict_source_workspace_bytes", "gp_sgprb_predict_source",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
 ]
 
@@ -165,6 +166,9 @@ def load_library():
         "gp_sgprb_bound_grad": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
         "gp_sgprb_set_graphs": (i32, [vp, i32]),
         "gp_sgprb_eval_counts": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+        "gp_sgprb_predict_f": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+        "gp_sgprb_predict_source_workspace_bytes": (sz, [vp, i32, i32]),
+        "gp_sgprb_predict_source": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, sz]),
         "gp_timers_enable": (i32, [vp, i32]),
         "gp_timers_reset": (i32, [vp]),
         "gp_timers_read": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(i64)]),

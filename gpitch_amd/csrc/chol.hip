@@ -558,67 +558,113 @@ gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, doub
 //   W = L^-1 by block rows:  W[i, :i] = -W_ii (L[i, :i] W[:i, :i])      (2 GEMMs per block row)
 // A is overwritten by L (lower triangle; the strict upper triangle is NOT cleared), W gets zeros above the diagonal.
 #define CHL_NB 128
-size_t cholesky_large_workspace_bytes(int N) {
+// `count` matrices of the same size go through the SAME launch sequence (every launch batched over the matrices):
+// the N = 2001 factorisation is ~80 dependent launches of small grids, so W windows cost little more than one.
+size_t cholesky_large_batched_workspace_bytes(int N, int count) {
   const int nblk = (N + CHL_NB - 1) / CHL_NB;
   const size_t ldT = (size_t)((N + 1) & ~1);
-  return gp_align_up((size_t)4 * nblk * sizeof(GemmProblem), 256) + gp_align_up((size_t)CHL_NB * ldT * sizeof(double), 256) + 512;
+  const size_t c = (size_t)(count < 1 ? 1 : count);
+  return gp_align_up((size_t)4 * nblk * c * sizeof(GemmProblem), 256) + gp_align_up((size_t)2 * nblk * c * sizeof(double*), 256) +
+         gp_align_up((size_t)(nblk + 1) * c * sizeof(int), 256) + c * gp_align_up((size_t)CHL_NB * ldT * sizeof(double), 256) + 512;
+}
+size_t cholesky_large_workspace_bytes(int N) { return cholesky_large_batched_workspace_bytes(N, 1); }
+
+// C (rows x cols, ldc) -> the strided destination of the same problem's A operand: panel write-back after P = A W_kk^T
+__global__ void __launch_bounds__(256) chl_panel_copy_kernel(const GemmProblem* __restrict__ probs) {
+  const GemmProblem p = probs[blockIdx.y];
+  const int64_t total = (int64_t)p.M * p.N;
+  double* dst = const_cast<double*>(p.A);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t i = idx / p.N, j = idx - i * p.N;
+    dst[i * p.lda + j] = p.C[i * p.ldc + j];
+  }
+}
+__global__ void __launch_bounds__(256) chl_zero_kernel(double* const* __restrict__ mats, int64_t n) {
+  double* m = mats[blockIdx.y];
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) m[idx] = 0.0;
 }
 
-gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_t ld, void* ws, size_t ws_bytes) {
-  if (N <= 0) return GP_OK;
+gp_status launch_cholesky_large_batched(gp_handle h, double* const* A, double* const* W, int count, int N, int64_t ld,
+                                        void* ws, size_t ws_bytes) {
+  if (N <= 0 || count <= 0) return GP_OK;
   if ((ld & 1) || ld < N) return gp_fail(h, GP_ERR_BAD_ARG, "launch_cholesky_large: ld must be even and >= N");
   GpArena ar(ws, ws_bytes);
   const int nblk = (N + CHL_NB - 1) / CHL_NB;
-  GemmProblem* d_probs = ar.take<GemmProblem>((size_t)4 * nblk);
+  const size_t C = (size_t)count;
+  GemmProblem* d_probs = ar.take<GemmProblem>((size_t)4 * nblk * C);      // [step][kind][matrix]
+  double** d_ptrs = ar.take<double*>((size_t)2 * nblk * C);               // [step][L_kk | W_kk][matrix]
+  int* d_ints = ar.take<int>((size_t)(nblk + 1) * C);                     // [step][matrix] block sizes, then the ld's
   const int64_t ldT = (N + 1) & ~1;
-  double* T = ar.take<double>((size_t)CHL_NB * ldT);     // panel (N x 128, ld 128) or block row (128 x N, ld ldT)
+  const size_t t_stride = gp_align_up((size_t)CHL_NB * ldT * sizeof(double), 256) / sizeof(double);
+  double* T0 = ar.take<double>(t_stride * C);     // per matrix: panel (N x 128, ld 128) or block row (128 x N, ld ldT)
   if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, "launch_cholesky_large: workspace too small");
-  std::vector<GemmProblem> hp((size_t)4 * nblk);
+  std::vector<GemmProblem> hp((size_t)4 * nblk * C);
+  std::vector<double*> hptr((size_t)2 * nblk * C);
+  std::vector<int> hint((size_t)(nblk + 1) * C);
   memset(hp.data(), 0, hp.size() * sizeof(GemmProblem));
   for (int k = 0; k < nblk; k++) {
     const int c0 = k * CHL_NB, nb = (N - c0 < CHL_NB) ? N - c0 : CHL_NB, r0 = c0 + nb, mrem = N - r0;
-    double* Akk = A + (int64_t)c0 * ld + c0;
-    double* Wkk = W + (int64_t)c0 * ld + c0;
-    { GemmProblem& r = hp[4 * k + 0];   // P = A[r0:, c0:c0+nb] W_kk^T
-      r.A = A + (int64_t)r0 * ld + c0; r.lda = ld; r.B = Wkk; r.ldb = ld; r.C = T; r.ldc = CHL_NB; r.M = mrem; r.N = nb; r.K = nb; }
-    { GemmProblem& r = hp[4 * k + 1];   // A[r0:, r0:] -= P P^T
-      r.A = T; r.lda = CHL_NB; r.B = T; r.ldb = CHL_NB; r.C = A + (int64_t)r0 * ld + r0; r.ldc = ld; r.M = mrem; r.N = mrem; r.K = nb; }
-    { GemmProblem& r = hp[4 * k + 2];   // T = L[c0:c0+nb, :c0] W[:c0, :c0]
-      r.A = A + (int64_t)c0 * ld; r.lda = ld; r.B = W; r.ldb = ld; r.C = T; r.ldc = ldT; r.M = nb; r.N = c0; r.K = c0; }
-    { GemmProblem& r = hp[4 * k + 3];   // W[c0:c0+nb, :c0] = -W_kk T
-      r.A = Wkk; r.lda = ld; r.B = T; r.ldb = ldT; r.C = W + (int64_t)c0 * ld; r.ldc = ld; r.M = nb; r.N = c0; r.K = nb; }
-    (void)Akk;
+    for (size_t w = 0; w < C; w++) {
+      double* Aw = A[w]; double* Ww = W[w]; double* T = T0 + w * t_stride;
+      double* Wkk = Ww + (int64_t)c0 * ld + c0;
+      hptr[((size_t)2 * k + 0) * C + w] = Aw + (int64_t)c0 * ld + c0;
+      hptr[((size_t)2 * k + 1) * C + w] = Wkk;
+      hint[(size_t)k * C + w] = nb;
+      { GemmProblem& r = hp[((size_t)4 * k + 0) * C + w];   // P = A[r0:, c0:c0+nb] W_kk^T
+        r.A = Aw + (int64_t)r0 * ld + c0; r.lda = ld; r.B = Wkk; r.ldb = ld; r.C = T; r.ldc = CHL_NB; r.M = mrem; r.N = nb; r.K = nb; }
+      { GemmProblem& r = hp[((size_t)4 * k + 1) * C + w];   // A[r0:, r0:] -= P P^T
+        r.A = T; r.lda = CHL_NB; r.B = T; r.ldb = CHL_NB; r.C = Aw + (int64_t)r0 * ld + r0; r.ldc = ld; r.M = mrem; r.N = mrem; r.K = nb; }
+      { GemmProblem& r = hp[((size_t)4 * k + 2) * C + w];   // T = L[c0:c0+nb, :c0] W[:c0, :c0]
+        r.A = Aw + (int64_t)c0 * ld; r.lda = ld; r.B = Ww; r.ldb = ld; r.C = T; r.ldc = ldT; r.M = nb; r.N = c0; r.K = c0; }
+      { GemmProblem& r = hp[((size_t)4 * k + 3) * C + w];   // W[c0:c0+nb, :c0] = -W_kk T
+        r.A = Wkk; r.lda = ld; r.B = T; r.ldb = ldT; r.C = Ww + (int64_t)c0 * ld; r.ldc = ld; r.M = nb; r.N = c0; r.K = nb; }
+    }
   }
+  for (size_t w = 0; w < C; w++) hint[(size_t)nblk * C + w] = (int)ld;
   GP_HIP_CHECK(h, hipMemcpyAsync(d_probs, hp.data(), hp.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, h->stream));
-  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // hp is a stack object
-  GP_HIP_CHECK(h, hipMemsetAsync(W, 0, (size_t)N * ld * sizeof(double), h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(d_ptrs, hptr.data(), hptr.size() * sizeof(double*), hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(d_ints, hint.data(), hint.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the staging vectors are stack objects
+  // the W matrices start as zeros (their upper blocks are never written): step 0's W_kk pointers are their bases
+  hipLaunchKernelGGL(chl_zero_kernel, dim3(512, count), dim3(256), 0, h->stream, (double* const*)(d_ptrs + C), (int64_t)N * ld);
+  GP_HIP_CHECK(h, hipGetLastError());
+  const int* d_ld = d_ints + (size_t)nblk * C;
   for (int k = 0; k < nblk; k++) {
     const int c0 = k * CHL_NB, nb = (N - c0 < CHL_NB) ? N - c0 : CHL_NB, r0 = c0 + nb, mrem = N - r0;
-    double* Akk = A + (int64_t)c0 * ld + c0;
-    double* Wkk = W + (int64_t)c0 * ld + c0;
-    GP_CHECK(launch_cholesky_single(h, Akk, nb, ld, c0));
-    GP_CHECK(launch_tri_inverse_single(h, Akk, Wkk, nb, ld));
+    double* const* dL = d_ptrs + ((size_t)2 * k + 0) * C;
+    double* const* dW = d_ptrs + ((size_t)2 * k + 1) * C;
+    const int* dM = d_ints + (size_t)k * C;
+    GP_CHECK(launch_cholesky_batched(h, dL, dM, d_ld, count, nb, c0));
+    GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)dL, dW, dM, d_ld, count));
     if (mrem > 0) {
       GemmFlags f;
       f.transB = 1; f.triB = TRI_UPPER;
-      GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 0, 1, mrem, nb, f));
-      GP_HIP_CHECK(h, hipMemcpy2DAsync(A + (int64_t)r0 * ld + c0, (size_t)ld * sizeof(double), T, CHL_NB * sizeof(double),
-                                       (size_t)nb * sizeof(double), (size_t)mrem, hipMemcpyDeviceToDevice, h->stream));
+      GP_CHECK(launch_gemm_batched(h, d_probs + ((size_t)4 * k + 0) * C, count, mrem, nb, f));
+      int blocks = (int)(((int64_t)mrem * nb + 255) / 256);
+      if (blocks > 256) blocks = 256;
+      hipLaunchKernelGGL(chl_panel_copy_kernel, dim3(blocks, count), dim3(256), 0, h->stream, d_probs + ((size_t)4 * k + 0) * C);
+      GP_HIP_CHECK(h, hipGetLastError());
       f = GemmFlags();
       f.transB = 1; f.triC = TRI_LOWER; f.alpha = -1.0; f.beta = 1.0;
-      GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 1, 1, mrem, mrem, f));
+      GP_CHECK(launch_gemm_batched(h, d_probs + ((size_t)4 * k + 1) * C, count, mrem, mrem, f));
     }
   }
   for (int k = 1; k < nblk; k++) {
     const int c0 = k * CHL_NB, nb = (N - c0 < CHL_NB) ? N - c0 : CHL_NB;
     GemmFlags f;
     f.triB = TRI_LOWER;
-    GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 2, 1, nb, c0, f));
+    GP_CHECK(launch_gemm_batched(h, d_probs + ((size_t)4 * k + 2) * C, count, nb, c0, f));
     f = GemmFlags();
     f.triA = TRI_LOWER; f.alpha = -1.0;
-    GP_CHECK(launch_gemm_batched(h, d_probs + 4 * k + 3, 1, nb, c0, f));
+    GP_CHECK(launch_gemm_batched(h, d_probs + ((size_t)4 * k + 3) * C, count, nb, c0, f));
   }
   return GP_OK;
+}
+
+gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_t ld, void* ws, size_t ws_bytes) {
+  double* a[1] = {A};
+  double* w[1] = {W};
+  return launch_cholesky_large_batched(h, a, w, 1, N, ld, ws, ws_bytes);
 }
 
 // after a panel-blocked factorisation: clear the blocks strictly above the block diagonal (the one-workgroup kernel

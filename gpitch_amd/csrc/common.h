@@ -195,6 +195,10 @@ gp_status launch_cholesky_batched(gp_handle h, double* const* d_mats, const int*
 gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld, int pivot_base = 0);
 // one large matrix, blocked over the GEMM kernels: A -> L in place (lower), W = L^-1 (upper part zero); ld even
 size_t cholesky_large_workspace_bytes(int N);
+size_t cholesky_large_batched_workspace_bytes(int N, int count);
+// host arrays of `count` device pointers: every launch of the blocked factorisation + inverse runs over all matrices
+gp_status launch_cholesky_large_batched(gp_handle h, double* const* A, double* const* W, int count, int N, int64_t ld,
+                                        void* ws, size_t ws_bytes);
 gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_t ld, void* ws, size_t ws_bytes);
 gp_status launch_tri_inverse_single(gp_handle h, const double* L, double* Linv, int M, int64_t ld);
 // Cholesky factor (in place) and its inverse in one launch, one resident workgroup per matrix

@@ -45,6 +45,7 @@ struct gp_sgprb_plan_s {
   bool desc_valid = false;
   hipGraphExec_t gexec = nullptr; int graphs = 1; int64_t n_eager = 0, n_captured = 0, n_replayed = 0; int graph_count = -1;
   int np_uf = 0, np_uu = 0;
+  char* d_pred_desc = nullptr; size_t pred_desc_bytes = 0;    // descriptors of gp_sgprb_predict_f (uploaded per call)
   ~gp_sgprb_plan_s() { if (gexec) (void)hipGraphExecDestroy(gexec); }
 };
 typedef gp_sgprb_plan_s* gp_sgprb_plan_t;
@@ -198,6 +199,8 @@ static void sgb_layout(gp_sgprb_plan_s* p) {
   p->win_doubles = d;
 }
 
+struct SgbPredWin;
+static size_t sgb_pred_desc_bytes(const gp_sgprb_plan_s* p);
 static size_t sgb_desc_bytes(const gp_sgprb_plan_s* p) {
   const size_t W = p->W, P = p->P;
   size_t b = 0;
@@ -250,7 +253,7 @@ int32_t gp_sgprb_num_windows(gp_sgprb_plan_t p) { return p ? p->W : 0; }
 size_t gp_sgprb_workspace_bytes(gp_sgprb_plan_t p) {
   if (!p) return 0;
   return (size_t)p->W * p->win_doubles * sizeof(double) + gp_align_up((size_t)p->N * sizeof(double), 256) + 3 * 1024 +
-         sgb_desc_bytes(p) + 8192;
+         sgb_desc_bytes(p) + sgb_pred_desc_bytes(p) + 8192;
 }
 
 gp_status gp_sgprb_set_workspace(gp_sgprb_plan_t p, void* workspace, size_t bytes) {
@@ -262,6 +265,8 @@ gp_status gp_sgprb_set_workspace(gp_sgprb_plan_t p, void* workspace, size_t byte
   GpArena ar(workspace, bytes);
   p->desc_bytes = sgb_desc_bytes(p);
   p->d_desc = ar.take<char>(p->desc_bytes);
+  p->pred_desc_bytes = sgb_pred_desc_bytes(p);
+  p->d_pred_desc = ar.take<char>(p->pred_desc_bytes);
   p->ones = ar.take<double>(p->N);
   p->d_toff = ar.take<int>(256); p->d_ktype = ar.take<int>(256); p->d_km = ar.take<int>(256);
   p->wsd = ar.take<double>((size_t)p->W * p->win_doubles);
@@ -535,6 +540,275 @@ gp_status gp_sgprb_bound_grad(gp_sgprb_plan_t p, const double* params, const dou
   GP_CHECK(sgb_enqueue(p, count, bound_dev, grad != nullptr));
   p->n_eager++;
   return GP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Predictions of W fitted windows in one launch sequence — the rest of the loop body of SoSp.optimize
+// (gpitch/separation.py:300-313: model.predict_f(X_i), model.predict_s(X_i) after every window's optimisation).
+//   predict_f : GPflow 0.5 SGPR.build_predict (full_cov = False) from the window's collapsed-bound state
+//               (W = chol(Kuu)^-1, WB = chol(B)^-1, c): tmp1 = W Kus, tmp2 = WB tmp1, mean = tmp2^T c,
+//               var = Kdiag_sum + sum tmp2^2 - sum tmp1^2
+//   predict_s : the EXACT GP of sgpr_ss.py:73-106 on the window's N frames: L = chol(K_sum(X) + s2 I) (N x N, N = 2001 per
+//               window), V = L^-1 y, per source A = L^-1 K_p(X, Xnew), mean_p = A^T V, var_p = Kdiag_sum - sum A^2.
+// Same kernels and operation order per window as gp_sgpr_predict_f / gp_sgpr_predict_source (sgpr.hip); what changes is
+// that every launch carries all windows: one window's predict_s is ~100 dependent launches of small grids (7 ms, nearly
+// all latency), W windows cost the arithmetic.
+struct SgbPredWin {
+  const double* params; double* L; int64_t ldL; double* scal;
+  const double* dot; const double* s1; const double* s2; const double* kd;
+  double* mean; double* var;
+};
+
+// L[i][i] += noise variance; scal[0] = Kdiag of the SUM kernel (sgpr_ss.py:101)
+__global__ void __launch_bounds__(256) sgb_pred_prep_kernel(const SgbPredWin* __restrict__ wins, int N, int P,
+                                                            const int* __restrict__ toff, const int* __restrict__ ktype,
+                                                            const int* __restrict__ km) {
+  const SgbPredWin w = wins[blockIdx.x];
+  const double s2 = w.params[0];
+  for (int i = threadIdx.x; i < N; i += 256) w.L[(int64_t)i * w.ldL + i] += s2;
+  if (threadIdx.x == 0) {
+    double kd = 0.0;
+    for (int p = 0; p < P; p++) {
+      const double* th = w.params + toff[p];
+      double v = th[0];
+      if (gp_kern_kdiag_energy(ktype[p])) {
+        double s = 0.0;
+        for (int q = 0; q < km[p]; q++) s += th[2 + q];
+        v *= s;
+      }
+      kd += v;
+    }
+    w.scal[0] = kd;
+  }
+}
+
+// mean[j] = sum_rb dot[rb][j];  var[j] = kd + sum_rb s2[rb][j] - sum_rb s1[rb][j]  (s2 null: kd - sum s1); grid (n / 256, window)
+__global__ void __launch_bounds__(256) sgb_pred_finish_kernel(const SgbPredWin* __restrict__ wins, int rb, int n,
+                                                              int64_t out_off) {
+  const SgbPredWin w = wins[blockIdx.y];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  double d = 0.0, a = 0.0, b = 0.0;
+  for (int r = 0; r < rb; r++) {
+    d += w.dot[(int64_t)r * n + j];
+    a += w.s1[(int64_t)r * n + j];
+    if (w.s2) b += w.s2[(int64_t)r * n + j];
+  }
+  w.mean[out_off + j] = d;
+  w.var[out_off + j] = w.s2 ? (w.kd[0] + b) - a : w.kd[0] - a;
+}
+
+static inline int64_t sgb_ld64(int n) { return (n + 1) & ~1; }
+static size_t sgb_pred_desc_bytes(const gp_sgprb_plan_s* p) {
+  const size_t W = p->W, P = p->P;
+  return gp_align_up(W * P * sizeof(FeatItem), 256) + gp_align_up(W * P * sizeof(CovItem), 256) +
+         2 * gp_align_up(W * sizeof(GemmProblem), 256) + gp_align_up(W * sizeof(SgbPredWin), 256);
+}
+
+extern "C" {
+
+// mean, var: [count][n].  Xnew: [count][n], n <= N.  Runs the forward pass of the bound at `params` first (same descriptors
+// and recorded launch sequence as gp_sgprb_bound_grad), then the prediction launches.
+gp_status gp_sgprb_predict_f(gp_sgprb_plan_t p, const double* params, const double* X, const double* Y, const double* Z,
+                             const double* Xnew, int32_t n, int32_t count, double* mean, double* var) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgprb_predict_f: workspace not set");
+  if (!params || !X || !Y || !Z || !Xnew || !mean || !var || count < 1 || count > p->W || n < 1 || n > p->N)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgprb_predict_f: bad argument (1 <= n <= N, 1 <= count <= num_windows)");
+  const int W = count, P = p->P, M = p->M, N = p->N;
+  const int64_t ld = sgb_ld(N);            // the strips of the plan keep their leading dimension
+  const int rb = p->rb;
+  // forward state of every window: W, WB, c, scal[3] = Kdiag_sum.  (The bound values nobody asked for land in the first
+  // window's G strip, which a forward-only evaluation leaves free and which the prediction overwrites afterwards.)
+  GP_CHECK(gp_sgprb_bound_grad(p, params, X, Y, Z, count, p->wsd + p->o_G, nullptr));
+  // descriptors of the prediction launches (host-built, uploaded per call: predictions are not in the training loop)
+  const size_t nfeat = (size_t)W * P, ncov = (size_t)W * P;
+  const size_t bytes = gp_align_up(nfeat * sizeof(FeatItem), 256) + gp_align_up(ncov * sizeof(CovItem), 256) +
+                       2 * gp_align_up((size_t)W * sizeof(GemmProblem), 256) + gp_align_up((size_t)W * sizeof(SgbPredWin), 256);
+  std::vector<char> hd(bytes, 0);
+  size_t off = 0;
+  auto region = [&](size_t b) { size_t o = off; off += gp_align_up(b, 256); return o; };
+  const size_t o_feat = region(nfeat * sizeof(FeatItem)), o_cov = region(ncov * sizeof(CovItem));
+  const size_t o_p1 = region((size_t)W * sizeof(GemmProblem)), o_p2 = region((size_t)W * sizeof(GemmProblem));
+  const size_t o_win = region((size_t)W * sizeof(SgbPredWin));
+  FeatItem* feat = (FeatItem*)(hd.data() + o_feat);
+  CovItem* cov = (CovItem*)(hd.data() + o_cov);
+  GemmProblem* p1 = (GemmProblem*)(hd.data() + o_p1);
+  GemmProblem* p2 = (GemmProblem*)(hd.data() + o_p2);
+  SgbPredWin* wins = (SgbPredWin*)(hd.data() + o_win);
+  for (int w = 0; w < W; w++) {
+    double* b = p->wsd + (size_t)w * p->win_doubles;
+    const double* par = params + (size_t)w * p->nparams;
+    const double* Zw = Z + (size_t)w * M;
+    const double* Xn = Xnew + (size_t)w * n;
+    double *Wm = b + p->o_W, *WB = b + p->o_WB, *Kus = b + p->o_Kuf, *A = b + p->o_A, *c = b + p->o_c;
+    double* s1 = b + p->o_s1;                         // [rb][n]
+    double* s2 = b + p->o_G;                          // [rb][n]   (G: M x ld doubles, free here)
+    double* dot = s2 + (size_t)rb * N;
+    for (int i = 0; i < P; i++) {
+      DevKern k{p->ktype[i], p->m[i], par + p->off_theta[i]};
+      double* ft = b + p->o_feat + (size_t)i * p->feat_stride;     // [Z features | frame features]: the frame half is rebuilt for Xnew
+      const int mp = sm_mpad(k.m);
+      const size_t idx = (size_t)i * W + w;
+      feat[idx] = FeatItem{k, Xn, ft + gp_align_up((size_t)2 * mp * M, 32), n, 0};
+      cov_item_fill(&cov[idx], k, Zw, M, Xn, n, Kus, ld, i > 0, 0.0, ft);
+    }
+    { GemmProblem& r = p1[w]; memset(&r, 0, sizeof(r));
+      r.A = Wm; r.lda = M; r.B = Kus; r.ldb = ld; r.C = A; r.ldc = ld; r.M = M; r.N = n; r.K = M; r.o0 = s1; }
+    { GemmProblem& r = p2[w]; memset(&r, 0, sizeof(r));
+      r.A = WB; r.lda = M; r.B = A; r.ldb = ld; r.M = M; r.N = n; r.K = M; r.v0 = c; r.o0 = s2; r.o1 = dot; }
+    SgbPredWin& sw = wins[w];
+    memset(&sw, 0, sizeof(sw));
+    sw.params = par; sw.dot = dot; sw.s1 = s1; sw.s2 = s2; sw.kd = b + p->o_scal + 3;
+    sw.mean = mean + (size_t)w * n; sw.var = var + (size_t)w * n;
+  }
+  if (bytes > p->pred_desc_bytes) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgprb_predict_f: descriptor block too small");
+  char* dd = p->d_pred_desc;
+  GP_HIP_CHECK(h, hipMemcpyAsync(dd, hd.data(), bytes, hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));       // hd is a stack object
+  const FeatItem* dfeat = (const FeatItem*)(dd + o_feat);
+  const CovItem* dcov = (const CovItem*)(dd + o_cov);
+  for (int i = 0; i < P; i++) {
+    if (gp_kern_is_mercer(p->ktype[i]))
+      GP_CHECK(launch_sm_features_items(h, dfeat + (size_t)i * W, W, n, sm_mpad(p->m[i]), nullptr, 0));
+    GP_CHECK(launch_kernel_build_items(h, p->ktype[i], p->m[i], dcov + (size_t)i * W, W, M, n, nullptr, 0));
+  }
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0; f.timer = GP_TIMER_COND_A;
+    f.epilogue = EPI_STORE | EPI_COLSUMSQ;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(dd + o_p1), W, M, n, f)); }
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0; f.timer = GP_TIMER_COND_A;
+    f.epilogue = EPI_COLSUMSQ | EPI_COLDOT;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(dd + o_p2), W, M, n, f)); }
+  hipLaunchKernelGGL(sgb_pred_finish_kernel, dim3((n + 255) / 256, W), dim3(256), 0, h->stream,
+                     (const SgbPredWin*)(dd + o_win), rb, n, (int64_t)0);
+  GP_HIP_CHECK(h, hipGetLastError());
+  // (the frame halves of the feature tables and the Kuf strips now hold Xnew's: every evaluation rebuilds them first)
+  return check_not_pd(h);
+}
+
+size_t gp_sgprb_predict_source_workspace_bytes(gp_sgprb_plan_t p, int32_t count, int32_t n) {
+  if (!p || count < 1 || n < 1) return 256;
+  const int N = p->N;
+  const size_t ldL = sgb_ld64(N), ld = sgb_ld64(n);
+  const int rb = gemm_rowblocks(N, 1);
+  size_t d = 0;
+  auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
+  add((size_t)N * ldL); add((size_t)N * ldL);     // K -> L, W = L^-1
+  add((size_t)N * ld);                            // K_p(X, Xnew)
+  add(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, N, n > N ? n : N));
+  add((size_t)rb * n); add((size_t)rb * n); add(N); add(64);
+  const size_t C = (size_t)count, P = p->P;
+  size_t desc = 2 * gp_align_up(C * P * sizeof(FeatItem), 256) + 2 * gp_align_up(C * P * sizeof(CovItem), 256) +
+                2 * gp_align_up(C * sizeof(GemmProblem), 256) + gp_align_up(C * sizeof(SgbPredWin), 256) +
+                2 * gp_align_up(C * sizeof(double*), 256) + 2 * gp_align_up(C * sizeof(int), 256);
+  return C * d * sizeof(double) + desc + cholesky_large_batched_workspace_bytes(N, count) + 8192;
+}
+
+// mean, var: [count][P][n] (window-major, then source).  Xnew: [count][n].
+gp_status gp_sgprb_predict_source(gp_sgprb_plan_t p, const double* params, const double* X, const double* Y,
+                                  const double* Xnew, int32_t n, int32_t count, double* mean, double* var, void* workspace,
+                                  size_t workspace_bytes) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgprb_predict_source: plan workspace not set");
+  if (!params || !X || !Y || !Xnew || !mean || !var || count < 1 || n < 1)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgprb_predict_source: bad argument");
+  if (!workspace || workspace_bytes < gp_sgprb_predict_source_workspace_bytes(p, count, n) || (((uintptr_t)workspace) & 255))
+    return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgprb_predict_source: workspace too small or not 256-byte aligned");
+  const int W = count, P = p->P, N = p->N;
+  const int64_t ldL = sgb_ld64(N), ld = sgb_ld64(n);
+  const int rb = gemm_rowblocks(N, 1);
+  GpArena ar(workspace, workspace_bytes);
+  const size_t C = (size_t)W;
+  // descriptor block
+  const size_t b_feat = gp_align_up(C * P * sizeof(FeatItem), 256), b_cov = gp_align_up(C * P * sizeof(CovItem), 256),
+               b_prob = gp_align_up(C * sizeof(GemmProblem), 256), b_win = gp_align_up(C * sizeof(SgbPredWin), 256),
+               b_ptr = gp_align_up(C * sizeof(double*), 256), b_int = gp_align_up(C * sizeof(int), 256);
+  const size_t desc_bytes = 2 * b_feat + 2 * b_cov + 2 * b_prob + b_win + 2 * b_ptr + 2 * b_int;
+  char* dd = ar.take<char>(desc_bytes);
+  void* chol_ws = ar.take<char>(cholesky_large_batched_workspace_bytes(N, W));
+  const size_t featd = gp_align_up(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, N, n > N ? n : N) * sizeof(double), 256) / sizeof(double);
+  std::vector<double*> hL(W), hW(W);
+  std::vector<double*> hKx(W), hfeat(W), hs1(W), hdot(W), hV(W), hscal(W);
+  for (int w = 0; w < W; w++) {
+    hL[w] = ar.take<double>((size_t)N * ldL); hW[w] = ar.take<double>((size_t)N * ldL);
+    hKx[w] = ar.take<double>((size_t)N * ld); hfeat[w] = ar.take<double>(featd);
+    hs1[w] = ar.take<double>((size_t)rb * n); hdot[w] = ar.take<double>((size_t)rb * n);
+    hV[w] = ar.take<double>(N); hscal[w] = ar.take<double>(64);
+  }
+  if (!ar.ok) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgprb_predict_source: arena exhausted");
+  std::vector<char> hd(desc_bytes, 0);
+  size_t off = 0;
+  auto region = [&](size_t b) { size_t o = off; off += b; return o; };
+  const size_t o_fx = region(b_feat), o_fn = region(b_feat), o_ck = region(b_cov), o_cx = region(b_cov),
+               o_pv = region(b_prob), o_pa = region(b_prob), o_win = region(b_win), o_pL = region(b_ptr), o_pW = region(b_ptr),
+               o_iM = region(b_int), o_ild = region(b_int);
+  FeatItem* fx = (FeatItem*)(hd.data() + o_fx); FeatItem* fn = (FeatItem*)(hd.data() + o_fn);
+  CovItem* ck = (CovItem*)(hd.data() + o_ck); CovItem* cx = (CovItem*)(hd.data() + o_cx);
+  GemmProblem* pv = (GemmProblem*)(hd.data() + o_pv); GemmProblem* pa = (GemmProblem*)(hd.data() + o_pa);
+  SgbPredWin* wins = (SgbPredWin*)(hd.data() + o_win);
+  double** pL = (double**)(hd.data() + o_pL); double** pW = (double**)(hd.data() + o_pW);
+  int* iM = (int*)(hd.data() + o_iM); int* ild = (int*)(hd.data() + o_ild);
+  for (int w = 0; w < W; w++) {
+    const double* par = params + (size_t)w * p->nparams;
+    const double* Xw = X + (size_t)w * N; const double* Yw = Y + (size_t)w * N; const double* Xn = Xnew + (size_t)w * n;
+    for (int i = 0; i < P; i++) {
+      DevKern k{p->ktype[i], p->m[i], par + p->off_theta[i]};
+      const int mp = sm_mpad(k.m);
+      const size_t idx = (size_t)i * W + w;
+      double* ft = hfeat[w];         // one table per window, rebuilt for every kernel of the sum (launches are ordered)
+      fx[idx] = FeatItem{k, Xw, ft, N, 0};
+      fn[idx] = FeatItem{k, Xn, ft + gp_align_up((size_t)2 * mp * N, 32), n, 0};
+      cov_item_fill(&ck[idx], k, Xw, N, nullptr, N, hL[w], ldL, i > 0, 0.0, ft);
+      cov_item_fill(&cx[idx], k, Xw, N, Xn, n, hKx[w], ld, 0, 0.0, ft);
+    }
+    { GemmProblem& r = pv[w]; memset(&r, 0, sizeof(r)); r.A = hW[w]; r.lda = ldL; r.M = N; r.v0 = Yw; r.o0 = hV[w]; }
+    { GemmProblem& r = pa[w]; memset(&r, 0, sizeof(r));
+      r.A = hW[w]; r.lda = ldL; r.B = hKx[w]; r.ldb = ld; r.M = N; r.N = n; r.K = N; r.v0 = hV[w]; r.o0 = hs1[w]; r.o1 = hdot[w]; }
+    SgbPredWin& sw = wins[w];
+    memset(&sw, 0, sizeof(sw));
+    sw.params = par; sw.L = hL[w]; sw.ldL = ldL; sw.scal = hscal[w]; sw.dot = hdot[w]; sw.s1 = hs1[w]; sw.s2 = nullptr;
+    sw.kd = hscal[w]; sw.mean = mean + (size_t)w * P * n; sw.var = var + (size_t)w * P * n;
+    pL[w] = hL[w]; pW[w] = hW[w]; iM[w] = N; ild[w] = (int)ldL;
+  }
+  GP_HIP_CHECK(h, hipMemcpyAsync(dd, hd.data(), desc_bytes, hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));       // hd is a stack object
+  const FeatItem* dfx = (const FeatItem*)(dd + o_fx); const FeatItem* dfn = (const FeatItem*)(dd + o_fn);
+  const CovItem* dck = (const CovItem*)(dd + o_ck); const CovItem* dcx = (const CovItem*)(dd + o_cx);
+  const SgbPredWin* dwins = (const SgbPredWin*)(dd + o_win);
+  // K = K_sum(X) + s2 I ; L = chol(K) ; W = L^-1 ; V = W y   (sgpr_ss.py:88-90)
+  for (int i = 0; i < P; i++) {
+    if (gp_kern_is_mercer(p->ktype[i]))
+      GP_CHECK(launch_sm_features_items(h, dfx + (size_t)i * W, W, N, sm_mpad(p->m[i]), nullptr, 0));
+    GP_CHECK(launch_kernel_build_items(h, p->ktype[i], p->m[i], dck + (size_t)i * W, W, N, N, nullptr, 0));
+  }
+  hipLaunchKernelGGL(sgb_pred_prep_kernel, dim3(W), dim3(256), 0, h->stream, dwins, N, P, p->d_toff, p->d_ktype, p->d_km);
+  GP_HIP_CHECK(h, hipGetLastError());
+  if (N > 512) {
+    GP_CHECK(launch_cholesky_large_batched(h, hL.data(), hW.data(), W, N, ldL, chol_ws, cholesky_large_batched_workspace_bytes(N, W)));
+  } else {
+    GP_CHECK(launch_cholesky_batched(h, (double* const*)(dd + o_pL), (const int*)(dd + o_iM), (const int*)(dd + o_ild), W, N, 0));
+    GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)(dd + o_pL), (double* const*)(dd + o_pW), (const int*)(dd + o_iM),
+                                        (const int*)(dd + o_ild), W));
+  }
+  GP_CHECK(launch_matvec_batched(h, (const GemmProblem*)(dd + o_pv), W, N, 0));
+  for (int i = 0; i < P; i++) {
+    // Kx = K_i(X, Xnew); A = W Kx (never stored); mean_i = A^T V; var_i = Kdiag_sum - sum A^2   (sgpr_ss.py:92-103)
+    if (gp_kern_is_mercer(p->ktype[i])) {
+      GP_CHECK(launch_sm_features_items(h, dfx + (size_t)i * W, W, N, sm_mpad(p->m[i]), nullptr, 0));
+      GP_CHECK(launch_sm_features_items(h, dfn + (size_t)i * W, W, n, sm_mpad(p->m[i]), nullptr, 0));
+    }
+    GP_CHECK(launch_kernel_build_items(h, p->ktype[i], p->m[i], dcx + (size_t)i * W, W, N, n, nullptr, 0));
+    GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A;
+    f.epilogue = EPI_COLSUMSQ | EPI_COLDOT;
+    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(dd + o_pa), W, N, n, f));
+    hipLaunchKernelGGL(sgb_pred_finish_kernel, dim3((n + 255) / 256, W), dim3(256), 0, h->stream, dwins, rb, n, (int64_t)i * n);
+    GP_HIP_CHECK(h, hipGetLastError());
+  }
+  return check_not_pd(h);
 }
 
 }  // extern "C"

@@ -150,6 +150,53 @@ class SgprWindowBatch(object):
         h.check(h.lib.gp_sync(h.h))
         return self._b_host[:n].numpy().copy(), (self._g_host[:n].numpy().copy() if with_grad else None)
 
+    def _load_xnew(self, xnews, n_windows):
+        t = self.h.torch
+        if xnews is None:
+            return self.X[:n_windows], self.N            # predict at the windows' own frames (separation.py:306, 311)
+        xn = np.stack([np.asarray(x, dtype=np.float64).reshape(-1) for x in xnews])
+        if xn.shape[0] != n_windows:
+            raise ValueError("one Xnew per loaded window")
+        return t.as_tensor(xn).to(self.X.device), int(xn.shape[1])
+
+    def predict_f(self, params_host, xnews=None):
+        """SGPRSS.predict_f of every loaded window at its parameters params_host[i] (constrained vectors, as
+        `fit_windows_batched` returns them in "params"): (mean, var), each (count, n) — separation.py:306"""
+        h = self.h
+        cnt = self.count
+        xn, n = self._load_xnew(xnews, cnt)
+        if n > self.N:
+            raise ValueError("window-batched predict_f takes at most N new points per window")
+        self._p_host[:cnt].copy_(h.torch.as_tensor(np.asarray(params_host, dtype=np.float64)))
+        self.params[:cnt].copy_(self._p_host[:cnt], non_blocking=True)
+        mean, var = h.empty(cnt, n), h.empty(cnt, n)
+        h.check(h.lib.gp_sgprb_predict_f(self.plan, self.params.data_ptr(), self.X.data_ptr(), self.Y.data_ptr(),
+                                         self.Z.data_ptr(), xn.data_ptr(), n, cnt, mean.data_ptr(), var.data_ptr()))
+        return mean.cpu().numpy(), var.cpu().numpy()
+
+    def predict_s(self, params_host, xnews=None, chunk=None):
+        """SGPRSS.predict_s (the exact per-source posteriors, sgpr_ss.py:73-114) of every loaded window: (mean, var),
+        each (count, P, n) — separation.py:311.  `chunk` windows share one launch sequence (default: as many as fit
+        in ~16 GiB of workspace: the N x N factor and its inverse are 64 MB per window at N = 2001)."""
+        h = self.h
+        cnt = self.count
+        xn, n = self._load_xnew(xnews, cnt)
+        P = len(self._keep[0])
+        self._p_host[:cnt].copy_(h.torch.as_tensor(np.asarray(params_host, dtype=np.float64)))
+        self.params[:cnt].copy_(self._p_host[:cnt], non_blocking=True)
+        if chunk is None:
+            per = max(1, int(h.lib.gp_sgprb_predict_source_workspace_bytes(self.plan, 1, n)))
+            chunk = max(1, min(cnt, (16 << 30) // per))
+        chunk = int(min(chunk, cnt))
+        ws = h.workspace(h.lib.gp_sgprb_predict_source_workspace_bytes(self.plan, chunk, n))
+        mean, var = h.empty(cnt, P, n), h.empty(cnt, P, n)
+        for b0 in range(0, cnt, chunk):
+            c = min(chunk, cnt - b0)
+            h.check(h.lib.gp_sgprb_predict_source(self.plan, self.params[b0:].data_ptr(), self.X[b0:].data_ptr(),
+                                                  self.Y[b0:].data_ptr(), xn[b0:].data_ptr(), n, c,
+                                                  mean[b0:].data_ptr(), var[b0:].data_ptr(), ws.data_ptr(), ws.numel()))
+        return mean.cpu().numpy(), var.cpu().numpy()
+
     def close(self):
         if self.plan is not None:
             self.h.sync()
@@ -164,7 +211,7 @@ class SgprWindowBatch(object):
 
 
 def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default_reset, handle=None, rank=0,
-                        world_size=1, params0=None):
+                        world_size=1, params0=None, predict=False):
     """fit_windows with the device work batched: `batch` windows go through every bound + gradient evaluation together
     (one launch sequence, gp_sgprb_bound_grad), each window driven by its own instance of scipy's L-BFGS-B routine
     (lbfgsb_batch.LbfgsbRC: the iterates of `model.optimize(maxiter=maxiter)` exactly, given the same f and g).
@@ -172,6 +219,9 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
     Every window starts from the parameter values of make_model(handle) after `reset(model, x, y, z)` (unit noise and
     kernel variances by default, transcription.py:253-263) — i.e. carry_kernel_state=False of fit_windows — or from
     params0[i] (constrained vector [noise | theta_0 | ...]) when given.  All windows must share N and M.
+    predict=True adds what SoSp.optimize computes after every window's optimisation (separation.py:300-313), batched the
+    same way: "mean", "var" (predict_f at the window's frames, (N, 1)) and "smean", "svar" (predict_s: lists over the
+    sources of (N, 1) arrays).
     Returns a list over windows of dicts: bound, nfev, nit, variances, noise, params."""
     from . import _lib, lbfgsb_batch
     from .dist import window_assignment
@@ -193,7 +243,7 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
             hs = _lib.Handle(dev0.index, stream=s)
             try:
                 return fit_windows_batched(make_model, windows, maxiter=maxiter, batch=batch, reset=reset, handle=hs,
-                                           rank=rank, world_size=world_size, params0=params0)
+                                           rank=rank, world_size=world_size, params0=params0, predict=predict)
             finally:
                 s.synchronize()
                 hs.close()
@@ -245,6 +295,13 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
         for r, i in enumerate(ids):
             results[i] = {"bound": -runs[r].fun, "nfev": runs[r].nfev, "nit": runs[r].nit,
                           "variances": pfin[r, var_idx].copy(), "noise": float(pfin[r, 0]), "params": pfin[r].copy()}
+        if predict:
+            fm, fv = dev.predict_f(pfin)
+            sm, sv = dev.predict_s(pfin)
+            for r, i in enumerate(ids):
+                results[i]["mean"], results[i]["var"] = fm[r].reshape(-1, 1), fv[r].reshape(-1, 1)
+                results[i]["smean"] = [sm[r, k].reshape(-1, 1) for k in range(sm.shape[1])]
+                results[i]["svar"] = [sv[r, k].reshape(-1, 1) for k in range(sv.shape[1])]
     dev.close()
     model._destroy()
     return results

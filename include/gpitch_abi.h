@@ -346,6 +346,19 @@ gp_status gp_sgprb_bound_grad(gp_sgprb_plan p, const double* params, const doubl
                               int32_t count, double* bound_dev, double* grad);
 gp_status gp_sgprb_set_graphs(gp_sgprb_plan p, int32_t enable);
 gp_status gp_sgprb_eval_counts(gp_sgprb_plan p, int64_t* eager, int64_t* captured, int64_t* replayed);
+/* The rest of SoSp.optimize's loop body (gpitch/separation.py:300-313), window-batched: after a window's optimisation
+ * the reference calls model.predict_f(X_i) (GPflow 0.5 SGPR.build_predict) and model.predict_s(X_i) (sgpr_ss.py:73-114).
+ * gp_sgprb_predict_f: Xnew [count][n] (n <= N), mean / var [count][n]; runs the forward pass at `params` first.
+ * gp_sgprb_predict_source: the exact GP on each window's N frames (N x N Cholesky per window, every launch of the blocked
+ * factorisation carrying all windows); Xnew [count][n], mean / var [count][P][n]; workspace from
+ * gp_sgprb_predict_source_workspace_bytes(p, count, n) (about 3 N^2 doubles per window), 256-byte aligned.
+ * Both synchronise the stream and report a failed factorisation (GP_ERR_NOT_PD). */
+gp_status gp_sgprb_predict_f(gp_sgprb_plan p, const double* params, const double* X, const double* Y, const double* Z,
+                             const double* Xnew, int32_t n, int32_t count, double* mean, double* var);
+size_t gp_sgprb_predict_source_workspace_bytes(gp_sgprb_plan p, int32_t count, int32_t n);
+gp_status gp_sgprb_predict_source(gp_sgprb_plan p, const double* params, const double* X, const double* Y,
+                                  const double* Xnew, int32_t n, int32_t count, double* mean, double* var,
+                                  void* workspace, size_t workspace_bytes);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * HIP-event timing of the dominant kernels on the handle's own stream.  Returns the accumulated time of

@@ -74,3 +74,84 @@ def test_fit_windows_batched_matches_sequential_fits(gp_handle):
         assert abs(a["noise"] - b["noise"]) <= 1e-4 * abs(a["noise"])
     # the fits improved on the starting point and each window's result is its own
     assert len({round(b["bound"], 6) for b in bat}) == len(bat)
+
+
+@pytest.mark.parametrize("N,M,P,n_new", [(700, 32, 2, None), (300, 24, 3, 211), (2001, 64, 3, None)])
+def test_batched_predictions_per_window(gp_handle, N, M, P, n_new):
+    """gp_sgprb_predict_f / gp_sgprb_predict_source: the per-window predictions of SoSp.optimize's loop body
+    (separation.py:300-313) for W windows at once, against the one-window engine (same kernels, same order: 1e-10)
+    and the oracle.  N = 300: one-workgroup factorisation; N = 700 / 2001: the blocked one, every launch batched."""
+    from gpitch_amd.windows import SgprWindowBatch
+    wins = _windows(4, N, M, P, seed0=3)
+    tmpl = _model(*wins[0][:3], wins[0][3], 0.3, gp_handle)
+    dev = SgprWindowBatch(tmpl, 5, N, M, handle=gp_handle)
+    dev.load([w[0] for w in wins], [w[1] for w in wins], [w[2] for w in wins])
+    noises = [0.2 + 0.05 * i for i in range(len(wins))]
+    pv = np.stack([_params_vector(nz, w[3]) for nz, w in zip(noises, wins)])
+    xnews = None
+    if n_new is not None:
+        xnews = [np.linspace(w[0].min(), w[0].max(), n_new).reshape(-1, 1) for w in wins]
+    fm, fv = dev.predict_f(pv, xnews)
+    sm, sv = dev.predict_s(pv, xnews, chunk=3)                 # 4 windows in chunks of 3: a partial second chunk
+    n = N if n_new is None else n_new
+    assert fm.shape == (4, n) and sm.shape == (4, P, n)
+    for i, w in enumerate(wins):
+        xs = w[0] if xnews is None else xnews[i]
+        one = _model(w[0], w[1], w[2], w[3], noises[i], gp_handle)
+        m1, v1 = one.predict_f(xs)
+        np.testing.assert_allclose(fm[i], m1[:, 0], rtol=0, atol=1e-10 * np.abs(m1).max())
+        np.testing.assert_allclose(fv[i], v1[:, 0], rtol=0, atol=1e-10 * np.abs(v1).max())
+        ms, vs = one.predict_s(xs)
+        for k in range(P):
+            np.testing.assert_allclose(sm[i, k], ms[k][:, 0], rtol=0, atol=1e-10 * max(np.abs(ms[k]).max(), 1e-12))
+            np.testing.assert_allclose(sv[i, k], vs[k][:, 0], rtol=0, atol=1e-10 * np.abs(vs[k]).max())
+    # one window against the oracle (the small cases: the oracle's N x N factorisation on the host)
+    if N <= 700:
+        w = wins[1]
+        xs = w[0] if xnews is None else xnews[1]
+        rm, rv = orc.sgpr_predict_f(xs, w[0], w[1], w[2], w[3], noises[1])
+        assert np.abs(fm[1] - rm[:, 0]).max() <= 1e-8 * np.abs(rm).max()
+        assert np.abs(fv[1] - rv[:, 0]).max() <= 1e-8 * np.abs(rv).max()
+        rms, rvs = orc.sgpr_predict_source(xs, w[0], w[1], w[3], noises[1])
+        for k in range(P):
+            assert np.abs(sm[1, k] - np.asarray(rms[k]).reshape(-1)).max() <= 1e-7 * max(np.abs(rms[k]).max(), 1e-12)
+            assert np.abs(sv[1, k] - np.asarray(rvs[k]).reshape(-1)).max() <= 1e-7 * np.abs(rvs[k]).max()
+    # the predictions leave the plan usable: the bound afterwards is the bound before
+    b, _ = dev.evaluate(pv, with_grad=False)
+    for i, w in enumerate(wins):
+        ref = orc.sgpr_bound(w[0], w[1], w[2], w[3], noises[i])
+        assert abs(b[i] - ref) <= 1e-9 * abs(ref)
+    dev.close()
+
+
+def test_fit_windows_batched_with_predictions(gp_handle):
+    """fit + predict_f + predict_s for every window, as SoSp.optimize does (separation.py:279-313)"""
+    from gpitch_amd.windows import fit_windows_batched
+    wins = _windows(5, 801, 32, 2, seed0=9)
+
+    def make(h):
+        return _model(*wins[0][:3], wins[0][3], 1.0, h)
+    data = [(w[0], w[1], w[2]) for w in wins]
+    res = fit_windows_batched(make, data, maxiter=5, batch=3, predict=True)
+    for r, w in zip(res, wins):
+        assert r["mean"].shape == (801, 1) and r["var"].shape == (801, 1)
+        assert len(r["smean"]) == 2 and r["smean"][0].shape == (801, 1) and len(r["svar"]) == 2
+        assert np.all(r["var"] > 0) and all(np.all(v > -1e-9) for v in r["svar"])
+        # the same numbers from a one-window model put at the fitted parameters
+        one = make(gp_handle)
+        one.X, one.Y, one.Z = w[0], w[1], w[2]
+        pv = r["params"]
+        one.likelihood.variance = pv[0]
+        o = 1
+        for k in one.kern.kern_list:
+            m = int(k.num_partials)
+            k.variance, k.lengthscales = pv[o], pv[o + 1]
+            for q in range(m):
+                k.energy[q].value, k.frequency[q].value = pv[o + 2 + q], pv[o + 2 + m + q]
+            o += 2 + 2 * m
+        m1, v1 = one.predict_f(w[0])
+        np.testing.assert_allclose(r["mean"], m1, rtol=0, atol=1e-9 * np.abs(m1).max())
+        np.testing.assert_allclose(r["var"], v1, rtol=0, atol=1e-9 * np.abs(v1).max())
+        ms, vs = one.predict_s(w[0])
+        np.testing.assert_allclose(r["smean"][1], ms[1], rtol=0, atol=1e-9 * max(np.abs(ms[1]).max(), 1e-12))
+        np.testing.assert_allclose(r["svar"][0], vs[0], rtol=0, atol=1e-9 * np.abs(vs[0]).max())

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--batches", type=int, nargs="+", default=[32, 64, 128, 256], help="windows per batched evaluation")
     ap.add_argument("--nwin-batched", type=int, default=512)
     ap.add_argument("--json", default=None, help="write the measurements here")
+    ap.add_argument("--predict", action="store_true", help="also time fit + predict_f + predict_s (SoSp's loop body)")
+    ap.add_argument("--nwin-predict", type=int, default=256)
     args = ap.parse_args()
     import torch
     from gpitch_amd import _lib
@@ -84,6 +86,32 @@ def main():
         print("batched B=%d: %d windows in %.3f s = %.1f windows/s; nfev total %d (%.1f per window); bound[0]=%.6f"
               % (B, len(res), dt, len(res) / dt, nfev, nfev / float(len(res)), res[0]["bound"]), flush=True)
         out["batched"][str(B)] = {"windows": len(res), "seconds": dt, "windows_per_s": len(res) / dt, "nfev": nfev}
+    # the whole loop body of SoSp.optimize (separation.py:279-313): fit, predict_f, predict_s for every window
+    if args.predict:
+        B = args.batches[-1]
+        nwp = min(args.nwin_batched, args.nwin_predict)
+        fit_windows_batched(lambda hh: build_model(wins_b[0][3], hh), data_b[:8], maxiter=2, batch=8, predict=True)   # warm-up
+        t0 = time.perf_counter()
+        res = fit_windows_batched(lambda hh: build_model(wins_b[0][3], hh), data_b[:nwp], maxiter=args.maxiter, batch=B,
+                                  predict=True)
+        dt = time.perf_counter() - t0
+        print("batched fit + predict_f + predict_s, B=%d: %d windows in %.3f s = %.1f windows/s" % (B, nwp, dt, nwp / dt),
+              flush=True)
+        out["batched_with_predictions"] = {"batch": B, "windows": nwp, "seconds": dt, "windows_per_s": nwp / dt}
+        # the same predictions from the one-window engine (what fit_windows' after_fit hook would call), 16 windows
+        model = build_model(wins_b[0][3], _lib.default_handle())
+        k = min(16, nwp)
+        model.predict_f(wins_b[0][0]); model.predict_s(wins_b[0][0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for w in wins_b[:k]:
+            model.X, model.Y, model.Z = w[0], w[1], w[2]
+            model.predict_f(w[0]); model.predict_s(w[0])
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / k
+        print("one-window engine: predict_f + predict_s %.2f ms per window" % (dt1 * 1e3), flush=True)
+        out["one_window_predictions_ms"] = dt1 * 1e3
+        model._destroy()
     for ns in args.streams:
         t0 = time.perf_counter()
         res = fit_windows(lambda hh: build_model(wins[0][3], hh), [(w[0], w[1], w[2]) for w in wins],
