@@ -305,3 +305,17 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
     dev.close()
     model._destroy()
     return results
+
+
+def merge_sources(results, ws, n):
+    """SoSp.predict_s (separation.py:340-368): overlap-add the per-window source posteriors of
+    `fit_windows_batched(..., predict=True)` into whole-signal estimates [[mean_1, var_1], [mean_2, var_2], ...]
+    (window_overlap.merged_mean / merged_variance, Hann-weighted halves of 50 %-overlapping windows)."""
+    from . import window_overlap
+    num_sources = len(results[0]["smean"])
+    out = []
+    for k in range(num_sources):
+        m = window_overlap.merged_mean(y=[r["smean"][k] for r in results], ws=ws, n=n)
+        v = window_overlap.merged_variance(y=[r["svar"][k] for r in results], ws=ws, n=n)
+        out.append([m, v])
+    return out

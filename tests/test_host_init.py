@@ -159,3 +159,20 @@ def test_windowed_short_signal_and_segmented():
     xa, ya = wo.augmentate(x, y, augment_size=160)
     assert ya.shape == (n + 320, 1) and np.all(ya[:160] == 0) and np.all(ya[-160:] == 0)
     assert abs(xa[0, 0] - (x[0, 0] - 0.01)) < 1e-15 and xa.shape == (n + 320, 1)
+
+
+def test_merge_sources_is_the_reference_overlap_add_of_every_source():
+    """windows.merge_sources = SoSp.predict_s's merging (separation.py:340-368) of per-window source posteriors"""
+    from gpitch_amd import window_overlap
+    from gpitch_amd.windows import merge_sources
+    rng = np.random.RandomState(0)
+    ws, n = 21, 101
+    x = np.linspace(0, 1, n).reshape(-1, 1)
+    xw, _ = window_overlap.windowed(x, x, ws)
+    res = [{"smean": [rng.randn(ws, 1) for _ in range(3)], "svar": [rng.rand(ws, 1) for _ in range(3)]} for _ in xw]
+    out = merge_sources(res, ws, n)
+    assert len(out) == 3
+    for k in range(3):
+        np.testing.assert_array_equal(out[k][0], window_overlap.merged_mean([r["smean"][k] for r in res], ws, n))
+        np.testing.assert_array_equal(out[k][1], window_overlap.merged_variance([r["svar"][k] for r in res], ws, n))
+        assert out[k][0].shape == (n, 1)
