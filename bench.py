@@ -35,7 +35,9 @@ def build_model(args, rank):
         # ONE model over all ranks: same problem everywhere, rank r holds pitches p = r (mod world)
         world = int(os.environ.get("WORLD_SIZE", "1"))
         prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=0)
-        model = pdgp_from_problem(prob, shard=(rank, world) if world > 1 else None, float_type=ft)
+        import torch.distributed as tdist
+        grouped = world > 1 or (tdist.is_available() and tdist.is_initialized())     # (a one-rank group: the RCCL rehearsal)
+        model = pdgp_from_problem(prob, shard=(rank, world) if grouped else None, float_type=ft)
     else:
         prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=rank)
         model = pdgp_from_problem(prob, float_type=ft)
@@ -230,7 +232,9 @@ def main():
     os.environ["LOCAL_RANK"] = str(dev_index)      # gpitch_amd's default handle binds to this device
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or ("MASTER_ADDR" in os.environ and "WORLD_SIZE" in os.environ):
+        # (a launcher started us: the process group is formed even for one rank, which is how a one-GPU box exercises
+        # RCCL — communicator set-up and the per-step all-reduce on the library's streams)
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -385,7 +389,7 @@ def main():
             kuf["kuf_build_sm_m5"] = kuf_m5
         out = {
             "metric": "ELBO-steps/sec", "value": (1 if pitch else world) * args.steps / elapsed, "unit": "steps/s",
-            "n_gpus": world, "backend": (args.backend if world > 1 else None),
+            "n_gpus": world, "backend": (args.backend if dist is not None else None),
             "rccl_ranks": (dist.get_world_size() if (dist is not None and args.backend == "nccl") else 0),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if pitch else "weak", "vs_baseline": None, "dtype": args.float_type, "data": "synthetic",

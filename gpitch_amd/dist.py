@@ -34,9 +34,10 @@ def init_process_group(backend=None):
 
 
 def allreduce_sum_(t):
-    """in-place sum over ranks of a (device or host) tensor; no-op single-process"""
+    """in-place sum over ranks of a (device or host) tensor; no-op without a process group.  (A one-rank group still goes
+    through the backend: that is how a one-GPU box exercises the RCCL path, stream ordering included.)"""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if t.is_cuda and dist.get_backend() == "gloo":
             # CPU rehearsal backend: stage through the host (RCCL reduces device memory directly)
             host = t.cpu()

@@ -57,3 +57,17 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak" and d["value"] > 0
     assert d["pitch_sharded"]["scaling"] == "strong" and d["pitch_sharded"]["value"] > 0
+
+
+@pytest.mark.parametrize("shard", ["window", "pitch"])
+def test_bench_one_rank_through_rccl(shard):
+    """the launcher form with ONE rank and the nccl backend: RCCL communicator set-up and the per-step all-reduce (the
+    device-resident scalar ELBO in window mode; the 3N+1 exchange vector between gp_pdgp_elbo_begin / _end in pitch mode,
+    ordered against the library's streams) run on this one-GPU box; the 2 / 4 / 8-rank runs are the driver's"""
+    port = 29950 + (os.getpid() % 40) + (0 if shard == "window" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--shard", shard] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["backend"] == "nccl" and d["rccl_ranks"] == 1 and d["value"] > 0
