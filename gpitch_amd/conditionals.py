@@ -15,9 +15,8 @@ def _kdesc(h, kern):
 
 def conditional(Xnew, X, kern, f, full_cov=False, q_sqrt=None, whiten=False, float_type=None):
     """mean and variance of f(Xnew) given q(u) = N(f, q_sqrt q_sqrt^T) at inducing inputs X.
+    full_cov=True: the variance is the N x N x 1 posterior covariance (GPflow's shape for one latent column).
     float_type=np.float32 (whiten=True only): the strips and strip products in float32 (gp_conditional_diag_f32)."""
-    if full_cov:
-        raise NotImplementedError("full_cov=True is never used on the gpitch path")
     h = _lib.default_handle()
     Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1, 1)
     X = np.asarray(X, dtype=np.float64).reshape(-1, 1)
@@ -35,6 +34,15 @@ def conditional(Xnew, X, kern, f, full_cov=False, q_sqrt=None, whiten=False, flo
             q = np.diag(q[:, 0])          # GPflow's diagonal (M x K) q_sqrt form
         dsq = h.to_device(q)
     dx, dz, dmu = h.to_device(Xnew), h.to_device(X), h.to_device(f)
+    if full_cov:
+        if _lib.precision_bits(float_type) == 32:
+            raise ValueError("full_cov=True is a float64 operator")
+        fm, fc = h.empty(max(N, 1)), h.empty(max(N, 1), max(N, 1))
+        ws = h.workspace(h.lib.gp_conditional_full_workspace_bytes(N, M))
+        h.check(h.lib.gp_conditional_full(h.h, C.byref(d), dx.data_ptr(), N, dz.data_ptr(), M, dmu.data_ptr(),
+                                          None if dsq is None else dsq.data_ptr(), int(bool(whiten)), 1e-6,
+                                          fm.data_ptr(), fc.data_ptr(), ws.data_ptr(), ws.numel()))
+        return fm[:N].cpu().numpy().reshape(-1, 1), fc[:N, :N].cpu().numpy().reshape(N, N, 1)
     fm, fv = h.empty(max(N, 1)), h.empty(max(N, 1))
     ws = h.workspace(h.lib.gp_conditional_workspace_bytes(N, M))
     if _lib.precision_bits(float_type) == 32:

@@ -320,6 +320,61 @@ gp_status gp_conditional_diag_f32(gp_handle h, const gp_kernel_desc* kern, const
                                true, "gp_conditional_diag_f32: bad argument");
 }
 
+// full_cov = True of the same operator (GPflow 0.5 conditionals.conditional): the N x N posterior covariance
+//   K(xnew, xnew) - A^T A + (Lq^T A')^T (Lq^T A'),   A = Lm^-1 Kuf,  A' = A (whitened) or Lm^-T A (unwhitened).
+// Never used by the reference's own callers (its N is a window of frames: N^2 values); here for API parity.
+size_t gp_conditional_full_workspace_bytes(int32_t N, int32_t M) {
+  if (N <= 0 || M <= 0) return 256;
+  return gp_conditional_workspace_bytes(N, M) + gp_align_up((size_t)N * sizeof(double), 256) +
+         gp_align_up(3 * sizeof(GemmProblem), 256) + 512;
+}
+
+gp_status gp_conditional_full(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N, const double* z,
+                              int32_t M, const double* q_mu, const double* q_sqrt, int32_t whiten, double jitter,
+                              double* fmean, double* fcov, void* workspace, size_t workspace_bytes) {
+  if (!h) return GP_ERR_BAD_ARG;
+  if (!kern_ok(kern) || !xnew || !z || !q_mu || !fmean || !fcov || N < 0 || M <= 0)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_conditional_full: bad argument");
+  if (N == 0) return GP_OK;
+  if (!workspace || workspace_bytes < gp_conditional_full_workspace_bytes(N, M) || (((uintptr_t)workspace) & 255))
+    return gp_fail(h, GP_ERR_WORKSPACE, "gp_conditional_full: workspace too small or not 256-byte aligned");
+  GpArena ar(workspace, workspace_bytes);
+  double* fvar_diag = ar.take<double>(N);
+  GemmProblem* d_prob = ar.take<GemmProblem>(3);
+  CondBatch cb;
+  cb.tasks.resize(1);
+  CondTask& t = cb.tasks[0];
+  t.kern = dev_kern(kern); t.z = z; t.M = M; t.q_mu = q_mu; t.q_sqrt = q_sqrt; t.fmean = fmean; t.fvar = fvar_diag;
+  cb.desc_bytes = cond_batch_desc_bytes(1);
+  cb.d_desc = ar.take<char>(cb.desc_bytes);
+  if (!cond_task_carve(ar, t, N, whiten != 0, false) || !cb.d_desc || !ar.ok)
+    return gp_fail(h, GP_ERR_WORKSPACE, "gp_conditional_full: workspace too small");
+  cb.N = N;
+  gp_status st = cond_batch_upload(h, cb, whiten != 0, jitter);
+  if (st == GP_OK) st = cond_batch_run(h, cb, xnew, N, whiten != 0, jitter);     // mean, and A (A') left in the workspace
+  const int64_t ld = gp_strip_ld(N, false);
+  GemmProblem hp[3];
+  memset(hp, 0, sizeof(hp));
+  const double* Aeff = whiten ? t.A : t.A2;
+  { GemmProblem& r = hp[0]; r.A = t.A; r.lda = ld; r.B = t.A; r.ldb = ld; r.C = fcov; r.ldc = N; r.M = N; r.N = N; r.K = M; }
+  { GemmProblem& r = hp[1]; r.A = q_sqrt; r.lda = M; r.B = Aeff; r.ldb = ld; r.C = t.Kuf; r.ldc = ld; r.M = M; r.N = N; r.K = M; }
+  { GemmProblem& r = hp[2]; r.A = t.Kuf; r.lda = ld; r.B = t.Kuf; r.ldb = ld; r.C = fcov; r.ldc = N; r.M = N; r.N = N; r.K = M; }
+  if (st == GP_OK) {
+    hipError_t e = hipMemcpyAsync(d_prob, hp, sizeof(hp), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) st = gp_fail(h, GP_ERR_HIP, hipGetErrorString(e));
+  }
+  if (st == GP_OK) st = launch_kernel_build(h, t.kern, xnew, N, nullptr, N, fcov, N, 0, 0.0, t.feat, 0, 0);
+  if (st == GP_OK) { GemmFlags f; f.transA = 1; f.alpha = -1.0; f.beta = 1.0; st = launch_gemm_batched(h, d_prob + 0, 1, N, N, f); }
+  if (st == GP_OK && q_sqrt) {
+    GemmFlags f; f.transA = 1; f.triA = TRI_UPPER;          // tril(q_sqrt)^T, as matrix_band_part has it
+    st = launch_gemm_batched(h, d_prob + 1, 1, M, N, f);
+    if (st == GP_OK) { f = GemmFlags(); f.transA = 1; f.beta = 1.0; st = launch_gemm_batched(h, d_prob + 2, 1, N, N, f); }
+  }
+  // cb.h_desc and hp are sources of asynchronous copies: the stream is drained on every path (check_not_pd synchronises)
+  const gp_status pd = check_not_pd(h);
+  return st != GP_OK ? st : pd;
+}
+
 gp_status gp_mpd_varexp(gp_handle h, const double* Fmu, const double* Fvar, const double* y, int32_t N, int32_t P,
                         int32_t nlin, const double* noise_var, double* per_frame, double* sum_host) {
   if (!h) return GP_ERR_BAD_ARG;

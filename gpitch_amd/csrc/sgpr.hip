@@ -653,8 +653,26 @@ gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, c
   return GP_OK;
 }
 
+static gp_status sgpr_predict_f_impl(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                                     const double* Z, const double* Xnew, int32_t n, double* mean, double* var, double* cov);
+
 gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                             const double* Z, const double* Xnew, int32_t n, double* mean, double* var) {
+  return sgpr_predict_f_impl(p, params, X, Y, N, Z, Xnew, n, mean, var, nullptr);
+}
+
+// full_cov = True of SGPR.build_predict: cov (n x n, row-major) = K_sum(Xnew) + tmp2^T tmp2 - tmp1^T tmp1; `var` still
+// receives the diagonal form (it is the finish kernel's output).  float64 plans only.
+gp_status gp_sgpr_predict_f_full(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                                 const double* Z, const double* Xnew, int32_t n, double* mean, double* var, double* cov) {
+  if (!p) return GP_ERR_BAD_ARG;
+  if (!cov) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_sgpr_predict_f_full: cov is null");
+  if (p->f32) return gp_fail(p->h, GP_ERR_UNSUPPORTED, "gp_sgpr_predict_f_full: float64 plans only");
+  return sgpr_predict_f_impl(p, params, X, Y, N, Z, Xnew, n, mean, var, cov);
+}
+
+static gp_status sgpr_predict_f_impl(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                                     const double* Z, const double* Xnew, int32_t n, double* mean, double* var, double* cov) {
   if (!p) return GP_ERR_BAD_ARG;
   gp_handle h = p->h;
   sg_invalidate(p);
@@ -668,10 +686,13 @@ gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* 
   const int64_t ld = gp_strip_ld(n, f32 != 0);
   const int rb = gemm_rowblocks(M, 1);
   // tmp1 = W Kus (stored in A; colsumsq -> s1); tmp2 = WB tmp1 (colsumsq -> s2, dot with c -> dot)
-  std::vector<GemmProblem> probs(2);
+  std::vector<GemmProblem> probs(4);
   memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
   { GemmProblem& r = probs[0]; r.A = p->W; r.lda = M; r.B = p->Kuf; r.ldb = ld; r.C = p->A; r.ldc = ld; r.M = M; r.N = n; r.K = M; r.o0 = p->s1; }
-  { GemmProblem& r = probs[1]; r.A = p->WB; r.lda = M; r.B = p->A; r.ldb = ld; r.M = M; r.N = n; r.K = M; r.v0 = p->c; r.o0 = p->s2; r.o1 = p->dot; }
+  { GemmProblem& r = probs[1]; r.A = p->WB; r.lda = M; r.B = p->A; r.ldb = ld; r.M = M; r.N = n; r.K = M; r.v0 = p->c; r.o0 = p->s2; r.o1 = p->dot;
+    if (cov) { r.C = p->Kuf; r.ldc = ld; } }      // full covariance: tmp2 is kept (Kus is spent once tmp1 exists)
+  { GemmProblem& r = probs[2]; r.A = p->A; r.lda = ld; r.B = p->A; r.ldb = ld; r.C = cov; r.ldc = n; r.M = n; r.N = n; r.K = M; }
+  { GemmProblem& r = probs[3]; r.A = p->Kuf; r.lda = ld; r.B = p->Kuf; r.ldb = ld; r.C = cov; r.ldc = n; r.M = n; r.N = n; r.K = M; }
   SgDesc d2;
   GP_CHECK(sg_upload(p, probs, &d2, 1));
   for (int i = 0; i < p->P; i++) {
@@ -681,12 +702,21 @@ gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* 
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ;
     if (f32) GP_CHECK(launch_gemm_f32_role(h, d2.probs + 0, 1, M, n, f));
     else GP_CHECK(launch_gemm_batched(h, d2.probs + 0, 1, M, n, f)); }
-  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A; f.epilogue = EPI_COLSUMSQ | EPI_COLDOT;
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A;
+    f.epilogue = EPI_COLSUMSQ | EPI_COLDOT | (cov ? EPI_STORE : 0);
     if (f32) GP_CHECK(launch_gemm_f32_role(h, d2.probs + 1, 1, M, n, f));
     else GP_CHECK(launch_gemm_batched(h, d2.probs + 1, 1, M, n, f)); }
   hipLaunchKernelGGL(predict_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, p->dot, p->s1, p->s2, rb, n,
                      p->scal + 3, mean, var);
   GP_HIP_CHECK(h, hipGetLastError());
+  if (cov) {
+    for (int i = 0; i < p->P; i++)
+      GP_CHECK(launch_kernel_build(h, sg_kern(p, params, i), Xnew, n, nullptr, n, cov, n, i > 0, 0.0, p->feat));
+    GemmFlags f; f.transA = 1; f.alpha = -1.0; f.beta = 1.0;
+    GP_CHECK(launch_gemm_batched(h, d2.probs + 2, 1, n, n, f));
+    f = GemmFlags(); f.transA = 1; f.beta = 1.0;
+    GP_CHECK(launch_gemm_batched(h, d2.probs + 3, 1, n, n, f));
+  }
   return check_not_pd(h);
 }
 
@@ -704,9 +734,28 @@ size_t gp_sgpr_predict_source_workspace_bytes(int32_t N, int32_t n) {
   return d * sizeof(double) + SG_DESC_BYTES + 4096;
 }
 
+static gp_status sgpr_predict_source_impl(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                                          const double* Xnew, int32_t n, double* mean, double* var, double* cov,
+                                          void* workspace, size_t workspace_bytes);
+
 gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                                  const double* Xnew, int32_t n, double* mean, double* var, void* workspace,
                                  size_t workspace_bytes) {
+  return sgpr_predict_source_impl(p, params, X, Y, N, Xnew, n, mean, var, nullptr, workspace, workspace_bytes);
+}
+
+// full_cov = True of SGPRSS.build_predict_source (sgpr_ss.py:95-99): cov [P][n][n], cov_p = K_sum(Xnew) - A_p^T A_p
+gp_status gp_sgpr_predict_source_full(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                                      const double* Xnew, int32_t n, double* mean, double* var, double* cov,
+                                      void* workspace, size_t workspace_bytes) {
+  if (!p) return GP_ERR_BAD_ARG;
+  if (!cov) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_sgpr_predict_source_full: cov is null");
+  return sgpr_predict_source_impl(p, params, X, Y, N, Xnew, n, mean, var, cov, workspace, workspace_bytes);
+}
+
+static gp_status sgpr_predict_source_impl(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                                          const double* Xnew, int32_t n, double* mean, double* var, double* cov,
+                                          void* workspace, size_t workspace_bytes) {
   if (!p) return GP_ERR_BAD_ARG;
   gp_handle h = p->h;
   sg_invalidate(p);
@@ -741,11 +790,16 @@ gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const dou
     GP_CHECK(launch_cholesky_single(h, L, N, ldL));
     GP_CHECK(launch_tri_inverse_single(h, L, W, N, ldL));
   }
-  std::vector<GemmProblem> probs(2);
+  std::vector<GemmProblem> probs(2 + (cov ? p->P : 0));
   memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
   { GemmProblem& r = probs[0]; r.A = W; r.lda = ldL; r.M = N; r.v0 = Y; r.o0 = V; }
   { GemmProblem& r = probs[1]; r.A = W; r.lda = ldL; r.B = Kx; r.ldb = ld; r.C = A; r.ldc = ld; r.M = N; r.N = n; r.K = N;
     r.v0 = V; r.o0 = s1; r.o1 = dot; }
+  for (int i = 0; cov && i < p->P; i++) {
+    GemmProblem& r = probs[2 + i];
+    r.A = A; r.lda = ld; r.B = A; r.ldb = ld; r.C = cov + (size_t)i * n * n; r.ldc = n; r.M = n; r.N = n; r.K = N;
+  }
+  if (probs.size() * sizeof(GemmProblem) > SG_DESC_BYTES) return gp_fail(h, GP_ERR_UNSUPPORTED, "gp_sgpr_predict_source_full: too many kernels");
   GP_HIP_CHECK(h, hipMemcpyAsync(d_desc, probs.data(), probs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, h->stream));
   GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // probs is a stack object
   GemmProblem* dp = (GemmProblem*)d_desc;
@@ -773,10 +827,17 @@ gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const dou
     // Kx = K_i(X, Xnew); A = W Kx; mean_i = A^T V; var_i = Kdiag_sum - sum A^2   (sgpr_ss.py:92-103)
     GP_CHECK(launch_kernel_build(h, sg_kern(p, params, i), X, N, Xnew, n, Kx, ld, 0, 0.0, feat));
     GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = 1; f.role = 1; f.timer = GP_TIMER_COND_A;
-    f.epilogue = EPI_COLSUMSQ | EPI_COLDOT;
+    f.epilogue = EPI_COLSUMSQ | EPI_COLDOT | (cov ? EPI_STORE : 0);
     GP_CHECK(launch_gemm_batched(h, dp + 1, 1, N, n, f));
     hipLaunchKernelGGL(predict_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, dot, s1,
                        (const double*)nullptr, rb, n, scal, mean + (size_t)i * n, var + (size_t)i * n);
+    if (cov) {     // cov_i = K_sum(Xnew) - A^T A
+      double* ci = cov + (size_t)i * n * n;
+      for (int q = 0; q < p->P; q++)
+        GP_CHECK(launch_kernel_build(h, sg_kern(p, params, q), Xnew, n, nullptr, n, ci, n, q > 0, 0.0, feat));
+      GemmFlags g; g.transA = 1; g.alpha = -1.0; g.beta = 1.0;
+      GP_CHECK(launch_gemm_batched(h, dp + 2 + i, 1, n, n, g));
+    }
   }
   GP_HIP_CHECK(h, hipGetLastError());
   return check_not_pd(h);

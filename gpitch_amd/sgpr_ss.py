@@ -173,8 +173,9 @@ class SGPRSS(Parameterized):
     def compute_log_likelihood(self):
         return self.build_likelihood()
 
-    def predict_f(self, Xnew):
-        """mean and variance of the mixture at Xnew (GPflow 0.5 SGPR.build_predict, full_cov=False)"""
+    def predict_f(self, Xnew, full_cov=False):
+        """mean and variance of the mixture at Xnew (GPflow 0.5 SGPR.build_predict; full_cov=True — `predict_f_full_cov`
+        in GPflow — returns the n x n x 1 covariance)"""
         if self._shard:
             raise NotImplementedError("predictions of a frame-sharded window: build the model unsharded on one GPU")
         Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1)
@@ -184,19 +185,29 @@ class SGPRSS(Parameterized):
         h = self._handle
         xs = h.to_device(Xnew)
         mean, var = h.empty(n), h.empty(n)
-        h.check(h.lib.gp_sgpr_predict_f(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
-                                        self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(), n, mean.data_ptr(),
-                                        var.data_ptr()))
+        cov = h.empty(n, n) if full_cov else None
+        if full_cov:
+            h.check(h.lib.gp_sgpr_predict_f_full(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
+                                                 self._Yd.data_ptr(), self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(),
+                                                 n, mean.data_ptr(), var.data_ptr(), cov.data_ptr()))
+        else:
+            h.check(h.lib.gp_sgpr_predict_f(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
+                                            self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(), n, mean.data_ptr(),
+                                            var.data_ptr()))
         mu = mean.cpu().numpy().reshape(-1, 1)
         if self.mean_function is not None:          # SGPR.build_predict: + mean_function(Xnew)
             mu = mu + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(-1, 1)
+        if full_cov:
+            return mu, cov.cpu().numpy().reshape(n, n, 1)
         return mu, var.cpu().numpy().reshape(-1, 1)
+
+    def predict_f_full_cov(self, Xnew):
+        """GPflow's AutoFlow'd name for predict_f(full_cov=True)"""
+        return self.predict_f(Xnew, full_cov=True)
 
     def build_predict_source(self, Xnew, full_cov=False):
         """p(source* | Y): exact GP on the N training frames, one posterior per kernel in kern_list
         (sgpr_ss.py:73-106; the variance uses the SUM kernel's Kdiag as the reference does)."""
-        if full_cov:
-            raise NotImplementedError("full_cov=True is never used on the gpitch path")
         if self._shard:
             raise NotImplementedError("predictions of a frame-sharded window: build the model unsharded on one GPU")
         Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1)
@@ -207,12 +218,21 @@ class SGPRSS(Parameterized):
         xs = h.to_device(Xnew)
         mean, var = h.empty(P, n), h.empty(P, n)
         ws = h.workspace(h.lib.gp_sgpr_predict_source_workspace_bytes(N, n))
-        h.check(h.lib.gp_sgpr_predict_source(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
-                                             self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(), var.data_ptr(),
-                                             ws.data_ptr(), ws.numel()))
+        cov = h.empty(P, n, n) if full_cov else None
+        if full_cov:
+            h.check(h.lib.gp_sgpr_predict_source_full(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
+                                                      self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(),
+                                                      var.data_ptr(), cov.data_ptr(), ws.data_ptr(), ws.numel()))
+        else:
+            h.check(h.lib.gp_sgpr_predict_source(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
+                                                 self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(), var.data_ptr(),
+                                                 ws.data_ptr(), ws.numel()))
         m, v = mean.cpu().numpy(), var.cpu().numpy()
         if self.mean_function is not None:          # sgpr_ss.py:95 adds it to EVERY source's mean
             m = m + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(1, -1)
+        if full_cov:                                # sgpr_ss.py:95-99: n x n x D with D = 1
+            c = cov.cpu().numpy()
+            return [m[i].reshape(-1, 1) for i in range(P)], [c[i].reshape(n, n, 1) for i in range(P)]
         return [m[i].reshape(-1, 1) for i in range(P)], [v[i].reshape(-1, 1) for i in range(P)]
 
     def predict_s(self, Xnew):

@@ -127,6 +127,13 @@ gp_status gp_conditional_diag_f32(gp_handle h, const gp_kernel_desc* kern, const
                                   const double* z, int32_t M, const double* q_mu, const double* q_sqrt,
                                   double jitter, double* fmean, double* fvar,
                                   void* workspace, size_t workspace_bytes);
+/* full_cov = True of the same operator (GPflow 0.5 conditionals.conditional; gpitch/pdgp.py never asks for it): fmean (N)
+ * and the N x N posterior covariance fcov (row-major, ld N) = K(xnew) - A^T A + (Lq^T A')^T (Lq^T A').
+ * workspace: gp_conditional_full_workspace_bytes(N, M). */
+size_t gp_conditional_full_workspace_bytes(int32_t N, int32_t M);
+gp_status gp_conditional_full(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N, const double* z,
+                              int32_t M, const double* q_mu, const double* q_sqrt, int32_t whiten, double jitter,
+                              double* fmean, double* fcov, void* workspace, size_t workspace_bytes);
 
 /* gpflow.kullback_leiblers.gauss_kl(q_mu, q_sqrt, K=None) (pdgp.py:120-121 whitened; :126-129 with
  * K = kern.K(z) + jitter I built internally when kern != NULL).  Result to *out_host (syncs).
@@ -322,6 +329,13 @@ gp_status gp_sgpr_predict_f(gp_sgpr_plan p, const double* params, const double* 
                             const double* Z, const double* Xnew, int32_t n, double* mean, double* var);
 /* SGPRSS.build_predict_source / predict_s (sgpr_ss.py:73-114): exact GP with an N x N Cholesky;
  * mean/var are P x n row-major.  workspace: gp_sgpr_predict_source_workspace_bytes(N, n). */
+/* full_cov = True forms (SGPR.build_predict / sgpr_ss.py:95-99; unused by the reference's callers): cov is n x n
+ * (predict_f) or [P][n][n] (predict_source), row-major; `var` still receives the diagonal form.  float64 plans. */
+gp_status gp_sgpr_predict_f_full(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
+                                 const double* Z, const double* Xnew, int32_t n, double* mean, double* var, double* cov);
+gp_status gp_sgpr_predict_source_full(gp_sgpr_plan p, const double* params, const double* X, const double* Y,
+                                      int32_t N, const double* Xnew, int32_t n, double* mean, double* var, double* cov,
+                                      void* workspace, size_t workspace_bytes);
 size_t gp_sgpr_predict_source_workspace_bytes(int32_t N, int32_t n);
 gp_status gp_sgpr_predict_source(gp_sgpr_plan p, const double* params, const double* X, const double* Y,
                                  int32_t N, const double* Xnew, int32_t n, double* mean, double* var,

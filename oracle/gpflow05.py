@@ -170,24 +170,32 @@ def Kdiag_sum(kern_list, X, xp=NP):
 # ----------------------------------------------------------------------------------
 # GPflow 0.5 conditionals.conditional / kullback_leiblers.gauss_kl
 # ----------------------------------------------------------------------------------
-def conditional(Xnew, X, kern, f, q_sqrt=None, whiten=False, xp=NP, jitter=JITTER):
-    """conditional(Xnew, X, kern, f, full_cov=False, q_sqrt, whiten) with one latent column
-    (call sites pdgp.py:147-155, 176-178, 185-187, 199-205).
+def conditional(Xnew, X, kern, f, q_sqrt=None, whiten=False, xp=NP, jitter=JITTER, full_cov=False):
+    """conditional(Xnew, X, kern, f, full_cov, q_sqrt, whiten) with one latent column
+    (call sites pdgp.py:147-155, 176-178, 185-187, 199-205 — all with full_cov=False).
     f: (M,1); q_sqrt: (M,M,1) full-matrix form, lower triangle forced by band_part.
-    Returns fmean (N,1), fvar (N,1)."""
+    Returns fmean (N,1), fvar (N,1) — or (N,N,1) with full_cov=True (GPflow 0.5: fvar = K(Xnew) - A^T A + LTA^T LTA)."""
     M = X.shape[0]
     Kmn = K(kern, X, Xnew, xp)
     Kmm = K(kern, X, None, xp) + xp.eye(M) * jitter
     Lm = xp.cholesky(Kmm)
     A = xp.trsm(Lm, Kmn, lower=True)
-    fvar = Kdiag(kern, Xnew, xp) - xp.sum(xp.square(A), 0)
+    if full_cov:
+        fvar = K(kern, Xnew, None, xp) - xp.matmul(xp.t(A), A)
+    else:
+        fvar = Kdiag(kern, Xnew, xp) - xp.sum(xp.square(A), 0)
     if not whiten:
         A = xp.trsm(xp.t(Lm), A, lower=False)
     fmean = xp.matmul(xp.t(A), f)
     if q_sqrt is not None:
         L = xp.tril(q_sqrt[:, :, 0])
         LTA = xp.matmul(xp.t(L), A)
-        fvar = fvar + xp.sum(xp.square(LTA), 0)
+        if full_cov:
+            fvar = fvar + xp.matmul(xp.t(LTA), LTA)
+        else:
+            fvar = fvar + xp.sum(xp.square(LTA), 0)
+    if full_cov:
+        return fmean, xp.reshape(fvar, (fvar.shape[0], fvar.shape[1], 1))
     return fmean, xp.reshape(fvar, (-1, 1))
 
 
@@ -368,18 +376,22 @@ def sgpr_bound(X, Y, Z, kern_list, noise_var, reg=False, xp=NP):
     return bound
 
 
-def sgpr_predict_f(Xnew, X, Y, Z, kern_list, noise_var, xp=NP):
-    """GPflow 0.5 SGPR.build_predict (predict_f, called separation.py:306), full_cov=False."""
+def sgpr_predict_f(Xnew, X, Y, Z, kern_list, noise_var, xp=NP, full_cov=False):
+    """GPflow 0.5 SGPR.build_predict (predict_f, called separation.py:306 with full_cov=False; full_cov=True:
+    var = K(Xnew) + tmp2^T tmp2 - tmp1^T tmp1, tiled to n x n x D)."""
     err, Kdg, L, A, AAT, LB, c = sgpr_common(X, Y, Z, kern_list, noise_var, xp)
     Kus = K_sum(kern_list, Z, Xnew, xp)
     tmp1 = xp.trsm(L, Kus, lower=True)
     tmp2 = xp.trsm(LB, tmp1, lower=True)
     mean = xp.matmul(xp.t(tmp2), c)
+    if full_cov:
+        var = K_sum(kern_list, Xnew, None, xp) + xp.matmul(xp.t(tmp2), tmp2) - xp.matmul(xp.t(tmp1), tmp1)
+        return mean, xp.reshape(var, (var.shape[0], var.shape[1], 1))
     var = Kdiag_sum(kern_list, Xnew, xp) + xp.sum(xp.square(tmp2), 0) - xp.sum(xp.square(tmp1), 0)
     return mean, xp.reshape(var, (-1, 1))
 
 
-def sgpr_predict_source(Xnew, X, Y, kern_list, noise_var, xp=NP):
+def sgpr_predict_source(Xnew, X, Y, kern_list, noise_var, xp=NP, full_cov=False):
     """SGPRSS.build_predict_source (sgpr_ss.py:73-106): exact GP, N x N Cholesky; the variance uses
     the SUM kernel's Kdiag (:101) — reproduced as is."""
     N = X.shape[0]
@@ -391,6 +403,10 @@ def sgpr_predict_source(Xnew, X, Y, kern_list, noise_var, xp=NP):
         Kx = K(kp, X, Xnew, xp)
         A = xp.trsm(L, Kx, lower=True)
         means.append(xp.matmul(xp.t(A), V))
+        if full_cov:     # sgpr_ss.py:95-99: the SUM kernel's K(Xnew), as the diagonal form uses its Kdiag
+            svar = K_sum(kern_list, Xnew, None, xp) - xp.matmul(xp.t(A), A)
+            variances.append(xp.reshape(svar, (svar.shape[0], svar.shape[1], 1)))
+            continue
         svar = Kdiag_sum(kern_list, Xnew, xp) - xp.sum(xp.square(A), 0)
         variances.append(xp.reshape(svar, (-1, 1)))
     return means, variances

@@ -282,3 +282,30 @@ def test_sgprss_mean_function(gp_handle):
             np.testing.assert_allclose(a, b + np.asarray(mf(xs)).reshape(-1, 1), rtol=0, atol=1e-11)
     with pytest.raises(TypeError):
         SGPRSS(X, Y, np.sum(ks), Z, mean_function=3.0, handle=gp_handle)
+
+
+def test_full_cov_predictions_match_oracle(gp_handle):
+    """full_cov=True of SGPR.build_predict and SGPRSS.build_predict_source (sgpr_ss.py:95-99): n x n x 1 covariances"""
+    X, Y, Z, kl = _problem(600, 40, 2, 11)
+    m = _model(X, Y, Z, kl, 0.3, gp_handle)
+    Xs = X[::9] + 1e-5                      # n = 67: partial tiles in the n x n products
+    n = Xs.shape[0]
+    mean, cov = m.predict_f(Xs, full_cov=True)
+    rm, rc = orc.sgpr_predict_f(Xs, X, Y, Z, kl, 0.3, full_cov=True)
+    assert cov.shape == (n, n, 1)
+    np.testing.assert_allclose(mean, rm, rtol=0, atol=1e-8 * np.abs(rm).max())
+    np.testing.assert_allclose(cov, rc, rtol=0, atol=1e-8 * np.abs(rc).max())
+    _, var = m.predict_f(Xs)
+    # (K(x, x) = Kdiag * exp(-1e-6) for the Matern-1/2 envelope: euclid_dist's 1e-12 under the root)
+    kd = float(np.max(orc.Kdiag_sum(kl, Xs)))
+    np.testing.assert_allclose(np.diag(cov[:, :, 0]), var[:, 0], rtol=0, atol=3e-6 * kd)
+    m2, c2 = m.predict_f_full_cov(Xs)
+    np.testing.assert_array_equal(c2, cov)
+    sm, sc = m.build_predict_source(Xs, full_cov=True)
+    rsm, rsc = orc.sgpr_predict_source(Xs, X, Y, kl, 0.3, full_cov=True)
+    _, sv = m.predict_s(Xs)
+    for i in range(2):
+        assert sc[i].shape == (n, n, 1)
+        np.testing.assert_allclose(sm[i], rsm[i], rtol=0, atol=1e-8 * max(np.abs(rsm[i]).max(), 1e-3))
+        np.testing.assert_allclose(sc[i], rsc[i], rtol=0, atol=1e-8 * np.abs(rsc[i]).max())
+        np.testing.assert_allclose(np.diag(sc[i][:, :, 0]), sv[i][:, 0], rtol=0, atol=3e-6 * kd)
