@@ -69,16 +69,17 @@ static inline gp_status gp_fail(gp_handle h, gp_status s, const char* msg) {
 // The M x N covariance builds and their gradient contraction are bound by float64 VALU issue, not by HBM (about 57
 // instructions per entry with the library sqrt / exp).  Both functions below drop the range handling the arguments
 // cannot need and stay within 1.5 ulp, far inside the 1e-9 parity bar.
-// sqrt(x) for 1e-13 <= x <= 1e300 (a squared distance + 1e-12): v_rsq_f64 and the library's two correction steps,
-// without its input scaling and class checks.
+// sqrt(x) for 1e-13 <= x <= 1e300 (a squared distance + 1e-12): v_rsq_f64, one Goldschmidt step and ONE residual
+// correction, without the library's input scaling and class checks.  The library's second correction changes nothing
+// here: 4.2 M arguments spread over [1e-12, 1e4] all come out correctly rounded after the first (tools/probe_f64_ops.hip
+// has the instruction costs: v_rsq_f64 and v_max_f64 are quarter-rate, 17 and 14 cycles per wavefront against 4.75 for
+// v_fma_f64).
 __device__ __forceinline__ double gp_sqrt_pos(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   const double e = fma(-h, g, 0.5);
   g = fma(g, e, g); h = fma(h, e, h);
-  double d = fma(-g, g, x);
-  g = fma(d, h, g);
-  d = fma(-g, g, x);
+  const double d = fma(-g, g, x);
   return fma(d, h, g);
 }
 // sqrt(x) and 1/sqrt(x) together (same argument range): the reciprocal costs one more correction step instead of a
@@ -88,9 +89,7 @@ __device__ __forceinline__ void gp_sqrt_rsqrt_pos(double x, double& s, double& r
   double g = x * y, h = 0.5 * y;
   const double e = fma(-h, g, 0.5);
   g = fma(g, e, g); h = fma(h, e, h);
-  double d = fma(-g, g, x);
-  g = fma(d, h, g);
-  d = fma(-g, g, x);
+  const double d = fma(-g, g, x);
   g = fma(d, h, g);
   double r = h + h;
   r = fma(fma(-g, r, 1.0), r, r);

@@ -358,7 +358,9 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
 //    LDS tile instead and leave as whole 512-byte row segments, 16 bytes per lane, with non-temporal stores — the
 //    four wavefronts of a workgroup cover 2 KiB of every row.
 // Kuf strips only (no diagonal term, no accumulation); blockIdx.y = item.
-#define CVM_ROWS 32                  // rows per staged chunk (2 row tiles)
+#ifndef CVM_ROWS
+#define CVM_ROWS 64                  // rows per staged chunk (4 row tiles; 32: +2.5 % per launch)
+#endif
 #define CVM_WCOLS 64                 // columns per wavefront
 #define CVM_TS (CVM_WCOLS + 2)       // LDS row stride of the transposition tile (doubles): rows stay 16-byte aligned
 // Measured on MI355X (profiles/r02): direct stores 0.82 ms per 12-GP launch; LDS-transposed 512-byte row stores 0.78;
@@ -394,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) cov_mercer_mfma_kernel(const CovItem* 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
   const int jw = blockIdx.x * (4 * CVM_WCOLS) + wave * CVM_WCOLS;   // first column of this wavefront
-  const int rbeg = blockIdx.z * row_seg, rend = min(n1, rbeg + row_seg);   // this workgroup's rows (row_seg % 32 == 0)
+  const int rbeg = blockIdx.z * row_seg, rend = min(n1, rbeg + row_seg);   // this workgroup's rows (row_seg % CVM_ROWS == 0)
   if ((int)(blockIdx.x * (4 * CVM_WCOLS)) >= n2 || rbeg >= n1) return;
   // column-side operands, loop-invariant: B fragments B[k = 4 s + kq][j = lc] of each column tile, scaled inputs
   double bfr[CT][KS], bsc[CT], bb[CT];
