@@ -255,6 +255,21 @@ def main():
                        "pitches_per_rank_max": -(-args.P // world), "elbo_final": rp["elbo_final"]}
         del rp
 
+    kuf_alone = None
+    if world == 1 and args.overlap != 0 and not args.no_f32_line:
+        # the Kuf builds alone on the device (helper stream off), forward passes of the model just timed: in the step the
+        # resident Kuu factorisation holds 24 of the 256 CUs beside them
+        h.check(h.lib.gp_pdgp_set_overlap(model._plan, 0))
+        model._elbo(False, sync=False)
+        torch.cuda.synchronize()
+        h.check(h.lib.gp_timers_enable(h.h, 1))
+        h.check(h.lib.gp_timers_reset(h.h))
+        for _ in range(5):
+            model._elbo(False, sync=False)
+        torch.cuda.synchronize()
+        h.check(h.lib.gp_timers_enable(h.h, 0))
+        kuf_alone = {k: h.timers()[k] for k in ("kuf_build", "kuf_build_sm")}
+        h.check(h.lib.gp_pdgp_set_overlap(model._plan, args.overlap))
     kuf_m5 = None
     if world == 1 and (args.N, args.M, args.P) == (32768, 512, 12) and args.partials != 5 and not args.no_f32_line:
         # the HBM-bound regime of the spectral-mixture Kuf build (m = 5 partials, the demo's size): forward passes only
@@ -385,6 +400,17 @@ def main():
             k["compute_roofline"] = {"bound": "f64 (vector + matrix share the DP units)", "algorithmic_flops_per_launch": fl,
                                      "achieved": fl / (k["avg_launch_ms"] * 1e-3) / 1e12, "peak": PEAK_F64_MFMA_TFLOPS,
                                      "unit": "TFLOP/s", "frac": fl / (k["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+        if kuf_alone is not None:
+            for name in ("kuf_build", "kuf_build_sm"):
+                ms, n = kuf_alone[name]
+                if n and name in kuf:
+                    byts = kuf[name]["algorithmic_bytes_per_launch"]
+                    al = {"avg_launch_ms": ms / n, "achieved": byts / (ms / n * 1e-3) / 1e9,
+                          "frac": byts / (ms / n * 1e-3) / 1e9 / PEAK_HBM_GBS, "overlap_level": 0}
+                    if "compute_roofline" in kuf[name]:
+                        fl = kuf[name]["compute_roofline"]["algorithmic_flops_per_launch"]
+                        al["compute_frac"] = fl / (ms / n * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS
+                    kuf[name]["alone"] = al
         if kuf_m5 is not None:
             kuf["kuf_build_sm_m5"] = kuf_m5
         out = {
