@@ -361,8 +361,10 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
 #ifndef CVM_ROWS
 #define CVM_ROWS 64                  // rows per staged chunk (4 row tiles; 32: +2.5 % per launch)
 #endif
-#define CVM_WCOLS 64                 // columns per wavefront
-#define CVM_TS (CVM_WCOLS + 2)       // LDS row stride of the transposition tile (doubles): rows stay 16-byte aligned
+#ifndef CVM_CT
+#define CVM_CT 2                     // 16-column tiles per wavefront (see the kernel)
+#endif
+#define CVM_SEP 1.0                  // separable envelope: |z - x| / lengthscale at least this for every entry of a tile
 // Measured on MI355X (profiles/r02): direct stores 0.82 ms per 12-GP launch; LDS-transposed 512-byte row stores 0.78;
 // address-space-1 pointers (the descriptor's pointers are generic, so the stores were FLAT and every LDS wait of the
 // row loop waited for them) 0.62.  What is left is arithmetic: the float64 MFMA and the float64 vector pipe do not
@@ -371,14 +373,21 @@ gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, 
 // software-pipelined form of this loop, sched_barrier-pinned, ran 0.82 ms) or two co-resident wavefronts run them out
 // of phase (splitting the rows over more workgroups to shorten the last round changed nothing either: 0.65 ms).  The row
 // range can be split over blockIdx.z; the launcher does so only when the column blocks alone would not fill the device.
-template <int MPAD, int ENV>
-__global__ void __launch_bounds__(256, 2) cov_mercer_mfma_kernel(const CovItem* __restrict__ items,
-                                                                 const double* __restrict__ x2s, int n2s, int row_seg) {
+// CT = 16-column tiles per wavefront: 4 (four wavefronts of 64 columns, two per SIMD) or 2 (eight wavefronts of 32
+// columns, four per SIMD: half the loop-invariant column fragments per wavefront, twice the wavefronts to hide the LDS
+// round trips of the transposition and the store addresses behind).  Either way a workgroup owns 256 columns.
+template <int MPAD, int ENV, int CT>
+__global__ void __launch_bounds__(1024 / CT, CT == 2 ? 2 : 2) cov_mercer_mfma_kernel(const CovItem* __restrict__ items,
+                                                                                     const double* __restrict__ x2s, int n2s,
+                                                                                     int row_seg) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int NF = 2 * MPAD;          // features per point (a multiple of 8)
   constexpr int KS = NF / 4;            // MFMA k-steps
   constexpr int FS = NF + 1;            // odd LDS stride
-  constexpr int CT = CVM_WCOLS / 16;    // column tiles per wavefront
+  constexpr int WCOLS = 16 * CT;        // columns per wavefront
+  constexpr int NWV = 256 / WCOLS;      // wavefronts per workgroup
+  constexpr int NTH = 64 * NWV;
+  constexpr int TS = WCOLS + 2;         // LDS row stride of the transposition tile (doubles): rows stay 16-byte aligned
   const CovItem it = items[blockIdx.y];
   const cov_gcptr x1 = (cov_gcptr)it.x1;
   const int n1 = it.n1;
@@ -389,15 +398,16 @@ __global__ void __launch_bounds__(256, 2) cov_mercer_mfma_kernel(const CovItem* 
   const int64_t ld = it.ld;
   __shared__ double zf[CVM_ROWS * FS];            // row features of the current 32-row chunk
   __shared__ double rowa[CVM_ROWS];
+  __shared__ double tile_lo[CVM_ROWS / 16], tile_hi[CVM_ROWS / 16];
   __shared__ double etab[GP_EXP_TAB];
-  __shared__ __attribute__((aligned(16))) double tbuf[4][16 * CVM_TS];   // per-wave 16 x 64 transposition tile
+  __shared__ __attribute__((aligned(16))) double tbuf[NWV][16 * TS];      // per-wave 16 x WCOLS transposition tile
   gp_exp_tab_init(etab);
   const double var = th[0], ls = th[1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
-  const int jw = blockIdx.x * (4 * CVM_WCOLS) + wave * CVM_WCOLS;   // first column of this wavefront
+  const int jw = blockIdx.x * 256 + wave * WCOLS;                     // first column of this wavefront
   const int rbeg = blockIdx.z * row_seg, rend = min(n1, rbeg + row_seg);   // this workgroup's rows (row_seg % CVM_ROWS == 0)
-  if ((int)(blockIdx.x * (4 * CVM_WCOLS)) >= n2 || rbeg >= n1) return;
+  if ((int)(blockIdx.x * 256) >= n2 || rbeg >= n1) return;
   // column-side operands, loop-invariant: B fragments B[k = 4 s + kq][j = lc] of each column tile, scaled inputs
   double bfr[CT][KS], bsc[CT], bb[CT];
 #pragma unroll
@@ -411,15 +421,51 @@ __global__ void __launch_bounds__(256, 2) cov_mercer_mfma_kernel(const CovItem* 
     bb[ct] = __dmul_rn(bsc[ct], bsc[ct]);
   }
   double* tw = tbuf[wave];
-  const int srow = lane >> 5, scol = (lane & 31) * 2;      // store phase: 2 rows x 32 column pairs per instruction
+  constexpr int PPR = WCOLS / 2, RPI = 64 / PPR;           // store phase: RPI rows x PPR column pairs per instruction
+  const int srow = lane / PPR, scol = (lane % PPR) * 2;
   const bool vec = it.vec_ok && ((jw & 1) == 0);
+  // ---- separable envelope -------------------------------------------------------------------------------------
+  // Away from the diagonal band the envelope factorises: with a = z_i / l, b = x_j / l and every a of a row tile on one
+  // side of every b of this wavefront's 64 columns by at least CVM_SEP,
+  //     exp(-s r_ij),  r_ij = sqrt((a - b)^2 + 1e-12)  ->  exp(-s (a_i - bmax)) * exp(-s (bmax - b_j))      (a above b)
+  //                                                         exp(-s (bmin - a_i)) * exp(-s (b_j - bmin))      (a below b)
+  // (s = 1 for the Matern-1/2 envelope, sqrt 5 for Matern-5/2): one exp per ROW of the tile and two multiplies per
+  // entry instead of a square root and an exp per entry (~27 of the ~30 float64 vector instructions an entry costs — as
+  // much matrix-core-equivalent time as the 40 MFMAs of the tile).  What is dropped is the 1e-12 under the root and the
+  // rounding of the reference's expanded square (GPflow's square_dist): relative 1e-12 / (2 |a - b|) = 5e-13 at the
+  // threshold |a - b| >= 1 (a lengthscale apart), below the 1e-11 the kernel tests hold; inside the band — and for any
+  // tile that straddles it — the entry-by-entry form runs as before.  Column factors are loop-invariant registers.
+  double bmin_w, bmax_w;
+  {
+    double lo = bsc[0], hi = bsc[0];
+#pragma unroll
+    for (int ct = 1; ct < CT; ct++) { lo = fmin(lo, bsc[ct]); hi = fmax(hi, bsc[ct]); }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+    bmin_w = lo; bmax_w = hi;
+  }
+  constexpr double SENV = (ENV == 0) ? 1.0 : 2.23606797749979;
+  const bool sep_ok = (SENV * (bmax_w - bmin_w) < 300.0);       // column factors stay normal numbers
+  __syncthreads();                                                 // etab is ready
+  double cfp[CT], cfn[CT];                                         // var * exp(-s (bmax - b)),  var * exp(-s (b - bmin))
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    cfp[ct] = var * gp_exp_neg(-SENV * (bmax_w - bsc[ct]), etab);
+    cfn[ct] = var * gp_exp_neg(-SENV * (bsc[ct] - bmin_w), etab);
+  }
   for (int r0 = rbeg; r0 < rend; r0 += CVM_ROWS) {
     __syncthreads();
-    for (int t = tid; t < CVM_ROWS * NF; t += 256) {
+    for (int t = tid; t < CVM_ROWS * NF; t += NTH) {
       const int f = t / CVM_ROWS, ii = t % CVM_ROWS;
       zf[ii * FS + f] = (r0 + ii < n1) ? gf1[(size_t)f * n1 + r0 + ii] : 0.0;
     }
-    if (tid < CVM_ROWS) rowa[tid] = (r0 + tid < n1) ? x1[r0 + tid] / ls : 0.0;
+    if (tid < CVM_ROWS) rowa[tid] = x1[min(r0 + tid, n1 - 1)] / ls;        // (rows past the end repeat the last one)
+    else if (tid < CVM_ROWS + CVM_ROWS / 16) {       // scaled-input range of every 16-row tile of the chunk
+      const int t16 = (tid - CVM_ROWS) * 16;
+      double lo = x1[min(r0 + t16, n1 - 1)] / ls, hi = lo;
+      for (int q = 1; q < 16; q++) { const double v = x1[min(r0 + t16 + q, n1 - 1)] / ls; lo = fmin(lo, v); hi = fmax(hi, v); }
+      tile_lo[tid - CVM_ROWS] = lo; tile_hi[tid - CVM_ROWS] = hi;
+    }
     __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < CVM_ROWS / 16; rt++) {
@@ -434,6 +480,20 @@ __global__ void __launch_bounds__(256, 2) cov_mercer_mfma_kernel(const CovItem* 
         for (int ct = 0; ct < CT; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bfr[ct][s], acc[ct], 0, 0, 0);
       }
       // envelope; element r of acc[ct]: row 16 rt + kq + 4 r, column 16 ct + lc of this wavefront's strip
+      const bool above = sep_ok && (tile_lo[rt] - bmax_w >= CVM_SEP), below = sep_ok && (bmin_w - tile_hi[rt] >= CVM_SEP);
+      if (above || below) {                 // (wavefront-uniform)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const double a = rowa[rt * 16 + kq + 4 * r];
+          const double rf = gp_exp_neg(-SENV * (above ? a - bmax_w : bmin_w - a), etab);
+#pragma unroll
+          for (int ct = 0; ct < CT; ct++) {
+            double e = rf * (above ? cfp[ct] : cfn[ct]);
+            if (ENV != 0) { const double rr = fabs(a - bsc[ct]); e *= 1.0 + SENV * rr + (5.0 / 3.0) * (rr * rr); }
+            tw[(kq + 4 * r) * TS + ct * 16 + lc] = e * acc[ct][r];
+          }
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int li = rt * 16 + kq + 4 * r;
@@ -445,16 +505,16 @@ __global__ void __launch_bounds__(256, 2) cov_mercer_mfma_kernel(const CovItem* 
           double env;
           if (ENV == 0) env = gp_exp_neg(-rr, etab);
           else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
-          tw[(kq + 4 * r) * CVM_TS + ct * 16 + lc] = var * env * acc[ct][r];
+          tw[(kq + 4 * r) * TS + ct * 16 + lc] = var * env * acc[ct][r];
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();          // LDS operations of one wavefront complete in order
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int lr = 2 * q + srow, i = r0 + rt * 16 + lr, j = jw + scol;
-        const cov_d2 v = *reinterpret_cast<const cov_d2*>(tw + lr * CVM_TS + scol);
+      for (int q = 0; q < 16 / RPI; q++) {
+        const int lr = RPI * q + srow, i = r0 + rt * 16 + lr, j = jw + scol;
+        const cov_d2 v = *reinterpret_cast<const cov_d2*>(tw + lr * TS + scol);
         if (i < n1 && j < n2) {
           if (it.f32out) {
             const cov_gfptr o = (cov_gfptr)out + (size_t)i * ld + j;
@@ -510,7 +570,7 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
     if (x2_shared && big) {
       // Kuf strips (shared frames, nothing accumulated, no diagonal): matrix-core form
       // rows split only while the grid is smaller than the 512 workgroups the device holds (row segments are multiples of 32)
-      const int colblk = (max_n2 + 4 * CVM_WCOLS - 1) / (4 * CVM_WCOLS);
+      const int colblk = (max_n2 + 255) / 256;
       int nseg = 1;
       while (nseg < 8 && (int64_t)colblk * count * nseg < 512 && (max_n1 + nseg * 2 - 1) / (nseg * 2) >= 2 * CVM_ROWS) nseg *= 2;
       const int row_seg = ((max_n1 + nseg - 1) / nseg + CVM_ROWS - 1) / CVM_ROWS * CVM_ROWS;
@@ -518,9 +578,9 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
 #define COV_MFMA(MP)                                                                                                   \
       do {                                                                                                             \
         if (type == GP_KERN_MERCER_MATERN12SM)                                                                         \
-          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0, CVM_CT>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else                                                                                                           \
-          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 2>), gm, dim3(256), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+          hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 2, CVM_CT>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
       } while (0)
       switch (sm_mpad(m)) {
         case 4: COV_MFMA(4); break;

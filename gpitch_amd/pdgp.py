@@ -210,6 +210,10 @@ class Pdgp(Parameterized):
         idx = self.x.next_indices()
         idy = self.y.next_indices()
         assert np.array_equal(idx, idy)
+        # The batch is a SET of frames (the ELBO sums over it): handing it to the engine in time order changes nothing but
+        # the order of that sum, and lets the covariance kernels factorise the envelope away from the diagonal band
+        # (cov.hip: separable envelope) — with a shuffled batch every 64-column tile straddles the whole signal.
+        idx = np.sort(idx, kind="stable")
         ti = self._upload_indices(idx)
         return self._x_dev.index_select(0, ti).contiguous(), self._y_dev.index_select(0, ti).contiguous(), idx.size
 
