@@ -342,6 +342,8 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
 // for all contractions of a step run alone, the same step time — the step is bound by the float64 units)
 #define HYR_COLSEG_MIN 512
 #define HYR_MAX_SEGS 32
+#define HYR_CF_MAX 4096        // columns of a segment whose envelope column factors fit the LDS table
+#define HYR_SEP 1.0            // separable envelope: at least this many lengthscales between an entry's row and column
 __device__ __forceinline__ double hyr_swap1(double v) {      // value of the neighbouring lane (lane ^ 1)
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]
@@ -407,6 +409,39 @@ __global__ void __launch_bounds__(256, 2) hyper_sm_rows_kernel(DevKern k, const 
   double acc_v = 0.0, acc_l = 0.0;
   const int cw0 = blockIdx.z * col_seg, cw1 = tile_on ? min(n2, cw0 + col_seg) : cw0;
   const bool vec_ok = ((n2 & 1) == 0) && ((ldg & 1) == 0) && ((ldk & 1) == 0);
+  // ---- separable envelope (cov.hip has the argument): with A / B the smallest / largest scaled row input a = z / l of
+  // this workgroup's 64 rows, an entry whose column lies at least HYR_SEP below A or above B has
+  //     exp(-s r) = exp(-s (a_i - A)) exp(-s (A - b_j))     or     exp(-s (B - a_i)) exp(-s (b_j - B)),   r = |a_i - b_j|
+  // (relative deviation from the reference's sqrt((a - b)^2 + 1e-12): 1e-12 / (2 r) <= 5e-13).  The column factors of
+  // the workgroup's segment are made once, into LDS (sign bit = "above the rows", NaN = inside the band: entry-by-entry
+  // arithmetic there); the two row factors are per-lane constants.  A fast entry then costs a dozen float64 vector
+  // instructions instead of ~45 (square root, reciprocal root and exp per entry).
+  __shared__ __attribute__((aligned(16))) double cft[HYR_CF_MAX];
+  __shared__ double wg_lo[4], wg_hi[4];
+  constexpr double SENV = M52 ? 2.23606797749979 : 1.0;
+  const int nseg_cols = min(n2, (int)(blockIdx.z * col_seg) + col_seg) - (int)(blockIdx.z * col_seg);
+  const bool sep = (col_seg <= HYR_CF_MAX) && vec_ok;
+  double rfp = 0.0, rfn = 0.0;
+  if (sep) {
+    const double ab = gx1[rowc] * inv_ls;           // the scaled input as the entry arithmetic below forms it (x * (1 / l))
+    double lo = ab, hi = ab;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+    if (lane == 0) { wg_lo[wave] = tile_on ? lo : 1e300; wg_hi[wave] = tile_on ? hi : -1e300; }
+    __syncthreads();
+    const double A = fmin(fmin(wg_lo[0], wg_lo[1]), fmin(wg_lo[2], wg_lo[3]));
+    const double B = fmax(fmax(wg_hi[0], wg_hi[1]), fmax(wg_hi[2], wg_hi[3]));
+    for (int j = tid; j < nseg_cols; j += 256) {
+      const double b = gx2[blockIdx.z * col_seg + j] * inv_ls;
+      double v = __builtin_nan("");
+      if (A - b >= HYR_SEP) v = gp_exp_neg(-SENV * (A - b), etab);
+      else if (b - B >= HYR_SEP) v = -gp_exp_neg(-SENV * (b - B), etab);
+      cft[j] = v;
+    }
+    rfp = gp_exp_neg(-SENV * (ab - A), etab);
+    rfn = gp_exp_neg(-SENV * (B - ab), etab);
+    __syncthreads();
+  }
   // Whole 32-column stretches run from two register buffers in turn, the loads of block b + 1 issued before the
   // arithmetic of block b (two wavefronts per SIMD do not hide an HBM round trip per 16 columns by themselves), with
   // 16-byte loads and no column predicates; what is left (ragged ends, odd strides) goes block by block, checked.
@@ -448,7 +483,43 @@ __global__ void __launch_bounds__(256, 2) hyper_sm_rows_kernel(DevKern k, const 
       for (int t = 0; t < NT; t++) B.bf[t][e] = (on && fok[t]) ? gf2[foff[t] + (unsigned)cc] : 0.0;
     }
   };
+  const double ab_i = zi * inv_ls;
   auto compute = [&](int jb, const Blk& B, bool checked) {
+    if (sep && !checked) {
+      // column factors of this lane's four entries; the block is fast when none is in the band and all lie on one side
+      const int cl = jb - cw0 + 2 * kq;
+      const d2v c0 = *reinterpret_cast<const d2v*>(cft + cl), c1 = *reinterpret_cast<const d2v*>(cft + cl + 8);
+      const double cf[4] = {c0.x, c0.y, c1.x, c1.y};
+      const bool band = (cf[0] != cf[0]) || (cf[1] != cf[1]) || (cf[2] != cf[2]) || (cf[3] != cf[3]);
+      const bool neg = (__double2hiint(cf[0]) < 0);
+      const bool mixed = ((__double2hiint(cf[1]) < 0) != neg) || ((__double2hiint(cf[2]) < 0) != neg) || ((__double2hiint(cf[3]) < 0) != neg);
+      const unsigned long long bad = __ballot(band || mixed), nb = __ballot(neg);
+      if (bad == 0ull && (nb == 0ull || nb == ~0ull)) {
+        const double rf = neg ? rfn : rfp;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const double xb = B.x[e];
+          const double w = rowok ? fma(al, B.gm[e], B.g[e]) : 0.0;
+          const double r = fabs(ab_i - xb * inv_ls);
+          double E = rf * fabs(cf[e]), nratio = 1.0;
+          if (M52) {
+            const double s5 = 2.23606797749979, poly = 1.0 + s5 * r + (5.0 / 3.0) * r * r;
+            E *= poly;
+            nratio = (5.0 / 3.0) * r * (1.0 + s5 * r) / poly;
+          }
+          const double wvE = w * var * E, wd = wvE * (zi - xb);
+          const double wk = w * B.k[e];
+          acc_v += wk;
+          acc_l = fma(M52 ? wk * nratio : wk, r * inv_ls, acc_l);
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+            TE[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wvE, B.bf[t][e], TE[t], 0, 0, 0);
+            TD[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wd, B.bf[t][e], TD[t], 0, 0, 0);
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int c = jb + 8 * (e >> 1) + 2 * kq + (e & 1);
