@@ -544,3 +544,47 @@ def test_adam_stops_at_a_failed_cholesky_and_leaves_the_state_alone(gp_handle):
     # the handle is usable again afterwards
     model.kern_act[0].variance = 1.0
     assert np.isfinite(model.compute_log_likelihood())
+
+
+@pytest.mark.parametrize("ls", [0.1, 0.002, 5.0])
+def test_separable_envelope_paths_match_autograd(gp_handle, ls):
+    """The Kuf build and the Kuf-side contraction factorise the envelope for entries a lengthscale away from the band
+    (cov.hip / bwd.hip "separable envelope"); inside it, and whenever a tile straddles it, they run entry by entry.
+    ls = 0.1: both in one strip (the bench's case); 0.002: nearly everything separable, factors underflowing to 0 far
+    out; 5.0: nothing separable.  The same problem with its data rows shuffled puts the whole signal into every tile,
+    i.e. runs the entry-by-entry path alone: the two must agree far below the parity bar, and both with autograd
+    through the oracle (inducing inputs fixed: the matrix-core contraction)."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(16384, 64, 1, num_partials=3, seed=5)
+    prob["kern_com"][0]["lengthscales"] = ls
+
+    def run(pr):
+        model = pdgp_from_problem(pr, handle=gp_handle)
+        model.za.fixed = True
+        model.zc.fixed = True
+        model._pack()
+        return model._elbo(True), model_grad_dict(model)
+    f, got_g = run(prob)
+    shuf = dict(prob)
+    perm = np.random.RandomState(0).permutation(prob["N"])
+    shuf["x"], shuf["y"] = prob["x"][perm], prob["y"][perm]
+    f2, got_g2 = run(shuf)
+    assert abs(f - f2) <= 1e-11 * abs(f), (f, f2)
+    for name, g1 in got_g.items():
+        if name.startswith("z"):
+            continue
+        scale = max(np.abs(g1).max(), 1e-12)
+        np.testing.assert_allclose(got_g2[name], g1, rtol=0, atol=1e-9 * scale, err_msg="separable vs entry-by-entry: " + name)
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    assert abs(f - ref_f) <= ELBO_RTOL * abs(ref_f), (f, ref_f)
+    # at l = 0.002 the scaled inputs reach 500 and the reference's expanded square (a^2 - 2ab + b^2) loses 1e-5 of the
+    # lengthscale gradient to cancellation — autograd through the oracle moves by that much when the rows are shuffled
+    tol = 2e-7 if ls >= 0.05 else 1e-4
+    for name, rg in ref_g.items():
+        if name.startswith("za") or name.startswith("zc"):
+            continue
+        gg = got_g[name]
+        if name.startswith("q_sqrt"):
+            rg = np.tril(rg[:, :, 0])[:, :, None]
+        scale = max(np.abs(rg).max(), 1e-12)
+        np.testing.assert_allclose(gg.reshape(rg.shape), rg, rtol=0, atol=tol * scale, err_msg=name)
