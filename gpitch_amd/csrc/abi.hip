@@ -155,6 +155,7 @@ gp_status gp_destroy(gp_handle h) {
   if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
   if (h->ev_era) (void)hipEventDestroy(h->ev_era);
   if (h->ev_kuu) (void)hipEventDestroy(h->ev_kuu);
+  if (h->ev_diag) (void)hipEventDestroy(h->ev_diag);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->d_status) (void)hipFree(h->d_status);

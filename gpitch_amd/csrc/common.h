@@ -24,7 +24,7 @@ struct gp_handle_s {
   GpLogisticTable logistic = {}; int num_logistic = 0;
   // helper stream for work that can overlap the main stream (the latency-bound Kuu factorisation runs on ~24 CUs
   // while the Kuf builds stream over the rest): created on first use, joined through events
-  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_era = nullptr, ev_kuu = nullptr;
+  hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_era = nullptr, ev_kuu = nullptr, ev_diag = nullptr;
   hipStream_t main_stream_saved = nullptr; bool aux_active = false, aux_pending = false;
   // second helper stream ("side"): one more independent piece of a step (the spectral-mixture Kuf-side contractions
   // underneath the second half of the Kuf_bar product); gp_side_begin / _end / _join
@@ -233,6 +233,7 @@ struct GemmFlags {
   int scale_mode = 0;    // 0 none; 1: opB(B)(k,n) *= v1[n]; 2: opB(B)(k,n) *= v1[k]
   int timer = GP_TIMER_SMALL_GEMM;
   int role = 0;          // 1 cond_A, 2 cond_LTA (needs transA), 3 kuf_bar: dedicated 128x128 instantiations
+  int tile_m0 = 0, tile_mcount = 0;   // strip products (big tiles, no split-K): only row-blocks [m0, m0 + mcount) (0 = all)
 };
 enum GemmEpi {
   EPI_STORE = 1,     // C = alpha*acc + beta*C

@@ -95,6 +95,7 @@ struct CondBatch {
   size_t off_cov_uu = 0, off_cov_uf = 0, off_feat_zuu = 0, off_feat_zuf = 0, off_feat_x = 0;
   // blocked Kuu factorisation (engine.hip: cond_batch_factorize)
   bool blocked = false; int nblk = 0;
+  bool diag_ready = false;   // set by a factorisation that recorded gp_handle_s::ev_diag after the diagonal blocks of W
   size_t off_blk_mats[8] = {0}, off_blk_w[8] = {0}, off_blk_M[8] = {0}, off_blk_gemm[8][4] = {{0}};
   size_t off_diag_mats = 0, off_diag_w = 0, off_diag_M = 0, off_diag_ld = 0;   // all panels' diagonal blocks, one batch
 };

@@ -256,6 +256,12 @@ static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb, bool resident)
                                         (double* const*)(cb.d_desc + cb.off_diag_w),
                                         (const int*)(cb.d_desc + cb.off_diag_M), (const int*)(cb.d_desc + cb.off_diag_ld),
                                         cb.nblk * G));
+    // the first row-block of A = W Kuf needs only W's first diagonal block: cond_batch_run starts it from here, underneath
+    // the six dependent launches of the block-row inverse (0.2 ms of a few workgroups each)
+    if (h->aux_active) {
+      if (!h->ev_diag && hipEventCreateWithFlags(&h->ev_diag, hipEventDisableTiming) != hipSuccess) h->ev_diag = nullptr;
+      if (h->ev_diag && hipEventRecord(h->ev_diag, h->stream) == hipSuccess) cb.diag_ready = true;
+    }
     return cond_batch_block_row_inverse(h, cb);
   }
   const int* lds = (const int*)(cb.d_desc + cb.off_lds);
@@ -325,6 +331,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     return GP_OK;
   };
   gp_status st = GP_OK;
+  cb.diag_ready = false;
   if (!reuse_factor) {
     st = build_kuu();
     // The Kuf builds (main stream) start only once the Kuu builds are through, i.e. together with the factorisation
@@ -340,14 +347,30 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
   GP_CHECK(st);
   // 3. Kuf
   GP_CHECK(build_kuf());
-  GP_CHECK(gp_aux_join(h));
-  // 4. A = W Kuf (+ column reductions)
+  // 4. A = W Kuf (+ column reductions).  When the factorisation left an event behind the diagonal blocks of W, the first
+  // row-block goes ahead of the join (it reads W[0:128, 0:128] only) and the rest follows it.
   {
     GemmFlags f;
     f.triA = TRI_LOWER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A; f.role = 1;
     f.epilogue = EPI_STORE | EPI_COLSUMSQ | (whiten ? EPI_COLDOT : 0);
-    if (cb.f32) GP_CHECK(launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, f));
-    else GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, f));
+    static const bool early_ok = !(getenv("GP_COND_A_EARLY") && atoi(getenv("GP_COND_A_EARLY")) == 0);   // A/B switch
+    const bool early = early_ok && forked && cb.diag_ready && cb.maxM > 128 &&
+                       hipStreamWaitEvent(h->stream, h->ev_diag, 0) == hipSuccess;
+    auto cond_a = [&](int m0, int mcount) -> gp_status {
+      GemmFlags g = f;
+      g.tile_m0 = m0; g.tile_mcount = mcount;
+      if (cb.f32) return launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, g);
+      return launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, g);
+    };
+    if (early) {
+      gp_status s1 = cond_a(0, 1);
+      gp_status s2 = gp_aux_join(h);
+      GP_CHECK(s1); GP_CHECK(s2);
+      GP_CHECK(cond_a(1, 0));
+    } else {
+      GP_CHECK(gp_aux_join(h));
+      GP_CHECK(cond_a(0, 0));
+    }
   }
   if (!whiten) {
     GemmFlags f;

@@ -55,6 +55,8 @@ struct GemmDevFlags {
   int scale_mode;  // 0 none, 1: B(k,n) *= v1[n], 2: B(k,n) *= v1[k]
   int ksplit;      // >1: split-K, slabs written to o2 + s*M*N (ldc = N), epi forced to plain store
   int tilesM, tilesN;
+  int tm0;         // first row-block of this launch (tilesM counts the launch's row-blocks)
+  int tilesM_req;  // host side only: requested number of row-blocks (0 = all)
 };
 
 template <int BM, int BN, bool TA, bool TB>
@@ -139,7 +141,7 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
     // to the shader engines round-robin, so a fixed (bid % tilesM) would pin all the heavy row-blocks on
     // one engine; rotating by the strip index keeps a strip's row-blocks adjacent but cycles who gets which.
     tn = bid / f.tilesM;
-    tm = (bid % f.tilesM + tn) % f.tilesM;
+    tm = f.tm0 + (bid % f.tilesM + tn) % f.tilesM;
   }
   const int i0 = tm * BM, j0 = tn * BN;
   if (i0 >= p.M || j0 >= p.N) return;
@@ -558,6 +560,11 @@ static gp_status launch_one(gp_handle h, const GemmProblem* d_probs, int batch, 
                             int ksplit) {
   using S = GemmSmem<BM, BN, TA, TB>;
   df.tilesM = (maxM + BM - 1) / BM;
+  if (df.tm0 > 0 || df.tilesM_req > 0) {       // a row-block range (never with split-K)
+    const int all = df.tilesM;
+    if (ksplit > 1 || df.tm0 >= all) return GP_OK;
+    df.tilesM = (df.tilesM_req > 0 && df.tm0 + df.tilesM_req < all) ? df.tilesM_req : all - df.tm0;
+  }
   df.tilesN = (maxN + BN - 1) / BN;
   df.ksplit = ksplit;
   int ntiles = df.tilesM * df.tilesN;
@@ -593,6 +600,7 @@ static GemmDevFlags to_dev(const GemmFlags& f) {
   df.epi = f.epilogue;
   df.scale_mode = f.scale_mode;
   df.ksplit = 1; df.tilesM = df.tilesN = 1;
+  df.tm0 = f.tile_m0; df.tilesM_req = f.tile_mcount;
   return df;
 }
 

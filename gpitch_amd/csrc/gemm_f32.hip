@@ -47,6 +47,7 @@ struct Gemm32Flags {
   int sym;          // role 4: lower tiles only
   int ksplit;       // role 4: K-slices
   int tilesM, tilesN;
+  int tm0, tilesM_req;   // row-block range of this launch (see GemmFlags::tile_m0)
 };
 
 // TAG: 1 cond_A (A = W lower, float64 in memory, k-contiguous), 2 cond_LTA (A = Lq^T, upper, float64, row-contiguous),
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) gemm_f32_kernel(co
     } else { tm = t % f.tilesM; tn = t / f.tilesM; }
   } else {
     tn = bid / f.tilesM;
-    tm = (bid % f.tilesM + tn) % f.tilesM;      // rotate the row-block by the strip index (see gemm.hip)
+    tm = f.tm0 + (bid % f.tilesM + tn) % f.tilesM;      // rotate the row-block by the strip index (see gemm.hip)
   }
   const int i0 = tm * F32_BT, j0 = tn * F32_BT;
   if (i0 >= p.M || j0 >= p.N) return;
@@ -427,6 +428,11 @@ static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, 
   constexpr int B_ELEMS = (TAG == 4) ? F32_KC_ELEMS : F32_RC_ELEMS;
   constexpr size_t BYTES = (size_t)2 * (A_ELEMS + B_ELEMS) * sizeof(float);
   f.tilesM = (maxM + F32_BT - 1) / F32_BT;
+  if (TAG != 4 && (f.tm0 > 0 || f.tilesM_req > 0)) {
+    const int all = f.tilesM;
+    if (f.tm0 >= all) return GP_OK;
+    f.tilesM = (f.tilesM_req > 0 && f.tm0 + f.tilesM_req < all) ? f.tilesM_req : all - f.tm0;
+  }
   f.tilesN = (maxN + F32_BT - 1) / F32_BT;
   int ntiles = f.tilesM * f.tilesN;
   if (TAG == 4) { if (f.sym) ntiles = f.tilesM * (f.tilesM + 1) / 2; ntiles *= f.ksplit; }
@@ -448,6 +454,7 @@ gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batc
   GpTimerScope ts(h, gf.timer);
   Gemm32Flags f;
   f.alpha = gf.alpha; f.epi = gf.epilogue; f.scale = gf.scale_mode; f.sym = 0; f.ksplit = 1; f.tilesM = f.tilesN = 1;
+  f.tm0 = gf.tile_m0; f.tilesM_req = gf.tile_mcount;
   if (gf.beta != 0.0) return gp_fail(h, GP_ERR_UNSUPPORTED, "float32 strip product: beta != 0");
   switch (gf.role) {
     case 1: return launch_f32<1>(h, d_probs, batch, maxM, maxN, f);
@@ -468,6 +475,7 @@ gp_status launch_gemm_f32_nt_reduce_batched(gp_handle h, const GemmProblem* d_pr
     GpTimerScope ts(h, GP_TIMER_NT_GEMM);
     Gemm32Flags f;
     f.alpha = 1.0; f.epi = 1; f.scale = scale_by_k; f.sym = sym; f.ksplit = nsplit > 1 ? nsplit : 2; f.tilesM = f.tilesN = 1;
+    f.tm0 = 0; f.tilesM_req = 0;
     GP_CHECK(launch_f32<4>(h, d_probs, batch, maxM, maxM, f));
   }
   return launch_slab_reduce(h, d_probs, batch, maxM, nsplit > 1 ? nsplit : 2, sym, alpha);
