@@ -1188,12 +1188,25 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   }
   const int nK = p->nK;   // latent GPs whose kernel hyper-parameters / inducing inputs are trainable
   // sum_n gv  (kdiag term)
-  hipLaunchKernelGGL(batched_sum_kernel, dim3(G), dim3(256), 0, h->stream, p->gFvar, (int64_t)n, n, p->bw[0].gvsum);
-  GP_HIP_CHECK(h, hipGetLastError());
+  // sum_n gv and the ELBO's final reduction (pdgp.hip: pdgp_finish) are wanted only when the step ends: they go to the head
+  // of the helper stream's chain when there is one, and run here otherwise
+  bool sums_done = false;
+  auto late_sums = [&]() -> gp_status {
+    if (sums_done) return GP_OK;
+    sums_done = true;
+    hipLaunchKernelGGL(batched_sum_kernel, dim3(G), dim3(256), 0, h->stream, p->gFvar, (int64_t)n, n, p->bw[0].gvsum);
+    GP_HIP_CHECK(h, hipGetLastError());
+    if (p->fin.pending) {
+      p->fin.pending = false;
+      GP_CHECK(launch_elbo_finish(h, p->fin.lik_partials, p->fin.nb, p->fin.kl, p->fin.nkl, p->fin.elbo, p->fin.g_noise));
+    }
+    return GP_OK;
+  };
   // Everything that hangs off H = A diag(2 gv) A^T — grad q_sqrt, Wbar, the whole Kuu side — is independent of the
   // Kuf_bar product, which needs only R = W^T (Lq Lq^T - I) and alpha = W^T q_mu.  With early_fork the H chain
   // (the split-K product included) goes to the helper stream and the main stream starts Kuf_bar right away.
   const bool early_fork = white && nK > 0 && n >= 4096 && p->overlap >= 2;
+  if (!early_fork) GP_CHECK(late_sums());
   auto h_chain_head = [&]() -> gp_status {
     GemmFlags f;
     // H = A diag(2 gv) A^T  (symmetric, split-K over the frames); u = A gm and grad q_mu += u are fused into it
@@ -1284,8 +1297,9 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       }
       return GP_OK;
     };
-    if (forked) {            // helper stream: [H chain when forked early,] Kuu side
-      if (early_fork) { st = h_chain_head(); if (st == GP_OK) st = wbar_chain(); }
+    if (!forked) GP_CHECK(late_sums());
+    if (forked) {            // helper stream: [the late sums and the H chain when forked early,] Kuu side
+      if (early_fork) { st = late_sums(); if (st == GP_OK) st = h_chain_head(); if (st == GP_OK) st = wbar_chain(); }
       if (st == GP_OK) st = kuu_side();
       gp_status s2 = gp_aux_end(h);
       if (st == GP_OK) st = s2;

@@ -297,9 +297,13 @@ static gp_status pdgp_finish(gp_pdgp_plan p, const double* params, const double*
   const double scale = num_data / (double)n;
   GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
                           grad ? p->gFmu : nullptr, grad ? p->gFvar : nullptr, nullptr, xchg));
-  if (xchg) GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, xchg + 3 * (size_t)n, 1, elbo_dev, grad ? grad : nullptr));
-  else GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G * GP_KL_BLOCKS, elbo_dev, grad ? grad : nullptr));
-  if (grad) GP_CHECK(pdgp_backward(p, params, x, n, grad));
+  if (grad) {     // (pdgp_backward launches it)
+    p->fin.lik_partials = p->lik_partials; p->fin.nb = nb; p->fin.elbo = elbo_dev; p->fin.g_noise = grad; p->fin.pending = true;
+    if (xchg) { p->fin.kl = xchg + 3 * (size_t)n; p->fin.nkl = 1; } else { p->fin.kl = p->kl; p->fin.nkl = p->G * GP_KL_BLOCKS; }
+    GP_CHECK(pdgp_backward(p, params, x, n, grad));
+    if (p->fin.pending) return gp_fail(h, GP_ERR_HIP, "pdgp_backward left the ELBO reduction behind");
+  } else if (xchg) GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, xchg + 3 * (size_t)n, 1, elbo_dev, nullptr));
+  else GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G * GP_KL_BLOCKS, elbo_dev, nullptr));
   if (elbo_host) {
     GP_HIP_CHECK(h, hipMemcpyAsync(elbo_host, elbo_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GP_CHECK(check_not_pd(h));

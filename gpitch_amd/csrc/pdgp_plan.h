@@ -77,6 +77,11 @@ struct gp_pdgp_plan_s {
   const double* last_params = nullptr; const double* last_x = nullptr; double* last_grad = nullptr; int last_n = -1;
   bool bwd_carved = false;
   GemmProblem dummy_prob;      // sink for descriptor slots a GP does not need (pdgp_upload_bwd)
+  // the ELBO's final reduction (and the noise-variance gradient it produces), handed to the backward pass: neither is
+  // needed before the step ends, so it runs at the head of the helper stream's chain instead of between the last forward
+  // product and Kuf_bar (bwd.hip: pdgp_backward)
+  struct { const double* lik_partials = nullptr; int nb = 0; const double* kl = nullptr; int nkl = 0; double* elbo = nullptr;
+           double* g_noise = nullptr; bool pending = false; } fin;
   int overlap = 2;             // gp_pdgp_set_overlap: 0 one stream, 1 Kuu factorisation / Kuu-side backward on the helper
                                // stream, 2 also the H = A D A^T chain next to Kuf_bar
   bool era_ready = false;      // pdgp_prefetch_backward ran for the current evaluation
