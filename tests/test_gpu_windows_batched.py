@@ -155,3 +155,38 @@ def test_fit_windows_batched_with_predictions(gp_handle):
         ms, vs = one.predict_s(w[0])
         np.testing.assert_allclose(r["smean"][1], ms[1], rtol=0, atol=1e-9 * max(np.abs(ms[1]).max(), 1e-12))
         np.testing.assert_allclose(r["svar"][0], vs[0], rtol=0, atol=1e-9 * np.abs(vs[0]).max())
+
+
+def test_batched_prediction_argument_and_failure_paths(gp_handle):
+    """status codes of the window-batched predictions: bad sizes are GP_ERR_BAD_ARG, a workspace that is too small
+    GP_ERR_WORKSPACE, a window whose exact-GP covariance is not positive definite GP_ERR_NOT_PD (raised, not a wrong
+    number) — and the plan stays usable afterwards"""
+    from gpitch_amd import _lib
+    from gpitch_amd.windows import SgprWindowBatch
+    N, M, P = 600, 24, 2
+    wins = _windows(2, N, M, P, seed0=4)
+    tmpl = _model(*wins[0][:3], wins[0][3], 0.3, gp_handle)
+    dev = SgprWindowBatch(tmpl, 2, N, M, handle=gp_handle)
+    dev.load([w[0] for w in wins], [w[1] for w in wins], [w[2] for w in wins])
+    pv = np.stack([_params_vector(0.3, w[3]) for w in wins])
+    h = gp_handle
+    with pytest.raises(ValueError):                                     # more new points than frames per window
+        dev.predict_f(pv, [np.linspace(0, 1, N + 5).reshape(-1, 1)] * 2)
+    mean, var = h.empty(2, N), h.empty(2, N)
+    st = h.lib.gp_sgprb_predict_f(dev.plan, dev.params.data_ptr(), dev.X.data_ptr(), dev.Y.data_ptr(), dev.Z.data_ptr(),
+                                  dev.X.data_ptr(), N, 3, mean.data_ptr(), var.data_ptr())       # count > windows of the plan
+    assert st == _lib.GP_ERR_BAD_ARG
+    small = h.workspace(1024)
+    sm, sv = h.empty(2, P, N), h.empty(2, P, N)
+    st = h.lib.gp_sgprb_predict_source(dev.plan, dev.params.data_ptr(), dev.X.data_ptr(), dev.Y.data_ptr(), dev.X.data_ptr(),
+                                       N, 2, sm.data_ptr(), sv.data_ptr(), small.data_ptr(), small.numel())
+    assert st == _lib.GP_ERR_WORKSPACE
+    bad = pv.copy()
+    bad[1, 0] = -50.0                                                   # noise variance: K + s2 I loses definiteness
+    with pytest.raises(_lib.NotPositiveDefiniteError):
+        dev.predict_s(bad)
+    fm, fv = dev.predict_f(pv)                                          # still in working order
+    one = _model(wins[1][0], wins[1][1], wins[1][2], wins[1][3], 0.3, gp_handle)
+    m1, v1 = one.predict_f(wins[1][0])
+    np.testing.assert_allclose(fm[1], m1[:, 0], rtol=0, atol=1e-10 * np.abs(m1).max())
+    dev.close()
