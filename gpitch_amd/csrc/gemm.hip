@@ -123,7 +123,6 @@ __global__ void __launch_bounds__(gemm_threads(BM, TAG), gemm_threads(BM, TAG) /
     // enumerated, so every launched workgroup has work.  Inside an XCD's range the OUTPUT TILE varies fastest, so the
     // workgroups resident together on one XCD work on the same K-slice of different tiles and share its operand
     // strips in that XCD's L2 (each strip is used by tilesM+1 tiles).
-    const int nblk = gridDim.x;
     const int ntl = (f.triC == TRI_LOWER) ? f.tilesM * (f.tilesM + 1) / 2 : f.tilesM * f.tilesN;
     ksl = bid / ntl;
     const int t = bid % ntl;
