@@ -1188,7 +1188,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   }
   const int nK = p->nK;   // latent GPs whose kernel hyper-parameters / inducing inputs are trainable
   // sum_n gv  (kdiag term)
-  // sum_n gv and the ELBO's final reduction (pdgp.hip: pdgp_finish) are wanted only when the step ends: they go to the head
+  // sum_n gv and the ELBO's final reduction (pdgp.hip: pdgp_finish) are wanted only when the step ends: they go to the end
   // of the helper stream's chain when there is one, and run here otherwise
   bool sums_done = false;
   auto late_sums = [&]() -> gp_status {
@@ -1299,8 +1299,9 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     };
     if (!forked) GP_CHECK(late_sums());
     if (forked) {            // helper stream: [the late sums and the H chain when forked early,] Kuu side
-      if (early_fork) { st = late_sums(); if (st == GP_OK) st = h_chain_head(); if (st == GP_OK) st = wbar_chain(); }
+      if (early_fork) { st = h_chain_head(); if (st == GP_OK) st = wbar_chain(); }
       if (st == GP_OK) st = kuu_side();
+      if (st == GP_OK) st = late_sums();      // (at the END of the chain: ahead of the split-K product they delayed it)
       gp_status s2 = gp_aux_end(h);
       if (st == GP_OK) st = s2;
       GP_CHECK(st);
