@@ -155,7 +155,11 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   // kernels (batched over the GPs), the O(M^3) panel solve / trailing update / block-row inverse to the batched GEMMs.
   // One workgroup per GP for the whole 512 x 512 factor + inverse took 1.8 ms of a 31 ms step.
   cb.nblk = (cb.maxM + CB_NB - 1) / CB_NB;
-  cb.blocked = (cb.maxM > 256 && cb.nblk <= CB_MAX_PANELS);
+  // (two panels already pay off for long batches: the factor comes from one resident launch, the first row-block of
+  // A = W Kuf starts from W's diagonal blocks — cond_batch_run — and the fused factor + inverse kernel was the head's
+  // critical path: 0.46 ms at M = 256)
+  static const bool blk256 = !(getenv("GP_BLOCKED_256") && atoi(getenv("GP_BLOCKED_256")) == 0);     // A/B switch
+  cb.blocked = (cb.maxM > 256 || (blk256 && cb.maxM > 128 && cb.N >= 4096)) && cb.nblk <= CB_MAX_PANELS;
   if (cb.blocked) {
     for (int k = 0; k < cb.nblk; k++) {
       cb.off_blk_mats[k] = region(G * sizeof(double*));
