@@ -667,6 +667,83 @@ gp_status launch_cholesky_large(gp_handle h, double* A, double* W, int N, int64_
   return launch_cholesky_large_batched(h, a, w, 1, N, ld, ws, ws_bytes);
 }
 
+// One M x M matrix (128 < M <= 1024) as the ELBO engine factors its Kuu batch (engine.hip: cond_batch_factorize, resident
+// form): the whole factor from ONE one-workgroup launch, then the inverse blocked over 128-column panels — all diagonal
+// blocks in one tri_inverse launch, the block rows below them as two GEMMs each.  The one-workgroup factor + inverse of a
+// 512 x 512 matrix takes 1.37 ms (the inverse is the slower half); this takes 0.9.  The descriptors are built and
+// uploaded ONCE (chol_inverse_blocked_prepare: the caller's buffers do not move), so a run is launches only and can sit
+// inside a recorded launch sequence.
+size_t chol_inverse_blocked_workspace_bytes(int M) {
+  const int nblk = (M + CHL_NB - 1) / CHL_NB;
+  const size_t ldT = (size_t)((M + 1) & ~1);
+  return gp_align_up((size_t)2 * nblk * sizeof(GemmProblem), 256) + gp_align_up((size_t)(2 * nblk + 2) * sizeof(double*), 256) +
+         gp_align_up((size_t)(2 * nblk + 2) * sizeof(int), 256) + gp_align_up((size_t)CHL_NB * ldT * sizeof(double), 256) + 512;
+}
+
+struct CholBlockedLayout {
+  GemmProblem* probs; double** ptrs; int* ints; double* T; int nblk;
+  // ptrs: [0] A, [1] W, [2 .. 2 + nblk) L_kk, [2 + nblk .. 2 + 2 nblk) W_kk;  ints: [0] M, [1] ld, [2 .. 2 + nblk) nb_k, then nblk x ld
+};
+static bool chol_blocked_layout(int M, void* ws, size_t ws_bytes, CholBlockedLayout* L) {
+  GpArena ar(ws, ws_bytes);
+  L->nblk = (M + CHL_NB - 1) / CHL_NB;
+  const int64_t ldT = (M + 1) & ~1;
+  L->probs = ar.take<GemmProblem>((size_t)2 * L->nblk);
+  L->ptrs = ar.take<double*>((size_t)2 * L->nblk + 2);
+  L->ints = ar.take<int>((size_t)2 * L->nblk + 2);
+  L->T = ar.take<double>((size_t)CHL_NB * ldT);
+  return ar.ok;
+}
+
+gp_status chol_inverse_blocked_prepare(gp_handle h, double* A, double* W, int M, int64_t ld, void* ws, size_t ws_bytes) {
+  if (M <= CHL_NB || (ld & 1) || ld < M) return gp_fail(h, GP_ERR_BAD_ARG, "chol_inverse_blocked: M > 128 and an even ld >= M");
+  CholBlockedLayout L;
+  if (!chol_blocked_layout(M, ws, ws_bytes, &L)) return gp_fail(h, GP_ERR_WORKSPACE, "chol_inverse_blocked: workspace too small");
+  const int nblk = L.nblk;
+  const int64_t ldT = (M + 1) & ~1;
+  std::vector<GemmProblem> hp((size_t)2 * nblk);
+  std::vector<double*> hptr((size_t)2 * nblk + 2);
+  std::vector<int> hint((size_t)2 * nblk + 2);
+  memset(hp.data(), 0, hp.size() * sizeof(GemmProblem));
+  hptr[0] = A; hptr[1] = W; hint[0] = M; hint[1] = (int)ld;
+  for (int k = 0; k < nblk; k++) {
+    const int c0 = k * CHL_NB, nb = (M - c0 < CHL_NB) ? M - c0 : CHL_NB;
+    double* Wkk = W + (int64_t)c0 * ld + c0;
+    hptr[2 + k] = A + (int64_t)c0 * ld + c0; hptr[2 + nblk + k] = Wkk;
+    hint[2 + k] = nb; hint[2 + nblk + k] = (int)ld;
+    { GemmProblem& r = hp[2 * k + 0];   // T = L[c0:c0+nb, :c0] W[:c0, :c0]
+      r.A = A + (int64_t)c0 * ld; r.lda = ld; r.B = W; r.ldb = ld; r.C = L.T; r.ldc = ldT; r.M = nb; r.N = c0; r.K = c0; }
+    { GemmProblem& r = hp[2 * k + 1];   // W[c0:c0+nb, :c0] = -W_kk T
+      r.A = Wkk; r.lda = ld; r.B = L.T; r.ldb = ldT; r.C = W + (int64_t)c0 * ld; r.ldc = ld; r.M = nb; r.N = c0; r.K = nb; }
+  }
+  GP_HIP_CHECK(h, hipMemcpyAsync(L.probs, hp.data(), hp.size() * sizeof(GemmProblem), hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(L.ptrs, hptr.data(), hptr.size() * sizeof(double*), hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipMemcpyAsync(L.ints, hint.data(), hint.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  GP_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the staging vectors are stack objects
+  return GP_OK;
+}
+
+gp_status chol_inverse_blocked_run(gp_handle h, int M, int64_t ld, void* ws, size_t ws_bytes) {
+  CholBlockedLayout L;
+  if (!chol_blocked_layout(M, ws, ws_bytes, &L)) return gp_fail(h, GP_ERR_WORKSPACE, "chol_inverse_blocked: workspace too small");
+  const int nblk = L.nblk;
+  GP_CHECK(launch_cholesky_batched(h, (double* const*)L.ptrs, L.ints, L.ints + 1, 1, M, 0));     // the whole factor, one workgroup
+  hipLaunchKernelGGL(chl_zero_kernel, dim3(256, 1), dim3(256), 0, h->stream, (double* const*)(L.ptrs + 1), (int64_t)M * ld);
+  GP_HIP_CHECK(h, hipGetLastError());
+  GP_CHECK(launch_tri_inverse_batched(h, (const double* const*)(L.ptrs + 2), (double* const*)(L.ptrs + 2 + nblk), L.ints + 2,
+                                      L.ints + 2 + nblk, nblk));
+  for (int k = 1; k < nblk; k++) {
+    const int c0 = k * CHL_NB, nb = (M - c0 < CHL_NB) ? M - c0 : CHL_NB;
+    GemmFlags f;
+    f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, L.probs + 2 * k + 0, 1, nb, c0, f));
+    f = GemmFlags();
+    f.triA = TRI_LOWER; f.alpha = -1.0;
+    GP_CHECK(launch_gemm_batched(h, L.probs + 2 * k + 1, 1, nb, c0, f));
+  }
+  return GP_OK;
+}
+
 // after a panel-blocked factorisation: clear the blocks strictly above the block diagonal (the one-workgroup kernel
 // clears the upper triangle only inside the diagonal blocks it is given), so that L is usable as a dense operand
 __global__ void __launch_bounds__(256) zero_upper_blocks_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,

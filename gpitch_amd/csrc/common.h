@@ -195,6 +195,11 @@ gp_status launch_cholesky_single(gp_handle h, double* A, int M, int64_t ld, int 
 // one large matrix, blocked over the GEMM kernels: A -> L in place (lower), W = L^-1 (upper part zero); ld even
 size_t cholesky_large_workspace_bytes(int N);
 size_t cholesky_large_batched_workspace_bytes(int N, int count);
+// one M x M matrix, 128 < M <= 1024: factor from one one-workgroup launch, inverse blocked over 128-column panels
+// (descriptors prepared once for fixed buffers; run = launches only)
+size_t chol_inverse_blocked_workspace_bytes(int M);
+gp_status chol_inverse_blocked_prepare(gp_handle h, double* A, double* W, int M, int64_t ld, void* ws, size_t ws_bytes);
+gp_status chol_inverse_blocked_run(gp_handle h, int M, int64_t ld, void* ws, size_t ws_bytes);
 // host arrays of `count` device pointers: every launch of the blocked factorisation + inverse runs over all matrices
 gp_status launch_cholesky_large_batched(gp_handle h, double* const* A, double* const* W, int count, int N, int64_t ld,
                                         void* ws, size_t ws_bytes);

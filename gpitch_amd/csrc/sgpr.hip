@@ -27,6 +27,9 @@ struct gp_sgpr_plan_s {
   double *scal = nullptr;   // [0] bound, [1] sum err^2, [2] sum colsumsq(A'), [3] kdiag total per point, [4] dF/dkd, [5] dF/ds
   char* d_desc = nullptr; std::vector<char> h_desc[2];   // two descriptor blocks (training pass / prediction pass)
   int nsplit = 2;
+  // M > 256: Kuu and B are factored by one resident launch and inverted block by block (chol.hip: chol_inverse_blocked_*),
+  // descriptors prepared when the workspace is set
+  void *chol_ws_kuu = nullptr, *chol_ws_b = nullptr; size_t chol_ws_bytes = 0; bool chol_blocked = false;
   // bound+gradient evaluations are launch-bound at window sizes (N ~ 2001): once the device descriptors match
   // the argument pointers the whole kernel sequence is captured into a hipGraph and replayed (L-BFGS-B calls it
   // dozens of times per window with the same buffers)
@@ -170,6 +173,7 @@ static size_t sgpr_feat_stride(const gp_sgpr_plan_s* p) {
   return gp_align_up(kernel_build_feat_ws_doubles(p->maxm > 0 ? p->maxm : 1, p->M, p->maxN), 32);
 }
 
+static bool sgpr_chol_blocked(const gp_sgpr_plan_s* p) { return p->M > 256 && p->M <= 1024 && (p->M % 2) == 0; }
 static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
@@ -188,6 +192,7 @@ static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
     add(ns * hyper_kuf_records(p->maxN, (int)M));
     add(ns * hyper_kuf_records((int)M, (int)M));
   }
+  if (sgpr_chol_blocked(p)) { add(chol_inverse_blocked_workspace_bytes(p->M) / sizeof(double) + 1); add(chol_inverse_blocked_workspace_bytes(p->M) / sizeof(double) + 1); }
   return d;
 }
 
@@ -254,8 +259,18 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
     p->hyp = ar.take<double>(ns * hyper_kuf_records(p->maxN, (int)M));
     p->hyp_uu = ar.take<double>(ns * hyper_kuf_records((int)M, (int)M));
   }
+  p->chol_blocked = sgpr_chol_blocked(p);
+  if (p->chol_blocked) {
+    p->chol_ws_bytes = chol_inverse_blocked_workspace_bytes(p->M);
+    p->chol_ws_kuu = ar.take<char>(p->chol_ws_bytes);
+    p->chol_ws_b = ar.take<char>(p->chol_ws_bytes);
+  }
   if (!ar.ok) return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: arena exhausted");
   p->ws = workspace; p->ws_bytes = bytes;
+  if (p->chol_blocked) {
+    GP_CHECK(chol_inverse_blocked_prepare(p->h, p->L, p->W, p->M, p->M, p->chol_ws_kuu, p->chol_ws_bytes));
+    GP_CHECK(chol_inverse_blocked_prepare(p->h, p->LB, p->WB, p->M, p->M, p->chol_ws_b, p->chol_ws_bytes));
+  }
   return GP_OK;
 }
 
@@ -315,7 +330,8 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
     GP_CHECK(launch_sm_features(h, k, Z, M, X, N, feat));
     GP_CHECK(launch_kernel_build(h, k, Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, feat, 1));
   }
-  GP_CHECK(launch_cholesky_inverse_single(h, p->L, p->W, M, M));
+  if (p->chol_blocked) GP_CHECK(chol_inverse_blocked_run(h, M, M, p->chol_ws_kuu, p->chol_ws_bytes));
+  else GP_CHECK(launch_cholesky_inverse_single(h, p->L, p->W, M, M));
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
     GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat + (size_t)i * sgpr_feat_stride(p), 1, f32));
@@ -337,7 +353,8 @@ static gp_status sgpr_global(gp_sgpr_plan p, const double* params, int Ntotal, c
   gp_handle h = p->h;
   const int M = p->M;
   hipLaunchKernelGGL(sgpr_B_kernel, dim3(64), dim3(256), 0, h->stream, p->H, p->LB, M, params);
-  GP_CHECK(launch_cholesky_inverse_single(h, p->LB, p->WB, M, M));
+  if (p->chol_blocked) GP_CHECK(chol_inverse_blocked_run(h, M, M, p->chol_ws_b, p->chol_ws_bytes));
+  else GP_CHECK(launch_cholesky_inverse_single(h, p->LB, p->WB, M, M));
   hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->WB, p->LB, p->u, p->c, M, Ntotal, params,
                      p->P, desc->toff, desc->ktype, desc->km, p->reg, p->scal);
   GP_HIP_CHECK(h, hipGetLastError());
