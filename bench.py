@@ -255,6 +255,18 @@ def main():
                        "pitches_per_rank_max": -(-args.P // world), "elbo_final": rp["elbo_final"]}
         del rp
 
+    forward_only = None
+    if world == 1:
+        # forward-only ELBO evaluations per second as a secondary line (fresh batch + ELBO, no gradient, no Adam)
+        for _ in range(2):
+            model._elbo(False, sync=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model._elbo(False, sync=False)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t0
+        forward_only = {"value": args.steps / dtf, "unit": "ELBO evaluations/s", "ms_per_evaluation": dtf / args.steps * 1e3}
     kuf_alone = None
     if world == 1 and args.overlap != 0 and not args.no_f32_line:
         # the Kuf builds alone on the device (helper stream off), forward passes of the model just timed: in the step the
@@ -436,6 +448,8 @@ def main():
             "kernel_ms_per_step": {k: ms / args.steps for k, (ms, n) in timers.items()},
             "elbo_final": elbo_final,
         }
+        if forward_only is not None:
+            out["forward_only"] = forward_only
         if extra_pitch is not None:
             out["pitch_sharded"] = extra_pitch
         if cfg3 is not None:
