@@ -91,6 +91,21 @@ def _k1_closed_form(y, N, kern_act, kern_com, s2):
     return -0.5 * tot / s2 - 0.5 * N * (np.log(2 * np.pi) + np.log(s2))
 
 
+def test_cfg5_as_pdgp_five_sources_N65536_M512(gp_handle):
+    """configs[4] reads "5 sources x activation + component GPs", which sgpr_ss does not have: the same
+    size as a Pdgp with 5 pitches (10 latent GPs), float64 and float32 strips against the oracle"""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(65536, 512, 5, num_partials=5, seed=2)
+    ref = float(oracle_elbo(prob))
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    assert abs(got - ref) <= FULLSIZE_RTOL * abs(ref), (got, ref)
+    model = None
+    m32 = pdgp_from_problem(prob, handle=gp_handle, float_type=np.float32)
+    got32 = m32.compute_log_likelihood()
+    assert abs(got32 - ref) <= 2e-4 * abs(ref), (got32, ref)       # the stated float32 tolerance (tests/test_gpu_f32.py)
+
+
 def test_cfg4_windowed_N262144_twelve_pitches(gp_handle):
     """configs[3]: 12 pitches, N = 262144 'windowed', one window per GPU on 8 GPUs.  The reference cuts long audio
     into independent pieces that are fitted one after another (window_overlap.py:194-211 non-overlapping segments;
