@@ -124,6 +124,7 @@ class SgprWindowBatch(object):
         self._p_host = t.zeros(self.W, self.nparams, dtype=t.float64).pin_memory()
         self._g_host = t.zeros(self.W, self.nparams, dtype=t.float64).pin_memory()
         self._b_host = t.zeros(self.W, dtype=t.float64).pin_memory()
+        self._ev, self._pending = None, None
 
     def load(self, xs, ys, zs):
         """put `len(xs)` windows into the first slots (the others keep whatever they held: still valid problems)"""
@@ -134,8 +135,11 @@ class SgprWindowBatch(object):
         self.Z[:n].copy_(t.as_tensor(np.stack([np.asarray(z, dtype=np.float64).reshape(-1) for z in zs])))
         self.count = n
 
-    def evaluate(self, params_host, with_grad=True):
-        """params_host: (count, nparams) constrained parameter vectors -> (bound (count,), grad (count, nparams))"""
+    def submit(self, params_host, with_grad=True):
+        """enqueue one evaluation (parameter upload, the launch sequence, result download) and return at once; `collect`
+        waits for exactly this evaluation — not for whatever else is queued on the stream (another batch's evaluation:
+        `fit_windows_batched` keeps two batches in flight so that the host's L-BFGS-B stepping of one overlaps the
+        device's evaluation of the other)"""
         h = self.h
         n = self.count
         self._p_host[:n].copy_(h.torch.as_tensor(params_host))
@@ -146,9 +150,21 @@ class SgprWindowBatch(object):
         self._b_host[:n].copy_(self.bound[:n], non_blocking=True)
         if with_grad:
             self._g_host[:n].copy_(self.grad[:n], non_blocking=True)
-        h.torch.cuda.current_stream(h.device).synchronize()
-        h.check(h.lib.gp_sync(h.h))
+        if self._ev is None:
+            self._ev = h.torch.cuda.Event()
+        self._ev.record(h.torch.cuda.current_stream(h.device))
+        self._pending = (n, bool(with_grad))
+
+    def collect(self):
+        n, with_grad = self._pending
+        self._ev.synchronize()
+        self._pending = None
         return self._b_host[:n].numpy().copy(), (self._g_host[:n].numpy().copy() if with_grad else None)
+
+    def evaluate(self, params_host, with_grad=True):
+        """params_host: (count, nparams) constrained parameter vectors -> (bound (count,), grad (count, nparams))"""
+        self.submit(params_host, with_grad)
+        return self.collect()
 
     def _load_xnew(self, xnews, n_windows):
         t = self.h.torch
@@ -211,7 +227,7 @@ class SgprWindowBatch(object):
 
 
 def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default_reset, handle=None, rank=0,
-                        world_size=1, params0=None, predict=False):
+                        world_size=1, params0=None, predict=False, inflight=2):
     """fit_windows with the device work batched: `batch` windows go through every bound + gradient evaluation together
     (one launch sequence, gp_sgprb_bound_grad), each window driven by its own instance of scipy's L-BFGS-B routine
     (lbfgsb_batch.LbfgsbRC: the iterates of `model.optimize(maxiter=maxiter)` exactly, given the same f and g).
@@ -222,6 +238,8 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
     predict=True adds what SoSp.optimize computes after every window's optimisation (separation.py:300-313), batched the
     same way: "mean", "var" (predict_f at the window's frames, (N, 1)) and "smean", "svar" (predict_s: lists over the
     sources of (N, 1) arrays).
+    `inflight` batches are kept going at once (default 2: the host's stepping of one overlaps the device's evaluation of
+    the other; 1 = one after another).
     Returns a list over windows of dicts: bound, nfev, nit, variances, noise, params."""
     from . import _lib, lbfgsb_batch
     from .dist import window_assignment
@@ -243,7 +261,8 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
             hs = _lib.Handle(dev0.index, stream=s)
             try:
                 return fit_windows_batched(make_model, windows, maxiter=maxiter, batch=batch, reset=reset, handle=hs,
-                                           rank=rank, world_size=world_size, params0=params0, predict=predict)
+                                           rank=rank, world_size=world_size, params0=params0, predict=predict,
+                                           inflight=inflight)
             finally:
                 s.synchronize()
                 hs.close()
@@ -259,52 +278,87 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
         if np.asarray(windows[i][0]).size != N or np.asarray(windows[i][2]).size != M:
             raise ValueError("fit_windows_batched: all windows must have the same number of frames and inducing points")
     B = max(1, min(int(batch), len(mine)))
-    dev = SgprWindowBatch(model, B, N, M, handle=h)
     back = np.array([ps[i].transform.backward(np.atleast_1d(vals0[i]))[0] for i in free_idx])
     var_idx = [int(o) for o in np.cumsum([1] + [2 + 2 * int(k.num_partials) for k in model.kern.kern_list])[:-1]]
-    for b0 in range(0, len(mine), B):
-        ids = mine[b0:b0 + B]
-        n = len(ids)
+    chunks = [mine[b0:b0 + B] for b0 in range(0, len(mine), B)]
+    # Two batches in flight, each on a device plan of its own: while the host steps the L-BFGS-B instances of one batch
+    # (setulb and the transforms: as long as a device evaluation at W = 256), the device evaluates the other.
+    nslots = min(int(inflight), len(chunks))
+    devs = [SgprWindowBatch(model, B, N, M, handle=h) for _ in range(max(1, nslots))]
+
+    class _Run(object):
+        pass
+
+    def start(dev, ids):
+        r = _Run()
+        r.dev, r.ids, r.n = dev, ids, len(ids)
         dev.load([windows[i][0] for i in ids], [windows[i][1] for i in ids], [windows[i][2] for i in ids])
-        base = np.tile(vals0, (n, 1))
+        r.base = np.tile(vals0, (r.n, 1))
         if params0 is not None:
-            base = np.stack([np.asarray(params0[i], dtype=np.float64) for i in ids])
-            x0s = [np.array([ps[j].transform.backward(np.atleast_1d(base[r, j]))[0] for j in free_idx]) for r in range(n)]
+            r.base = np.stack([np.asarray(params0[i], dtype=np.float64) for i in ids])
+            x0s = [np.array([ps[j].transform.backward(np.atleast_1d(r.base[q, j]))[0] for j in free_idx]) for q in range(r.n)]
         else:
-            x0s = [back.copy() for _ in range(n)]
-        runs = [lbfgsb_batch.LbfgsbRC(x0, maxiter=maxiter) for x0 in x0s]
-        Xf = np.stack(x0s)
-        active = list(range(n))
-        last_bound = np.zeros(n)
-        while active:
-            y, dy = SGPRSS._free_to_params(st, Xf)
-            pv = base.copy()
-            pv[:, free_idx] = y
-            bound, grad = dev.evaluate(pv)
-            nxt = []
-            for r in active:
-                g = -(grad[r, free_idx] * dy[r])
-                runs[r].give(-bound[r], g)
-                if runs[r].step():
-                    Xf[r] = runs[r].x
-                    nxt.append(r)
-            active = nxt
-        yfin, _ = SGPRSS._free_to_params(st, np.stack([r.x for r in runs]))
-        pfin = base.copy()
+            x0s = [back.copy() for _ in range(r.n)]
+        r.runs = [lbfgsb_batch.LbfgsbRC(x0, maxiter=maxiter) for x0 in x0s]
+        r.Xf = np.stack(x0s)
+        r.active = list(range(r.n))
+        submit(r)
+        return r
+
+    def submit(r):
+        y, r.dy = SGPRSS._free_to_params(st, r.Xf)
+        pv = r.base.copy()
+        pv[:, free_idx] = y
+        r.dev.submit(pv)
+
+    def advance(r):
+        """collect the evaluation in flight, step every active instance; True while the batch still needs evaluations"""
+        bound, grad = r.dev.collect()
+        nxt = []
+        for q in r.active:
+            g = -(grad[q, free_idx] * r.dy[q])
+            r.runs[q].give(-bound[q], g)
+            if r.runs[q].step():
+                r.Xf[q] = r.runs[q].x
+                nxt.append(q)
+        r.active = nxt
+        if nxt:
+            submit(r)
+        return bool(nxt)
+
+    def finish(r):
+        yfin, _ = SGPRSS._free_to_params(st, np.stack([q.x for q in r.runs]))
+        pfin = r.base.copy()
         pfin[:, free_idx] = yfin
-        for r, i in enumerate(ids):
-            results[i] = {"bound": -runs[r].fun, "nfev": runs[r].nfev, "nit": runs[r].nit,
-                          "variances": pfin[r, var_idx].copy(), "noise": float(pfin[r, 0]), "params": pfin[r].copy()}
+        for q, i in enumerate(r.ids):
+            results[i] = {"bound": -r.runs[q].fun, "nfev": r.runs[q].nfev, "nit": r.runs[q].nit,
+                          "variances": pfin[q, var_idx].copy(), "noise": float(pfin[q, 0]), "params": pfin[q].copy()}
         if predict:
-            fm, fv = dev.predict_f(pfin)
-            sm, sv = dev.predict_s(pfin)
-            for r, i in enumerate(ids):
-                results[i]["mean"], results[i]["var"] = fm[r].reshape(-1, 1), fv[r].reshape(-1, 1)
-                results[i]["smean"] = [sm[r, k].reshape(-1, 1) for k in range(sm.shape[1])]
-                results[i]["svar"] = [sv[r, k].reshape(-1, 1) for k in range(sv.shape[1])]
-    dev.close()
+            fm, fv = r.dev.predict_f(pfin)
+            sm, sv = r.dev.predict_s(pfin)
+            for q, i in enumerate(r.ids):
+                results[i]["mean"], results[i]["var"] = fm[q].reshape(-1, 1), fv[q].reshape(-1, 1)
+                results[i]["smean"] = [sm[q, k].reshape(-1, 1) for k in range(sm.shape[1])]
+                results[i]["svar"] = [sv[q, k].reshape(-1, 1) for k in range(sv.shape[1])]
+
+    pending = list(chunks)
+    live = []
+    for dev in devs:
+        if pending:
+            live.append(start(dev, pending.pop(0)))
+    while live:
+        for r in list(live):
+            if advance(r):
+                continue
+            finish(r)
+            live.remove(r)
+            if pending:
+                live.append(start(r.dev, pending.pop(0)))
+    for dev in devs:
+        dev.close()
     model._destroy()
     return results
+
 
 
 def merge_sources(results, ws, n):
