@@ -9,7 +9,7 @@ from . import _lib
 _lib.load_library()
 
 from .methods import (logistic, ilogistic, softplus, isoftplus, gaussfun, logistic_tf, softplus_tf,  # noqa: E402
-                      gaussfun_tf, midi2freq, freq2midi, norm)
+                      gaussfun_tf, midi2freq, freq2midi, norm, find_ideal_f0, readaudio, init_cparam)
 from . import param, kernels, matern12_spectral_mixture, likelihoods, conditionals, pdgp, sgpr_ss, synth, train  # noqa: E402,F401
 from .init_models import init_liv, init_iv  # noqa: E402,F401
 from .window_overlap import segmented, windowed, merged_mean, merged_variance  # noqa: E402,F401

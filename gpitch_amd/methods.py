@@ -80,6 +80,37 @@ def find_ideal_f0(string):
     return [midi2freq(midi) for name in string for midi in range(21, 109) if ("M%d" % midi) in name]
 
 
+def readaudio(fname, frames=-1, start=0, aug=False, scaled=False):
+    """methods.py:36-54: wav file -> (x, y, fs) with y (n,1) float64, x = linspace(0, (n-1)/fs, n) (n,1).
+    The reference reads through `soundfile.read` (float64 output: integer PCM divided by its full scale, float
+    files as stored); here the RIFF container is parsed by scipy.io.wavfile and scaled the same way.  Stereo is
+    averaged to mono (:40-41), `scaled` divides by max|y| (:43-47), `aug` prepends 1000 zeros (:48-50)."""
+    from scipy.io import wavfile
+    fs, data = wavfile.read(fname)
+    if data.dtype.kind == "i":
+        y = data.astype(np.float64) / float(2 ** (8 * data.dtype.itemsize - 1))
+    elif data.dtype.kind == "u":                      # 8-bit PCM is unsigned, centred on 128
+        y = (data.astype(np.float64) - 128.) / 128.
+    else:
+        y = data.astype(np.float64)
+    y = y[start:] if frames < 0 else y[start:start + frames]
+    if len(y.shape) == 1:
+        y = y.reshape(-1, 1)
+    if y.shape[1] == 2:  # convert to mono
+        y = np.mean(y, 1)
+    y = y.reshape(-1, 1)
+    if scaled:
+        beta = np.max(np.abs(y))
+        if beta == 0.:
+            beta = 1.
+        y /= beta
+    if aug:
+        y = np.append(np.zeros((1000, 1)), y).reshape(-1, 1)
+    n = y.size
+    x = np.linspace(0., (n - 1.) / fs, n).reshape(-1, 1)
+    return x, y, int(fs)
+
+
 def _fill_flat_steps(step):
     """First differences with every run of zeros replaced by a neighbouring non-zero slope: a leading run takes the
     slope that follows it, a trailing run the slope before it, an interior run (a flat top or bottom) the left slope

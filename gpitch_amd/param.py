@@ -203,6 +203,23 @@ class Parameterized(object):
             object.__setattr__(self, name, value)
 
 
+def sorted_params(obj):
+    """Every Param underneath `obj` in the order of GPflow 0.5's free-state vector (Parameterized.sorted_params /
+    get_free_state): children by attribute NAME, the items of a ParamList in list order.  This is the order of the `x`
+    and `jac` that Model.optimize returns and hands to callbacks (demos/notebooks/demo_modgp-real-audio.ipynb cell 9
+    prints them)."""
+    if isinstance(obj, Param):
+        return [obj]
+    out = []
+    if isinstance(obj, ParamList):
+        for it in obj:
+            out.extend(sorted_params(it))
+    elif isinstance(obj, Parameterized):
+        for name in sorted(k for k, v in obj.__dict__.items() if isinstance(v, (Param, ParamList, Parameterized))):
+            out.extend(sorted_params(obj.__dict__[name]))
+    return out
+
+
 def _collect(obj):
     if isinstance(obj, Param):
         return [obj]

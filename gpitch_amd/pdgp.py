@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from .likelihoods import MpdLik
 from .methods import logistic, logistic_tf, nlin_code
-from .param import MinibatchData, Param, ParamList, Parameterized, param_version
+from .param import MinibatchData, Param, ParamList, Parameterized, param_version, sorted_params
 from .train import AdamOptimizer, OptimizeResult
 
 jitter = 1e-6   # gpflow settings.numerics.jitter_level (pdgp.py:14)
@@ -199,11 +199,31 @@ class Pdgp(Parameterized):
             h.check(h.lib.gp_pdgp_set_grad_needs(self._plan, g, int(need_theta), int(not z.fixed)))
         h.check(h.lib.gp_transform_backward(h.h, self._params.data_ptr(), self._tcode.data_ptr(), self._nparams,
                                             self._free.data_ptr()))
+        self._packed_key = self._host_key()
+
+    def _host_key(self):
+        """what the packed device copy depends on: every Param value (param_version) and the `.fixed` flags"""
+        return (param_version(), tuple(p.fixed for _, p in self._segments()))
+
+    def _free_index(self):
+        """engine offsets of the entries of GPflow's free-state vector, in GPflow's order (param.sorted_params: Params by
+        attribute name, `.fixed` ones absent) — the `x` / `jac` layout of optimize(), its callback and _objective()"""
+        key = tuple(p.fixed for _, p in self._segments())
+        memo = self.__dict__.get("_free_index_memo")
+        if memo is None or memo[0] != key:
+            off = {id(p): o for o, p in self._segments()}
+            idx = [np.arange(off[id(p)], off[id(p)] + p.size) for p in sorted_params(self)
+                   if not p.fixed and id(p) in off]
+            idx = np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64)
+            memo = (key, idx, self._handle.torch.as_tensor(idx, device=self._handle.device))
+            self._free_index_memo = memo
+        return memo[1], memo[2]
 
     def _unpack(self):
         host = self._params.cpu().numpy()
         for off, p in self._segments():
             p.value = host[off:off + p.size]
+        self._packed_key = self._host_key()
 
     def _batch(self):
         """fresh minibatch (x and y generators are seeded identically so rows stay paired: pdgp.py:76-77)"""
@@ -305,23 +325,28 @@ class Pdgp(Parameterized):
     def _objective(self, x_free):
         """GPflow Model._objective: (-(ELBO), -grad wrt the free state) in float64"""
         h = self._handle
-        self._free.copy_(h.torch.as_tensor(np.asarray(x_free, dtype=np.float64)))
+        if self._plan is None or self.__dict__.get("_packed_key") != self._host_key():
+            self._pack()       # (inside optimize()'s loop the device copy is ahead of the host Params and is left alone)
+        idx, idx_dev = self._free_index()
+        xf = np.zeros(self._nparams)
+        xf[idx] = np.asarray(x_free, dtype=np.float64).reshape(-1)
+        self._free.index_copy_(0, idx_dev, h.torch.as_tensor(xf[idx]).to(h.device))
         h.check(h.lib.gp_transform_forward(h.h, self._free.data_ptr(), self._tcode.data_ptr(), self._nparams,
                                            self._params.data_ptr()))
         f = self._elbo(True)
         g = self._grad.cpu().numpy()
-        xf = np.asarray(x_free, dtype=np.float64)
-        # chain rule through each Param's transform (fixed Params drop out)
+        # chain rule through each Param's transform (fixed Params are not part of the free state)
         scale = np.zeros_like(g)
         for off, p in self._segments():
             if not p.fixed:
                 scale[off:off + p.size] = p.transform.dforward(xf[off:off + p.size])
         g = g * scale
-        return -f, -g
+        return -f, -g[idx]
 
     def get_free_state(self):
+        """GPflow Model.get_free_state: the non-fixed Params' unconstrained values, ordered by name"""
         self._pack()
-        return self._free.cpu().numpy()
+        return self._free.index_select(0, self._free_index()[1]).cpu().numpy()
 
     def optimize(self, method='L-BFGS-B', tol=None, callback=None, maxiter=1000, disp=False, **kw):
         """GPflow Model.optimize.  `method` is an AdamOptimizer token (demo-modgp.py:44-45) or a
@@ -343,10 +368,10 @@ class Pdgp(Parameterized):
                 if flag.value:
                     h.check(h.lib.gp_check_not_pd(h.h))     # raises NotPositiveDefiniteError with the pivot index
                 if callback is not None:
-                    callback(self._free.cpu().numpy())
+                    callback(self._free.index_select(0, self._free_index()[1]).cpu().numpy())
             h.check(h.lib.gp_check_not_pd(h.h))             # a failure in the last few steps, not polled yet
             # GPflow evaluates the returned `fun`/`jac` on a fresh minibatch (demo_modgp.ipynb:140-146)
-            x_final = self._free.cpu().numpy()
+            x_final = self._free.index_select(0, self._free_index()[1]).cpu().numpy()
             f, g = self._objective(x_final)
             self._unpack()
             if self._shard:
@@ -358,10 +383,11 @@ class Pdgp(Parameterized):
             # consistent across ranks without exchanging it
             raise NotImplementedError("a pitch-sharded Pdgp is trained with AdamOptimizer")
         from scipy.optimize import minimize
-        x0 = self._free.cpu().numpy()
+        idx_dev = self._free_index()[1]
+        x0 = self._free.index_select(0, idx_dev).cpu().numpy()
         res = minimize(self._objective, x0, jac=True, method=method, tol=tol, callback=callback,
                        options=dict(maxiter=maxiter, disp=disp))
-        self._free.copy_(h.torch.as_tensor(res.x))
+        self._free.index_copy_(0, idx_dev, h.torch.as_tensor(res.x).to(h.device))
         h.check(h.lib.gp_transform_forward(h.h, self._free.data_ptr(), self._tcode.data_ptr(), self._nparams,
                                            self._params.data_ptr()))
         self._unpack()

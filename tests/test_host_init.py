@@ -176,3 +176,25 @@ def test_merge_sources_is_the_reference_overlap_add_of_every_source():
         np.testing.assert_array_equal(out[k][0], window_overlap.merged_mean([r["smean"][k] for r in res], ws, n))
         np.testing.assert_array_equal(out[k][1], window_overlap.merged_variance([r["svar"][k] for r in res], ws, n))
         assert out[k][0].shape == (n, 1)
+
+
+def test_readaudio_matches_the_reference_reader_on_its_demo_recording(tmp_path):
+    """methods.py:36-54 through a float32 and a 16-bit file: samples as soundfile.read hands them out (float64; PCM
+    divided by full scale), the time axis of :53, mono mix-down, `scaled` and `aug`."""
+    from scipy.io import wavfile
+    import gpitch_amd
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "init_liv_real_audio.npz"))
+    y32, fs = d["y"], int(d["fs"])
+    f = str(tmp_path / "a.wav")
+    wavfile.write(f, fs, y32)
+    x, y, fs2 = gpitch_amd.readaudio(f)
+    assert fs2 == fs and y.dtype == np.float64 and y.shape == (y32.size, 1) == x.shape
+    np.testing.assert_array_equal(y[:, 0], y32.astype(np.float64))
+    np.testing.assert_array_equal(x[:, 0], np.linspace(0., (y32.size - 1.) / fs, y32.size))
+    pcm = np.round(y32[:4000] * 32767).astype(np.int16)
+    wavfile.write(f, fs, np.stack([pcm, pcm // 2], 1))                       # stereo PCM16
+    x, y, _ = gpitch_amd.readaudio(f, frames=1000, start=100, aug=True, scaled=True)
+    mono = np.mean(np.stack([pcm, pcm // 2], 1)[100:1100].astype(np.float64) / 32768., 1)
+    assert y.shape == (2000, 1) and np.all(y[:1000] == 0)
+    np.testing.assert_allclose(y[1000:, 0], mono / np.max(np.abs(mono)), rtol=0, atol=1e-15)
+    assert x[-1, 0] == (2000 - 1.) / fs
