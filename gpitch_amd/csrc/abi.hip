@@ -538,6 +538,17 @@ gp_status gp_poll_not_pd(gp_handle h, int32_t* flag) {
   return GP_OK;
 }
 
+// Asynchronous hand-over of the not-positive-definite status word: behind everything enqueued so far on the handle's
+// stream, copy {flag, pivot, matrix index, spare} into `host_status4` (pinned host memory of the caller) and clear the
+// device word — so the NEXT evaluation on this stream reports its own failures only.  The caller reads host_status4 once
+// an event recorded after this call has completed.  Used by the window-batched fit: one status snapshot per evaluation.
+gp_status gp_take_not_pd(gp_handle h, int32_t* host_status4) {
+  if (!h || !host_status4) return GP_ERR_BAD_ARG;
+  GP_HIP_CHECK(h, hipMemcpyAsync(host_status4, h->d_status, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  GP_HIP_CHECK(h, hipMemsetAsync(h->d_status, 0, 4 * sizeof(int32_t), h->stream));
+  return GP_OK;
+}
+
 gp_status gp_adam_step(gp_handle h, double* fs, double* params, const double* grad, const uint8_t* tcode, double* m,
                        double* v, int64_t n, int64_t t, double lr, double beta1, double beta2, double eps) {
   if (!h) return GP_ERR_BAD_ARG;

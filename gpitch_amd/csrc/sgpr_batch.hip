@@ -41,7 +41,7 @@ struct gp_sgprb_plan_s {
   enum { F_A = 0, F_H, F_U, Q_BINV, Q_UBAR, Q_EH, Q_WBAR, Q_LU, Q_RANK1, Q_R, Q_ALPHA, Q_G, Q_T2, Q_LBAR, Q_P, Q_T3, Q_S, Q_COUNT };
   size_t off_prob[Q_COUNT] = {0};
   // cache: what the uploaded descriptors describe
-  const double *k_params = nullptr, *k_X = nullptr, *k_Y = nullptr, *k_Z = nullptr; double* k_grad = nullptr;
+  const double *k_params = nullptr, *k_X = nullptr, *k_Y = nullptr, *k_Z = nullptr; double *k_grad = nullptr, *k_bound = nullptr;
   bool desc_valid = false;
   hipGraphExec_t gexec = nullptr; int graphs = 1; int64_t n_eager = 0, n_captured = 0, n_replayed = 0; int graph_count = -1;
   int np_uf = 0, np_uu = 0;
@@ -491,7 +491,8 @@ gp_status gp_sgprb_bound_grad(gp_sgprb_plan_t p, const double* params, const dou
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_sgprb_bound_grad: workspace not set");
   if (!params || !X || !Y || !Z || !bound_dev || count < 1 || count > p->W)
     return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgprb_bound_grad: bad argument");
-  const bool same = p->desc_valid && p->k_params == params && p->k_X == X && p->k_Y == Y && p->k_Z == Z && p->k_grad == grad;
+  const bool same = p->desc_valid && p->k_params == params && p->k_X == X && p->k_Y == Y && p->k_Z == Z && p->k_grad == grad &&
+                    p->k_bound == bound_dev;   // (bound_dev is baked into the captured finish launch)
   if (!same) {
     if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
     GP_CHECK(sgb_upload(p, params, X, Y, Z, grad ? grad : (double*)p->wsd));
@@ -504,7 +505,7 @@ gp_status gp_sgprb_bound_grad(gp_sgprb_plan_t p, const double* params, const dou
       for (size_t i = 0; i < (size_t)p->W * p->P; i++) { fin[i].np_uf = p->np_uf; fin[i].np_uu = p->np_uu; }
     }
     GP_HIP_CHECK(h, hipMemcpyAsync(p->d_desc, p->h_desc.data(), p->desc_bytes, hipMemcpyHostToDevice, h->stream));
-    p->k_params = params; p->k_X = X; p->k_Y = Y; p->k_Z = Z; p->k_grad = grad; p->desc_valid = true;
+    p->k_params = params; p->k_X = X; p->k_Y = Y; p->k_Z = Z; p->k_grad = grad; p->k_bound = bound_dev; p->desc_valid = true;
     GP_CHECK(sgb_enqueue(p, count, bound_dev, grad != nullptr));
     p->n_eager++;
     return GP_OK;

@@ -22,9 +22,40 @@ except Exception:      # pragma: no cover
     _SCIPY_OK = False
 
 
+_SELF_CHECK = [None]
+
+
+def _self_check():
+    """`setulb` is private: a scipy that keeps the name but changes the argument list or the task codes would fail or,
+    worse, iterate differently.  Minimise a 2-D Rosenbrock function through LbfgsbRC and through scipy.optimize.minimize:
+    x, fun, nit and nfev must be identical, otherwise this module reports itself unavailable (callers use fit_windows)."""
+    from scipy.optimize import minimize
+
+    def fg(x):
+        f = 100. * (x[1] - x[0] ** 2) ** 2 + (1. - x[0]) ** 2
+        g = np.array([-400. * x[0] * (x[1] - x[0] ** 2) - 2. * (1. - x[0]), 200. * (x[1] - x[0] ** 2)])
+        return f, g
+    x0 = np.array([-1.2, 1.0])
+    try:
+        ref = minimize(fg, x0, jac=True, method="L-BFGS-B", options=dict(maxiter=25))
+        run = LbfgsbRC(x0, maxiter=25)
+        guard = 0
+        while run.step() and guard < 1000:
+            run.give(*fg(run.x))
+            guard += 1
+        return bool(np.array_equal(run.x, ref.x) and run.fun == ref.fun and run.nit == ref.nit and run.nfev == ref.nfev)
+    except Exception:
+        return False
+
+
 def available():
-    """True when the installed scipy exposes the reverse-communication routine this module drives"""
-    return bool(_SCIPY_OK)
+    """True when the installed scipy exposes the reverse-communication routine this module drives AND a small
+    self-check reproduces scipy.optimize.minimize's iterates exactly (verified on scipy 1.15.x)"""
+    if not _SCIPY_OK:
+        return False
+    if _SELF_CHECK[0] is None:
+        _SELF_CHECK[0] = _self_check()
+    return _SELF_CHECK[0]
 
 
 class LbfgsbRC(object):

@@ -124,7 +124,9 @@ class SgprWindowBatch(object):
         self._p_host = t.zeros(self.W, self.nparams, dtype=t.float64).pin_memory()
         self._g_host = t.zeros(self.W, self.nparams, dtype=t.float64).pin_memory()
         self._b_host = t.zeros(self.W, dtype=t.float64).pin_memory()
+        self._st_host = t.zeros(4, dtype=t.int32).pin_memory()      # not-positive-definite status of the evaluation in flight
         self._ev, self._pending = None, None
+        self.last_status = (0, 0, 0)
 
     def load(self, xs, ys, zs):
         """put `len(xs)` windows into the first slots (the others keep whatever they held: still valid problems)"""
@@ -150,21 +152,35 @@ class SgprWindowBatch(object):
         self._b_host[:n].copy_(self.bound[:n], non_blocking=True)
         if with_grad:
             self._g_host[:n].copy_(self.grad[:n], non_blocking=True)
+        # this evaluation's own status word, cleared behind the copy: a failed Cholesky is reported by the evaluation that
+        # caused it (status[2] = window slot) and never leaks into the next batch / the next user of the handle
+        h.check(h.lib.gp_take_not_pd(h.h, self._st_host.data_ptr()))
         if self._ev is None:
             self._ev = h.torch.cuda.Event()
         self._ev.record(h.torch.cuda.current_stream(h.device))
         self._pending = (n, bool(with_grad))
 
     def collect(self):
+        """(bound, grad) of the evaluation in flight.  `self.last_status` = (flag, pivot, window slot) of the FIRST Cholesky
+        failure in it (flag 0: none): that window's numbers — and possibly those of other windows that failed in the same
+        evaluation, the device word keeps the first only — are not a bound; `fit_windows_batched` retires the window and
+        evaluates again, `evaluate` raises."""
         n, with_grad = self._pending
         self._ev.synchronize()
         self._pending = None
+        st = self._st_host.numpy()
+        self.last_status = (int(st[0]), int(st[1]), int(st[2]))
         return self._b_host[:n].numpy().copy(), (self._g_host[:n].numpy().copy() if with_grad else None)
 
     def evaluate(self, params_host, with_grad=True):
         """params_host: (count, nparams) constrained parameter vectors -> (bound (count,), grad (count, nparams))"""
         self.submit(params_host, with_grad)
-        return self.collect()
+        out = self.collect()
+        if self.last_status[0]:
+            from ._lib import GP_ERR_NOT_PD, NotPositiveDefiniteError
+            raise NotPositiveDefiniteError(GP_ERR_NOT_PD, "Cholesky failed: window %d of the batch is not positive "
+                                           "definite (pivot %d)" % (self.last_status[2], self.last_status[1]))
+        return out
 
     def _load_xnew(self, xnews, n_windows):
         t = self.h.torch
@@ -240,7 +256,13 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
     sources of (N, 1) arrays).
     `inflight` batches are kept going at once (default 2: the host's stepping of one overlaps the device's evaluation of
     the other; 1 = one after another).
-    Returns a list over windows of dicts: bound, nfev, nit, variances, noise, params."""
+    `reset` is evaluated ONCE, on this rank's first window, to obtain the starting parameter values of every window (the
+    default reset and AMT.reset_model set the same values for every window); per-window starting values go in `params0`.
+    The template model must have no mean function and float64 strips (NotImplementedError otherwise).
+    A window whose Kuu or B loses positive definiteness during its fit (the reference: tf.cholesky raises out of that
+    window's optimize()) is retired with results[i]["error"] set, bound = nan and its starting parameters; the other
+    windows of the batch are unaffected (their evaluation is repeated without it).
+    Returns a list over windows of dicts: bound, nfev, nit, variances, noise, params [, error]."""
     from . import _lib, lbfgsb_batch
     from .dist import window_assignment
     from .sgpr_ss import SGPRSS
@@ -268,6 +290,14 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
                 hs.close()
     h = handle
     model = make_model(h)
+    # what the batched plan takes from the template model: kernel structure, `reg`, the parameter values after ONE
+    # reset() (on this rank's first window).  It does not carry a mean function or float32 strips: refuse, do not drop.
+    if getattr(model, "mean_function", None) is not None and type(model.mean_function).__name__ != "Zero":
+        raise NotImplementedError("fit_windows_batched: the template model has a mean_function; the batched plan has "
+                                  "none (use fit_windows)")
+    if getattr(model, "_bits", 64) != 64:
+        raise NotImplementedError("fit_windows_batched runs in float64; the template model asks for float32 strips "
+                                  "(use fit_windows)")
     x0w, y0w, z0w = windows[mine[0]][:3]
     reset(model, x0w, y0w, z0w)
     st = model._objective_setup()
@@ -302,6 +332,7 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
         r.runs = [lbfgsb_batch.LbfgsbRC(x0, maxiter=maxiter) for x0 in x0s]
         r.Xf = np.stack(x0s)
         r.active = list(range(r.n))
+        r.failed = {}
         submit(r)
         return r
 
@@ -309,11 +340,27 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
         y, r.dy = SGPRSS._free_to_params(st, r.Xf)
         pv = r.base.copy()
         pv[:, free_idx] = y
+        for q in r.failed:                  # retired windows ride along at their (valid) starting parameters
+            pv[q] = r.base[q]
         r.dev.submit(pv)
 
     def advance(r):
         """collect the evaluation in flight, step every active instance; True while the batch still needs evaluations"""
         bound, grad = r.dev.collect()
+        flag, pivot, slot = r.dev.last_status
+        if flag:
+            # TF raises InvalidArgumentError out of the one session.run whose tf.cholesky failed and the reference's window
+            # loop dies there (transcription.py:283); here that window alone is retired with the error, and the evaluation
+            # is repeated for the others (the device word names the first failure only: another window may have failed in
+            # the same evaluation — it is found by the repeat)
+            if slot in r.failed or not (0 <= slot < r.n):
+                raise _lib.NotPositiveDefiniteError(_lib.GP_ERR_NOT_PD, "Cholesky failed in window slot %d (pivot %d) at "
+                                                    "its starting parameters" % (slot, pivot))
+            r.failed[slot] = "Cholesky failed: not positive definite (pivot %d) at evaluation %d" % (pivot, r.runs[slot].nfev + 1)
+            r.active = [q for q in r.active if q != slot]
+            if r.active:
+                submit(r)
+            return bool(r.active)
         nxt = []
         for q in r.active:
             g = -(grad[q, free_idx] * r.dy[q])
@@ -330,13 +377,19 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
         yfin, _ = SGPRSS._free_to_params(st, np.stack([q.x for q in r.runs]))
         pfin = r.base.copy()
         pfin[:, free_idx] = yfin
+        for q in r.failed:
+            pfin[q] = r.base[q]
         for q, i in enumerate(r.ids):
             results[i] = {"bound": -r.runs[q].fun, "nfev": r.runs[q].nfev, "nit": r.runs[q].nit,
                           "variances": pfin[q, var_idx].copy(), "noise": float(pfin[q, 0]), "params": pfin[q].copy()}
+            if q in r.failed:
+                results[i].update(error=r.failed[q], bound=float("nan"))
         if predict:
             fm, fv = r.dev.predict_f(pfin)
             sm, sv = r.dev.predict_s(pfin)
             for q, i in enumerate(r.ids):
+                if q in r.failed:           # (predicted at the starting parameters only to keep the batch whole)
+                    continue
                 results[i]["mean"], results[i]["var"] = fm[q].reshape(-1, 1), fv[q].reshape(-1, 1)
                 results[i]["smean"] = [sm[q, k].reshape(-1, 1) for k in range(sm.shape[1])]
                 results[i]["svar"] = [sv[q, k].reshape(-1, 1) for k in range(sv.shape[1])]

@@ -268,6 +268,12 @@ gp_status gp_transform_backward(gp_handle h, const double* params, const uint8_t
  * call that returns a host scalar) then gives GP_ERR_NOT_PD with the pivot index and clears the flag. */
 gp_status gp_poll_not_pd(gp_handle h, int32_t* flag);
 gp_status gp_check_not_pd(gp_handle h);
+/* gp_take_not_pd: asynchronous per-evaluation snapshot — behind everything enqueued so far, copies the device status
+ * word {flag, pivot index, matrix index (= window slot in a gp_sgprb_* batch), spare} into host_status4 (pinned host
+ * memory, read it after an event recorded behind this call) and clears the device word, so a failure is reported by the
+ * evaluation that caused it and does not leak into the next user of the handle.  Replaces what the reference gets from
+ * TF raising InvalidArgumentError inside the one session.run that failed (transcription.py:283 per window). */
+gp_status gp_take_not_pd(gp_handle h, int32_t* host_status4);
 gp_status gp_adam_step(gp_handle h, double* free_state, double* params, const double* grad,
                        const uint8_t* tcode, double* m, double* v, int64_t n, int64_t t, double lr,
                        double beta1, double beta2, double eps);

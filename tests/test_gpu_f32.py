@@ -173,3 +173,35 @@ def test_f32_sgpr_window_sizes(gp_handle, N, M, P):
     got = m.build_likelihood()
     ref = orc.sgpr_bound(X, Y, Z, kl, 0.3)
     assert abs(got - ref) <= ELBO_RTOL * abs(ref), (got, ref)
+
+
+def test_f32_adam_trajectory_stays_with_the_f64_one_on_cfg3(gp_handle):
+    """BASELINE configs[2] (N=32768, M=256, P=12, m=5) trained for 50 full-batch Adam steps (lr 0.0025, za / zc fixed as in
+    demo-modgp.py:40-41) with float32 strips and with float64: the same index stream (RandomState(0)), so the two runs
+    differ by the strips' precision only.  STATED BOUNDS after 50 steps (measured in brackets): `fun` 5e-5 relative (3.6e-6),
+    activation lengthscales 2e-4 relative (2.0e-5; they move by 6.5e-2), every hyper-parameter 2e-4 relative (2.0e-5), q_mu 1e-2 of
+    its largest entry (2.5e-3)."""
+    import gpitch_amd
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(32768, 256, 12, num_partials=5, seed=1)
+    out = {}
+    for ft in (np.float32, np.float64):
+        m = _model(prob, gp_handle, float_type=ft)
+        m.za.fixed = True
+        m.zc.fixed = True
+        res = m.optimize(method=gpitch_amd.train.AdamOptimizer(0.0025), maxiter=50)
+        out[ft] = dict(fun=res.fun, ls_act=np.array([k.lengthscales.value[0] for k in m.kern_act]),
+                       hyp=np.concatenate([k.theta() for k in list(m.kern_act) + list(m.kern_com)] +
+                                          [m.likelihood.variance.value]),
+                       q_mu=np.concatenate([q.value.ravel() for q in list(m.q_mu_act) + list(m.q_mu_com)]))
+        del m
+    a, b = out[np.float32], out[np.float64]
+    d_fun = abs(a["fun"] - b["fun"]) / abs(b["fun"])
+    d_ls = np.max(np.abs(a["ls_act"] - b["ls_act"]) / b["ls_act"])
+    d_hyp = np.max(np.abs(a["hyp"] - b["hyp"]) / np.abs(b["hyp"]))
+    d_q = np.max(np.abs(a["q_mu"] - b["q_mu"])) / np.max(np.abs(b["q_mu"]))
+    moved = np.max(np.abs(b["ls_act"] - 1.0))
+    print("50 Adam steps f32 vs f64: fun %.2e, activation lengthscales %.2e (they moved %.2e), hyper-parameters %.2e, q_mu %.2e"
+          % (d_fun, d_ls, moved, d_hyp, d_q))
+    assert moved > 0.05                      # the lengthscales did train (50 steps x lr 0.0025 on the free state)
+    assert d_fun <= 5e-5 and d_ls <= 2e-4 and d_hyp <= 2e-4 and d_q <= 1e-2

@@ -151,3 +151,26 @@ def test_cfg4_windowed_N262144_twelve_pitches(gp_handle):
     got = model.compute_log_likelihood()
     ref = float(oracle_elbo(prob))
     assert abs(got - ref) <= FULLSIZE_RTOL * abs(ref), (got, ref)
+
+
+def test_headline_launch_against_the_oracle_N32768_M512_P12_m20(gp_handle):
+    """The workload bench.py times (make_problem(32768, 512, 12, num_partials=20, seed=0): 4 x 4 tile grid x 24 latent GPs in
+    every strip launch, NON-trivial q_mu / q_sqrt so both big products contribute): forward ELBO against the oracle's numpy
+    pass over the same arrays, and one pitch's posterior moments / source mean (pdgp.py:190-208) against the oracle's
+    conditionals for that pitch."""
+    from gpitch_amd.synth import make_problem
+    from oracle import gpflow05 as orc
+    prob = make_problem(32768, 512, 12, num_partials=20, seed=0)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    got = model.compute_log_likelihood()
+    ref = float(oracle_elbo(prob))
+    print("headline ELBO: HIP %.12e oracle %.12e relative difference %.2e" % (got, ref, abs(got / ref - 1)))
+    assert abs(got - ref) <= FULLSIZE_RTOL * abs(ref), (got, ref)
+    p = 7
+    xt = prob["x"][::8].copy()
+    ma, va, mc, vc, ms = model.predict_act_n_com(xt)
+    r = orc.pdgp_predict_act_n_com(xt, [prob["za"][p]], [prob["zc"][p]], [prob["kern_act"][p]], [prob["kern_com"][p]],
+                                   [prob["q_mu_act"][p]], [prob["q_sqrt_act"][p]], [prob["q_mu_com"][p]],
+                                   [prob["q_sqrt_com"][p]])
+    for got_l, ref_l in zip((ma, va, mc, vc, ms), r):
+        np.testing.assert_allclose(got_l[p], ref_l[0], rtol=0, atol=1e-7 * max(np.abs(ref_l[0]).max(), 1e-3))

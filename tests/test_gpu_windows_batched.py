@@ -190,3 +190,96 @@ def test_batched_prediction_argument_and_failure_paths(gp_handle):
     m1, v1 = one.predict_f(wins[1][0])
     np.testing.assert_allclose(fm[1], m1[:, 0], rtol=0, atol=1e-10 * np.abs(m1).max())
     dev.close()
+
+
+def test_a_window_that_turns_not_positive_definite_mid_fit_is_retired_alone(gp_handle, monkeypatch):
+    """a failed Cholesky inside a batched fit must not hand finite garbage to L-BFGS-B.  The evaluation's own
+    status word comes down with its results; the failing window is retired with results[i]["error"], the others finish
+    exactly as in a clean run, the flag does not leak to the next user of the handle, and predict=True still works."""
+    from gpitch_amd import windows as W
+    wins = _windows(6, 801, 32, 2, seed0=21)
+    data = [(w[0], w[1], w[2]) for w in wins]
+
+    def make(h):
+        return _model(*wins[0][:3], wins[0][3], 1.0, h)
+    clean = W.fit_windows_batched(make, data, maxiter=6, batch=6, handle=None, predict=True, inflight=1)
+    assert all("error" not in r for r in clean)
+    real_submit = W.SgprWindowBatch.submit
+    calls = {"n": 0}
+
+    def bad_submit(self, params_host, with_grad=True):
+        calls["n"] += 1
+        p = np.array(params_host, dtype=np.float64, copy=True)
+        if calls["n"] == 3:                    # the third evaluation of the fit: window slot 4 gets a negative kernel variance
+            p[4, 1] = -3.0                     # -> its Kuu is negative definite
+        return real_submit(self, p, with_grad)
+    monkeypatch.setattr(W.SgprWindowBatch, "submit", bad_submit)
+    res = W.fit_windows_batched(make, data, maxiter=6, batch=6, handle=None, predict=True, inflight=1)
+    monkeypatch.setattr(W.SgprWindowBatch, "submit", real_submit)
+    assert "error" in res[4] and "positive definite" in res[4]["error"] and np.isnan(res[4]["bound"])
+    assert "mean" not in res[4]
+    for i in (0, 1, 2, 3, 5):
+        assert "error" not in res[i]
+        assert res[i]["bound"] == clean[i]["bound"] and res[i]["nfev"] == clean[i]["nfev"]
+        np.testing.assert_array_equal(res[i]["params"], clean[i]["params"])
+        np.testing.assert_array_equal(res[i]["mean"], clean[i]["mean"])
+    # nothing left behind on the default handle either: a Pdgp Adam loop on it would freeze at step 1 otherwise
+    gp_handle.check(gp_handle.lib.gp_check_not_pd(gp_handle.h))
+
+
+def test_evaluate_raises_for_a_bad_window_and_a_new_bound_buffer_is_not_served_from_the_old_graph(gp_handle):
+    """(i) SgprWindowBatch.evaluate reports a failed Cholesky instead of returning numbers; (ii) ADVICE r2: predict_f runs
+    the forward pass with its own bound buffer — a following evaluate() with the same window count must write self.bound,
+    not replay the graph captured for predict_f's address."""
+    from gpitch_amd import _lib
+    from gpitch_amd.windows import SgprWindowBatch
+    import torch
+    N, M, P = 600, 24, 2
+    wins = _windows(3, N, M, P, seed0=8)
+    s = torch.cuda.Stream(device=gp_handle.device)
+    with torch.cuda.stream(s):
+        h = _lib.Handle(gp_handle.device.index, stream=s)         # a stream of its own: graphs are recorded
+        tmpl = _model(*wins[0][:3], wins[0][3], 0.3, h)
+        dev = SgprWindowBatch(tmpl, 3, N, M, handle=h)
+        dev.load([w[0] for w in wins], [w[1] for w in wins], [w[2] for w in wins])
+        pv = np.stack([_params_vector(0.3, w[3]) for w in wins])
+        bad = pv.copy()
+        bad[2, 1] = -3.0
+        with pytest.raises(_lib.NotPositiveDefiniteError, match="window 2"):
+            dev.evaluate(bad)
+        b0, _ = dev.evaluate(pv, with_grad=False)                 # the flag was cleared with the failing evaluation
+        for _ in range(3):                                        # eager, captured, replayed — at predict_f's bound address
+            dev.predict_f(pv)
+        pv2 = pv.copy()
+        pv2[:, 0] = 0.45
+        b1, _ = dev.evaluate(pv2, with_grad=False)
+        for i, w in enumerate(wins):
+            ref = orc.sgpr_bound(w[0], w[1], w[2], w[3], 0.45)
+            assert abs(b1[i] - ref) <= 1e-9 * abs(ref), (i, b1[i], ref, b0[i])
+        dev.close()
+        tmpl._destroy()
+        s.synchronize()
+        h.close()
+
+
+def test_fit_windows_batched_refuses_what_it_would_silently_drop(gp_handle):
+    from gpitch_amd import mean_functions
+    from gpitch_amd.windows import fit_windows_batched
+    wins = _windows(2, 400, 16, 2, seed0=2)
+    data = [(w[0], w[1], w[2]) for w in wins]
+    from gpitch_amd.sgpr_ss import SGPRSS
+    from gpitch_amd.synth import kernels_from_problem
+
+    def make_mf(h):
+        m = _model(*wins[0][:3], wins[0][3], 1.0, h)
+        object.__setattr__(m, "mean_function", mean_functions.Constant(0.1))
+        return m
+    with pytest.raises(NotImplementedError, match="mean_function"):
+        fit_windows_batched(make_mf, data, maxiter=2, batch=2)
+
+    def make_f32(h):
+        m = _model(*wins[0][:3], wins[0][3], 1.0, h)
+        m._bits = 32
+        return m
+    with pytest.raises(NotImplementedError, match="float64"):
+        fit_windows_batched(make_f32, data, maxiter=2, batch=2)
