@@ -31,13 +31,15 @@ def build_model(args, rank):
     from gpitch_amd.pdgp import Pdgp
     from gpitch_amd.synth import make_problem, pdgp_from_problem
     ft = np.float32 if args.float_type == "f32" else np.float64
-    if args.shard == "pitch":
-        # ONE model over all ranks: same problem everywhere, rank r holds pitches p = r (mod world)
+    if args.shard in ("pitch", "gp"):
+        # ONE model over all ranks: same problem everywhere; rank r holds pitches p = r (mod world) ("pitch": both GPs of a
+        # pitch, all-reduce of 3N+1) or latent GPs g = r (mod world) ("gp": all-gather of (fmean, fvar) per GP)
         world = int(os.environ.get("WORLD_SIZE", "1"))
         prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=0)
         import torch.distributed as tdist
         grouped = world > 1 or (tdist.is_available() and tdist.is_initialized())     # (a one-rank group: the RCCL rehearsal)
-        model = pdgp_from_problem(prob, shard=(rank, world) if grouped else None, float_type=ft)
+        sh = ((rank, world) if args.shard == "pitch" else ("gp", rank, world)) if grouped else None
+        model = pdgp_from_problem(prob, shard=sh, float_type=ft)
     else:
         prob = make_problem(args.N, args.M, args.P, num_partials=args.partials, seed=rank)
         model = pdgp_from_problem(prob, float_type=ft)
@@ -202,10 +204,11 @@ def main():
     ap.add_argument("--cpu-full", type=int, default=0,
                     help="also time this many whole P-pitch CPU steps (validates the 1/P scaling; ~1 min each)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--shard", choices=["window", "pitch"], default="window",
+    ap.add_argument("--shard", choices=["window", "pitch", "gp"], default="window",
                     help="window: one independent P-pitch window per GPU (weak scaling, scalar all-reduce only); "
                          "pitch: ONE P-pitch model spread over the GPUs, one all-reduce of 3N+1 doubles per step "
-                         "(strong scaling, ceiling P / ceil(P / gpus))")
+                         "(strong scaling, ceiling P / ceil(P / gpus)); gp: ONE model with its 2P latent GPs dealt over the "
+                         "GPUs, one all-gather of (fmean, fvar) per GP per step (strong scaling, ceiling 2P / ceil(2P / gpus))")
     ap.add_argument("--overlap", type=int, choices=[0, 1, 2], default=2,
                     help="gp_pdgp_set_overlap level: 0 one stream (clean single-kernel timings), 1 Kuu-side work on the "
                          "helper stream, 2 (library default) also H = A D A^T next to Kuf_bar")
@@ -243,17 +246,27 @@ def main():
 
     res = run_timed(args, args.shard, rank, dist)
     model, h, elapsed, elbo_final, timers = res["model"], res["handle"], res["elapsed"], res["elbo_final"], res["timers"]
-    n_local = len(model._local)      # pitches in this rank's launches
-    extra_pitch = None
+    local_gps = model._gps()         # latent GPs in this rank's launches
+    n_act_local = sum(1 for g in local_gps if any(g[0] is k for k in model.kern_act))
+    n_com_local = len(local_gps) - n_act_local
+    extra_pitch = extra_gp = None
     if world > 1 and args.shard == "window" and not args.no_pitch_line:
-        # the same job as ONE model spread over the ranks (strong scaling): an extra key of the same JSON line
+        # the same job as ONE model spread over the ranks (strong scaling): extra keys of the same JSON line
         model = res = None
         torch.cuda.empty_cache()
         rp = run_timed(args, "pitch", rank, dist)
         extra_pitch = {"value": args.steps / rp["elapsed"], "unit": "steps/s", "ms_per_step": rp["elapsed"] / args.steps * 1e3,
                        "scaling": "strong", "exchange": "one all-reduce of 3N+1 doubles per step",
-                       "pitches_per_rank_max": -(-args.P // world), "elbo_final": rp["elbo_final"]}
+                       "pitches_per_rank_max": -(-args.P // world), "ceiling_x": args.P / float(-(-args.P // world)),
+                       "elbo_final": rp["elbo_final"]}
         del rp
+        torch.cuda.empty_cache()
+        rg = run_timed(args, "gp", rank, dist)
+        extra_gp = {"value": args.steps / rg["elapsed"], "unit": "steps/s", "ms_per_step": rg["elapsed"] / args.steps * 1e3,
+                    "scaling": "strong", "exchange": "one all-gather of 2N doubles per latent GP (+ the KL scalar) per step",
+                    "latent_gps_per_rank_max": -(-2 * args.P // world),
+                    "ceiling_x": 2 * args.P / float(-(-2 * args.P // world)), "elbo_final": rg["elbo_final"]}
+        del rg
 
     forward_only = None
     if world == 1:
@@ -346,8 +359,8 @@ def main():
         cfg3["dtype"] = "f32"
         cfg3["speedup_over_f64"] = cfg3["f32"]["value"] / cfg3["f64"]["value"]
     if rank == 0:
-        pitch = args.shard == "pitch" and world > 1
-        G, M, N, T = 2 * n_local, args.M, args.N, 8      # latent GPs in this rank's launches
+        pitch = args.shard in ("pitch", "gp") and world > 1          # ONE model over the ranks (strong scaling)
+        G, M, N, T = len(local_gps), args.M, args.N, 8      # latent GPs in this rank's launches
         m2n = float(M) * M * N
         # algorithmic flops per step (SURVEY §8d / DESIGN.md) and per launch: a product is one launch over all 2P latent
         # GPs, except Kuf_bar, which is issued per kernel family (two launches of 12 GPs each at the default overlap
@@ -398,7 +411,7 @@ def main():
             ms, n = timers[name]
             if n:
                 # one launch builds the Kuf strips of a whole kernel family (all P activation or all P component GPs)
-                gps = max(1, int(round(n_local * args.steps / float(n))))
+                gps = max(1, n_act_local if name == "kuf_build" else n_com_local)
                 byts = gps * (T * (float(M) * N + N + M) + T * 2.0 * mm * (M + N))
                 a = byts / (ms / n * 1e-3) / 1e9
                 kuf[name] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
@@ -435,10 +448,13 @@ def main():
                                    "(2P=%d latent GPs), m=%d partials, %s, full batch; %s"
                                    % (N, M, args.P, 2 * args.P, args.partials,
                                       "float32 strips and strip products (float64 Kuu / reductions)" if f32 else "float64",
-                                      "one model pitch-sharded over the GPUs (all-reduce of 3N+1 doubles per step)"
+                                      ("one model pitch-sharded over the GPUs (all-reduce of 3N+1 doubles per step)"
+                                       if args.shard == "pitch" else
+                                       "one model, its 2P latent GPs dealt over the GPUs (all-gather of (fmean, fvar) per step)")
                                       if pitch else "one independent window per GPU"),
                        "N": N, "M": M, "P": args.P, "partials": args.partials, "whiten": True,
-                       "parallelism": ("pitch-sharded x%d" if pitch else "window-per-gpu x%d") % world,
+                       "parallelism": (("pitch-sharded x%d" if args.shard == "pitch" else "gp-sharded x%d") if pitch
+                                       else "window-per-gpu x%d") % world,
                        "overlap_level": args.overlap},
             "roofline": roof,
             "mfma_frac_step": {"algorithmic_flops_per_step": step_flops, "achieved": step_tf, "unit": "TFLOP/s",
@@ -452,6 +468,8 @@ def main():
             out["forward_only"] = forward_only
         if extra_pitch is not None:
             out["pitch_sharded"] = extra_pitch
+        if extra_gp is not None:
+            out["gp_sharded"] = extra_gp
         if cfg3 is not None:
             out["cfg3_fp32"] = cfg3
         if world == 1 and not args.no_cpu:

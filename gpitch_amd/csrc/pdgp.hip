@@ -29,19 +29,29 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
 
 extern "C" {
 
-gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* out) {
+static gp_status pdgp_create_impl(gp_handle h, const gp_pdgp_config* cfg, const int32_t* gp_index, int32_t count,
+                                  gp_pdgp_plan* out) {
   if (!h || !out) return GP_ERR_BAD_ARG;
   *out = nullptr;
   if (!cfg || cfg->num_sources < 1 || cfg->max_batch < 1 || !cfg->M_act || !cfg->M_com || !cfg->kern_type_act ||
       !cfg->kern_type_com || !cfg->partials_act || !cfg->partials_com || cfg->nlin < 0 || cfg->nlin > 2)
     return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_create: bad config");
+  if (gp_index) {
+    if (count < 1 || count > 2 * cfg->num_sources) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_create_subset: bad count");
+    for (int l = 0; l < count; l++)
+      if (gp_index[l] < 0 || gp_index[l] >= 2 * cfg->num_sources || (l > 0 && gp_index[l] <= gp_index[l - 1]))
+        return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_create_subset: gp_index must be strictly increasing in [0, 2 P)");
+  }
   gp_pdgp_plan p = new gp_pdgp_plan_s();
-  p->h = h; p->P = cfg->num_sources; p->G = 2 * p->P; p->whiten = cfg->whiten ? 1 : 0; p->nlin = cfg->nlin;
+  p->h = h; p->P = cfg->num_sources; p->G = gp_index ? count : 2 * p->P; p->whiten = cfg->whiten ? 1 : 0; p->nlin = cfg->nlin;
   p->maxN = cfg->max_batch; p->jitter = cfg->jitter;
+  p->subset = gp_index != nullptr;
+  if (gp_index) p->grow.assign(gp_index, gp_index + count);
   p->gps.resize(p->G);
   int64_t off = 1;  // [0] = noise variance
-  for (int g = 0; g < p->G; g++) {
-    PdgpGP& q = p->gps[g];
+  for (int l = 0; l < p->G; l++) {
+    PdgpGP& q = p->gps[l];
+    const int g = gp_index ? gp_index[l] : l;      // row of the whole model's [g_0..g_{P-1}, f_0..f_{P-1}]
     const bool act = g < p->P;
     const int i = act ? g : g - p->P;
     q.M = act ? cfg->M_act[i] : cfg->M_com[i];
@@ -64,6 +74,16 @@ gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* o
   p->nparams = off;
   *out = p;
   return GP_OK;
+}
+
+gp_status gp_pdgp_create(gp_handle h, const gp_pdgp_config* cfg, gp_pdgp_plan* out) {
+  return pdgp_create_impl(h, cfg, nullptr, 0, out);
+}
+
+gp_status gp_pdgp_create_subset(gp_handle h, const gp_pdgp_config* cfg, const int32_t* gp_index, int32_t count,
+                                gp_pdgp_plan* out) {
+  if (!gp_index) return h ? gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_create_subset: gp_index is NULL") : GP_ERR_BAD_ARG;
+  return pdgp_create_impl(h, cfg, gp_index, count, out);
 }
 
 gp_status gp_pdgp_destroy(gp_pdgp_plan p) {
@@ -119,6 +139,7 @@ size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   for (int g = 0; g < p->G; g++) d += cond_task_workspace_doubles(p->gps[g].M, p->maxN, p->gps[g].m, p->whiten != 0, p->f32 != 0);
   auto addd = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   for (int i = 0; i < 4; i++) addd((size_t)p->G * p->maxN);
+  if (p->subset) for (int i = 0; i < 2; i++) addd((size_t)2 * p->P * p->maxN);
   addd((size_t)p->G * GP_KL_BLOCKS);
   addd(2 * (size_t)mpd_lik_blocks(p->maxN) + 8);
   if (!p->whiten)
@@ -149,6 +170,10 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
   p->fvar = ar.take<double>((size_t)p->G * p->maxN);
   p->gFmu = ar.take<double>((size_t)p->G * p->maxN);
   p->gFvar = ar.take<double>((size_t)p->G * p->maxN);
+  if (p->subset) {
+    p->gF_full_mu = ar.take<double>((size_t)2 * p->P * p->maxN);
+    p->gF_full_var = ar.take<double>((size_t)2 * p->P * p->maxN);
+  }
   p->kl = ar.take<double>((size_t)p->G * GP_KL_BLOCKS);
   p->lik_partials = ar.take<double>(2 * (size_t)mpd_lik_blocks(p->maxN) + 8);
   for (int g = 0; g < p->G; g++) {
@@ -262,10 +287,10 @@ extern "C" {
 //   stage 1 (begin): conditionals, per-frame partial sums [A | B | D] and sum of the local KL terms -> xchg[0..3n]
 //   stage 2 (end)  : likelihood + gradients from the rank-summed xchg, local backward pass.
 static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double* x, const double* y, int n,
-                              double* grad, double* xchg) {
+                              double* grad, double* xchg, double* fmean = nullptr, double* fvar = nullptr) {
   gp_handle h = p->h;
   p->factor_valid = false;   // an optimiser step normally follows: predictions must re-factorise
-  GP_CHECK(pdgp_bind(p, params, x, n, grad, p->fmean, p->fvar));
+  GP_CHECK(pdgp_bind(p, params, x, n, grad, fmean ? fmean : p->fmean, fvar ? fvar : p->fvar));
   if (grad) GP_HIP_CHECK(h, hipMemsetAsync(grad, 0, (size_t)p->nparams * sizeof(double), h->stream));
   GP_CHECK(cond_batch_run(h, p->cb, x, n, p->whiten != 0, p->jitter));
   bool kl_done = false;   // the whitened KL kernel went to the helper stream with the backward prefetch
@@ -290,19 +315,51 @@ static gp_status pdgp_forward(gp_pdgp_plan p, const double* params, const double
   return GP_OK;
 }
 
+// GP-sharded plan: rows grow[l] of the whole model's gradient arrays -> this plan's compact [G][n] arrays
+struct RowGather { int rows[64]; int count; };
+__global__ void __launch_bounds__(256) rows_gather_kernel(const double* __restrict__ src_mu, const double* __restrict__ src_var,
+                                                          double* __restrict__ dst_mu, double* __restrict__ dst_var,
+                                                          RowGather rg, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+  if (i >= n) return;
+  const size_t s = (size_t)rg.rows[l] * n + i, d = (size_t)l * n + i;
+  dst_mu[d] = src_mu[s];
+  dst_var[d] = src_var[s];
+}
+
+// full_mu / full_var / kl_total != NULL: the GP-sharded second stage (moments of ALL 2 P latent GPs, [2 P][n], and the
+// whole model's KL sum as one device double)
 static gp_status pdgp_finish(gp_pdgp_plan p, const double* params, const double* x, const double* y, int n,
-                             double num_data, const double* xchg, double* elbo_dev, double* elbo_host, double* grad) {
+                             double num_data, const double* xchg, double* elbo_dev, double* elbo_host, double* grad,
+                             const double* full_mu = nullptr, const double* full_var = nullptr,
+                             const double* kl_total = nullptr) {
   gp_handle h = p->h;
   int nb = 0;
   const double scale = num_data / (double)n;
-  GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
-                          grad ? p->gFmu : nullptr, grad ? p->gFvar : nullptr, nullptr, xchg));
+  if (full_mu) {
+    GP_CHECK(launch_mpd_lik(h, full_mu, full_var, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
+                            grad ? p->gF_full_mu : nullptr, grad ? p->gF_full_var : nullptr, nullptr, nullptr));
+    if (grad) {
+      for (int l0 = 0; l0 < p->G; l0 += 64) {
+        RowGather rg;
+        rg.count = p->G - l0 < 64 ? p->G - l0 : 64;
+        for (int l = 0; l < rg.count; l++) rg.rows[l] = p->grow[l0 + l];
+        hipLaunchKernelGGL(rows_gather_kernel, dim3((n + 255) / 256, rg.count), dim3(256), 0, h->stream, p->gF_full_mu,
+                           p->gF_full_var, p->gFmu + (size_t)l0 * n, p->gFvar + (size_t)l0 * n, rg, n);
+        GP_HIP_CHECK(h, hipGetLastError());
+      }
+    }
+  } else {
+    GP_CHECK(launch_mpd_lik(h, p->fmean, p->fvar, 1, n, y, n, p->P, p->nlin, params, scale, nullptr, p->lik_partials, &nb,
+                            grad ? p->gFmu : nullptr, grad ? p->gFvar : nullptr, nullptr, xchg));
+  }
+  const double* kl_one = kl_total ? kl_total : (xchg ? xchg + 3 * (size_t)n : nullptr);
   if (grad) {     // (pdgp_backward launches it)
     p->fin.lik_partials = p->lik_partials; p->fin.nb = nb; p->fin.elbo = elbo_dev; p->fin.g_noise = grad; p->fin.pending = true;
-    if (xchg) { p->fin.kl = xchg + 3 * (size_t)n; p->fin.nkl = 1; } else { p->fin.kl = p->kl; p->fin.nkl = p->G * GP_KL_BLOCKS; }
+    if (kl_one) { p->fin.kl = kl_one; p->fin.nkl = 1; } else { p->fin.kl = p->kl; p->fin.nkl = p->G * GP_KL_BLOCKS; }
     GP_CHECK(pdgp_backward(p, params, x, n, grad));
     if (p->fin.pending) return gp_fail(h, GP_ERR_HIP, "pdgp_backward left the ELBO reduction behind");
-  } else if (xchg) GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, xchg + 3 * (size_t)n, 1, elbo_dev, nullptr));
+  } else if (kl_one) GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, kl_one, 1, elbo_dev, nullptr));
   else GP_CHECK(launch_elbo_finish(h, p->lik_partials, nb, p->kl, p->G * GP_KL_BLOCKS, elbo_dev, nullptr));
   if (elbo_host) {
     GP_HIP_CHECK(h, hipMemcpyAsync(elbo_host, elbo_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -317,6 +374,7 @@ gp_status gp_pdgp_elbo(gp_pdgp_plan p, const double* params, const double* x, co
   gp_handle h = p->h;
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo: workspace not set");
   if (!params || !x || !y || !elbo_dev || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo: bad argument");
+  if (p->subset) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo: a GP-sharded plan is evaluated with gp_pdgp_cond_begin / _end");
   GP_CHECK(pdgp_forward(p, params, x, y, n, grad, nullptr));
   return pdgp_finish(p, params, x, y, n, num_data, nullptr, elbo_dev, elbo_host, grad);
 }
@@ -327,10 +385,41 @@ gp_status gp_pdgp_elbo_begin(gp_pdgp_plan p, const double* params, const double*
   gp_handle h = p->h;
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_elbo_begin: workspace not set");
   if (!params || !x || !y || !exchange || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo_begin: bad argument");
+  if (p->subset) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_elbo_begin: a GP-sharded plan is evaluated with gp_pdgp_cond_begin / _end");
   p->staged_n = 0;
   GP_CHECK(pdgp_forward(p, params, x, y, n, grad, exchange));
   p->staged_n = n; p->staged_grad = grad; p->staged_params = params;
   return GP_OK;
+}
+
+/* GP-sharded evaluation (SURVEY section 8e option 2): see include/gpitch_abi.h */
+gp_status gp_pdgp_cond_begin(gp_pdgp_plan p, const double* params, const double* x, int32_t n, double* grad,
+                             double* fmean_local, double* fvar_local, double* kl_local_sum) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_cond_begin: workspace not set");
+  if (!p->subset) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_cond_begin: not a gp_pdgp_create_subset plan");
+  if (!params || !x || !fmean_local || !fvar_local || !kl_local_sum || n < 1 || n > p->maxN)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_cond_begin: bad argument");
+  p->staged_n = 0;
+  GP_CHECK(pdgp_forward(p, params, x, nullptr, n, grad, nullptr, fmean_local, fvar_local));
+  GP_CHECK(launch_finish_sum(h, p->kl, p->G * GP_KL_BLOCKS, 1, 1, kl_local_sum, 1.0, 0));
+  p->staged_n = n; p->staged_grad = grad; p->staged_params = params;
+  return GP_OK;
+}
+
+gp_status gp_pdgp_cond_end(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                           double num_data, const double* fmean_full, const double* fvar_full, const double* kl_total,
+                           double* elbo_dev, double* elbo_host, double* grad) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->subset) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_cond_end: not a gp_pdgp_create_subset plan");
+  if (!params || !x || !y || !fmean_full || !fvar_full || !kl_total || !elbo_dev)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_cond_end: bad argument");
+  if (p->staged_n != n || p->staged_grad != grad || p->staged_params != params)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_cond_end: no matching gp_pdgp_cond_begin (same params, n and grad required)");
+  p->staged_n = 0;
+  return pdgp_finish(p, params, x, y, n, num_data, nullptr, elbo_dev, elbo_host, grad, fmean_full, fvar_full, kl_total);
 }
 
 gp_status gp_pdgp_elbo_end(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
@@ -350,6 +439,8 @@ static gp_status pdgp_predict_impl(gp_pdgp_plan p, const double* params, const d
   gp_handle h = p->h;
   if (!p->ws) return gp_fail(h, GP_ERR_WORKSPACE, "gp_pdgp_predict: workspace not set");
   if (!params || !xnew || !fmean || !fvar || n < 1 || n > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_predict: bad argument");
+  if (p->subset && mean_source)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_predict: a GP-sharded plan holds single latent GPs, not (activation, component) pairs: mean_source must be NULL");
   if (reuse_factor && !p->factor_valid)
     return gp_fail(h, GP_ERR_BAD_ARG, "gp_pdgp_predict_reuse: no factorisation to reuse (call gp_pdgp_predict first)");
   GP_CHECK(pdgp_bind(p, params, xnew, n, nullptr, fmean, fvar));

@@ -88,5 +88,10 @@ struct gp_pdgp_plan_s {
   bool factor_valid = false;   // L / W hold the factorisation of the parameters last passed to gp_pdgp_predict
   // two-stage (pitch-sharded) evaluation: what gp_pdgp_elbo_begin staged for gp_pdgp_elbo_end
   int staged_n = 0; double* staged_grad = nullptr; const double* staged_params = nullptr;
+  // GP-sharded plan (gp_pdgp_create_subset): this plan's G latent GPs are rows `grow[g]` of the whole model's 2 P latent
+  // GPs (engine order [g_0..g_{P-1}, f_0..f_{P-1}]); P is the WHOLE model's source count (the likelihood's)
+  bool subset = false;
+  std::vector<int> grow;
+  double* gF_full_mu = nullptr; double* gF_full_var = nullptr;   // [2 P][maxN]: d varexp / d fmean, fvar of every latent GP
 };
 

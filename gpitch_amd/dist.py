@@ -53,3 +53,45 @@ def allreduce_max_(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GP-sharded Pdgp (SURVEY section 8e option 2): the 2 P latent GPs of ONE model dealt over the ranks, one all-gather of
+# (fmean, fvar) per step.  Everything below is plain torch / Python, device-agnostic: the gloo tests run it on the CPU.
+def gp_assignment(num_gps, world_size, rank):
+    """latent GPs (rows of the model's order [g_0..g_{P-1}, f_0..f_{P-1}], pdgp.py:157-164) held by `rank`: g = rank (mod world)"""
+    return list(range(rank, num_gps, world_size))
+
+
+def gp_exchange_layout(num_gps, world_size, n):
+    """(rows per rank, doubles per rank) of the all-gather's send block: [fmean rows | fvar rows | KL sum + 7 pad].  Every
+    rank sends the same size (ranks with one GP fewer leave their last row slot zero)."""
+    per = -(-num_gps // world_size)
+    return per, 2 * per * n + 8
+
+
+def gp_assemble(gathered, num_gps, world_size, n):
+    """gathered: (world * block,) — the all-gather's output.  Returns (fmean (num_gps, n), fvar (num_gps, n), kl_total (1,))
+    in the model's row order: rank r's l-th row is latent GP r + l * world."""
+    per, blk = gp_exchange_layout(num_gps, world_size, n)
+    r = gathered.view(world_size, blk)
+    fm = r[:, :per * n].reshape(world_size, per, n).permute(1, 0, 2).reshape(per * world_size, n)[:num_gps].contiguous()
+    fv = r[:, per * n:2 * per * n].reshape(world_size, per, n).permute(1, 0, 2).reshape(per * world_size, n)[:num_gps].contiguous()
+    kl = r[:, 2 * per * n].sum().reshape(1)
+    return fm, fv, kl
+
+
+def allgather_(out, send):
+    """out (world * len(send),) <- every rank's `send`, rank-major; a plain copy without a process group (a one-rank group
+    still goes through the backend, as allreduce_sum_ does)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        if send.is_cuda and dist.get_backend() == "gloo":
+            host_out, host_in = out.cpu(), send.cpu()
+            dist.all_gather_into_tensor(host_out, host_in)
+            out.copy_(host_out)
+        else:
+            dist.all_gather_into_tensor(out, send)
+    else:
+        out.copy_(send)
+    return out

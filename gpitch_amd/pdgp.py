@@ -62,6 +62,9 @@ class Pdgp(Parameterized):
         shard=(rank, world) spreads ONE model over `world` GPUs (one process each): this rank's engine plan holds
         the pitches {p : p mod world == rank} (both GPs of a pitch), the likelihood noise is replicated, and each
         ELBO evaluation exchanges one all-reduce of 3n+1 doubles (include/gpitch_abi.h: gp_pdgp_elbo_begin/_end).
+        shard=("gp", rank, world) deals the 2P LATENT GPs instead (row g of [g_0..g_{P-1}, f_0..f_{P-1}] -> rank g mod
+        world; 24 GPs on 8 GPUs = 3 each, where whole pitches give 2,2,2,2,1,1,1,1): one all-gather of (fmean, fvar)
+        per step, the likelihood recomputed on every rank, backward local (gp_pdgp_cond_begin/_end).
         Every rank constructs the model with the same arguments.
 
         float_type: the reference's `settings.dtypes.float_type` (pdgp.py:13), np.float64 (default) or np.float32.
@@ -78,10 +81,21 @@ class Pdgp(Parameterized):
         self.minibatch_size = int(minibatch_size)
         self.num_data = x.shape[0]
         self.num_sources = len(kern[0])
+        self._gp_shard = None          # ("gp", rank, world): the latent GPs this rank holds, rows of [g_0.., f_0..]
         if shard is None:
             self._shard = None
             self._local = list(range(self.num_sources))
+        elif len(shard) == 3 and shard[0] == "gp":
+            rank, world = int(shard[1]), int(shard[2])
+            if not (0 <= rank < world) or world > 2 * self.num_sources:
+                raise ValueError('shard=("gp", rank, world) needs 0 <= rank < world <= 2 x number of sources')
+            from .dist import gp_assignment
+            self._shard = (rank, world)
+            self._gp_shard = gp_assignment(2 * self.num_sources, world, rank)
+            self._local = []           # no whole pitch lives here
         else:
+            if len(shard) == 3 and shard[0] == "pitch":
+                shard = shard[1:]
             rank, world = int(shard[0]), int(shard[1])
             if not (0 <= rank < world) or world > self.num_sources:
                 raise ValueError("shard=(rank, world) needs 0 <= rank < world <= number of sources")
@@ -123,6 +137,13 @@ class Pdgp(Parameterized):
     def _gps(self):
         """GP order of the engine: act then com of the pitches this rank holds (all of them when unsharded)"""
         out = []
+        if self._gp_shard is not None:
+            P = self.num_sources
+            for g in self._gp_shard:
+                i = g if g < P else g - P
+                out.append((self.kern_act[i], self.za[i], self.q_mu_act[i], self.q_sqrt_act[i]) if g < P else
+                           (self.kern_com[i], self.zc[i], self.q_mu_com[i], self.q_sqrt_com[i]))
+            return out
         for i in self._local:
             out.append((self.kern_act[i], self.za[i], self.q_mu_act[i], self.q_sqrt_act[i]))
         for i in self._local:
@@ -133,7 +154,7 @@ class Pdgp(Parameterized):
         if self._plan is not None:
             return
         h = self._handle = self._handle or _lib.default_handle()
-        loc = self._local
+        loc = self._local if self._gp_shard is None else list(range(self.num_sources))   # (GP-sharded: cfg = whole model)
         P = len(loc)
         i32 = C.c_int32 * P
         self._cfg_keep = dict(
@@ -147,13 +168,17 @@ class Pdgp(Parameterized):
         cfg = _lib.PdgpConfig(P, int(bool(self.whiten)), nlin_code(self.nlinfun), self._max_batch,
                               k["M_act"], k["M_com"], k["kt_act"], k["kt_com"], k["np_act"], k["np_com"], jitter)
         plan = C.c_void_p()
-        h.check(h.lib.gp_pdgp_create(h.h, C.byref(cfg), C.byref(plan)))
+        if self._gp_shard is not None:
+            idx = (C.c_int32 * len(self._gp_shard))(*self._gp_shard)
+            h.check(h.lib.gp_pdgp_create_subset(h.h, C.byref(cfg), idx, len(self._gp_shard), C.byref(plan)))
+        else:
+            h.check(h.lib.gp_pdgp_create(h.h, C.byref(cfg), C.byref(plan)))
         self._plan = plan
         if self._bits == 32:
             h.check(h.lib.gp_pdgp_set_precision(plan, 32))
         n = self._nparams = int(h.lib.gp_pdgp_num_params(plan))
         self._layout = []
-        for g in range(2 * P):
+        for g in range(2 * P if self._gp_shard is None else len(self._gp_shard)):
             o = [C.c_int64() for _ in range(4)]
             h.check(h.lib.gp_pdgp_layout(plan, g, *[C.byref(v) for v in o]))
             self._layout.append(tuple(v.value for v in o))
@@ -169,7 +194,12 @@ class Pdgp(Parameterized):
         h.check(h.lib.gp_pdgp_set_workspace(plan, self._ws.data_ptr(), self._ws.numel()))
         self._x_dev = h.to_device(self.x._array.reshape(-1))
         self._y_dev = h.to_device(self.y._array.reshape(-1))
-        self._xchg = h.zeros(3 * self._max_batch + 1) if self._shard else None
+        self._xchg = h.zeros(3 * self._max_batch + 1) if (self._shard and self._gp_shard is None) else None
+        if self._gp_shard is not None:
+            from .dist import gp_exchange_layout
+            _, blk = gp_exchange_layout(2 * self.num_sources, self._shard[1], self._max_batch)
+            self._gp_send = h.zeros(blk)
+            self._gp_recv = h.zeros(blk * self._shard[1])
 
     def _segments(self):
         """[(offset, Param)] of every Param in the flat vector"""
@@ -263,6 +293,12 @@ class Pdgp(Parameterized):
     def _elbo(self, want_grad, sync=True):
         h = self._handle
         self._pred_state = None      # the engine drops its prediction factorisation on every ELBO evaluation
+        if self._gp_shard is not None:
+            from .dist import allgather_
+            send = self._gp_begin(want_grad)
+            recv = self._gp_recv[:send.numel() * self._shard[1]]
+            allgather_(recv, send)
+            return self._gp_end(want_grad, recv, sync)
         if self._shard:
             xchg = self._elbo_begin(want_grad)
             from .dist import allreduce_sum_
@@ -286,6 +322,38 @@ class Pdgp(Parameterized):
         h.check(h.lib.gp_pdgp_elbo_begin(self._plan, self._params.data_ptr(), xb.data_ptr(), yb.data_ptr(), n,
                                          self._grad.data_ptr() if want_grad else None, xchg.data_ptr()))
         return xchg
+
+    def _gp_begin(self, want_grad):
+        """GP-sharded stage 1: conditionals of this rank's latent GPs, written straight into the all-gather's send block
+        [fmean rows | fvar rows | sum of the local KL terms] (dist.gp_exchange_layout)"""
+        from .dist import gp_exchange_layout
+        h = self._handle
+        self._pred_state = None
+        xb, yb, n = self._batch()
+        self._last_batch = (xb, yb)
+        per, blk = gp_exchange_layout(2 * self.num_sources, self._shard[1], n)
+        send = self._gp_send[:blk]
+        if len(self._gp_shard) < per:
+            send.zero_()                  # this rank's last row slot is padding
+        h.check(h.lib.gp_pdgp_cond_begin(self._plan, self._params.data_ptr(), xb.data_ptr(), n,
+                                         self._grad.data_ptr() if want_grad else None, send.data_ptr(),
+                                         send[per * n:].data_ptr(), send[2 * per * n:].data_ptr()))
+        return send
+
+    def _gp_end(self, want_grad, gathered, sync=True):
+        """GP-sharded stage 2 on the all-gather's output (world x block): the whole model's likelihood, local backward"""
+        from .dist import gp_assemble
+        h = self._handle
+        xb, yb = self._last_batch
+        n = xb.numel()
+        fm, fv, kl = gp_assemble(gathered, 2 * self.num_sources, self._shard[1], n)
+        self._gp_keep = (fm, fv, kl)      # alive while the stream uses them
+        out = C.c_double()
+        h.check(h.lib.gp_pdgp_cond_end(self._plan, self._params.data_ptr(), xb.data_ptr(), yb.data_ptr(), n,
+                                       float(self.num_data), fm.data_ptr(), fv.data_ptr(), kl.data_ptr(),
+                                       self._elbo_dev.data_ptr(), C.byref(out) if sync else None,
+                                       self._grad.data_ptr() if want_grad else None))
+        return out.value if sync else None
 
     def _elbo_end(self, want_grad, sync=True):
         """pitch-sharded stage 2 on the rank-summed exchange tensor"""
@@ -410,29 +478,36 @@ class Pdgp(Parameterized):
         predict = h.lib.gp_pdgp_predict_reuse if reuse else h.lib.gp_pdgp_predict
         P, n = self.num_sources, xnew.size
         loc = self._local
-        Pl, Gl = len(loc), 2 * len(loc)
+        gp_mode = self._gp_shard is not None
+        Pl, Gl = len(loc), (len(self._gp_shard) if gp_mode else 2 * len(loc))
         fmean = np.zeros((2 * P, n))
         fvar = np.zeros((2 * P, n))
         src = np.zeros((P, n))
-        rows = np.array(loc + [P + i for i in loc])      # engine row -> model row [g_0..g_{P-1}, f_0..f_{P-1}]
+        # engine row -> model row [g_0..g_{P-1}, f_0..f_{P-1}]
+        rows = np.array(self._gp_shard if gp_mode else loc + [P + i for i in loc])
         step = self._max_batch
         for s in range(0, n, step):
             xs = h.to_device(xnew[s:s + step])
             c = xs.numel()
-            fm, fv, ms = h.empty(Gl, c), h.empty(Gl, c), h.empty(Pl, c)
+            fm, fv, ms = h.empty(Gl, c), h.empty(Gl, c), (None if gp_mode else h.empty(Pl, c))
             h.check(predict(self._plan, self._params.data_ptr(), xs.data_ptr(), c, fm.data_ptr(), fv.data_ptr(),
-                            ms.data_ptr()))
+                            None if gp_mode else ms.data_ptr()))
             predict = h.lib.gp_pdgp_predict_reuse     # further chunks of the same call share the factorisation
             fmean[rows, s:s + c] = fm.cpu().numpy()
             fvar[rows, s:s + c] = fv.cpu().numpy()
-            src[loc, s:s + c] = ms.cpu().numpy()
+            if not gp_mode:
+                src[loc, s:s + c] = ms.cpu().numpy()
         self._pred_state = state
         if self._shard:
             # rows of other ranks are zero here: a sum over ranks assembles the full prediction
             from .dist import allreduce_sum_
             t = h.torch
-            for a in (fmean, fvar, src):
+            for a in ((fmean, fvar) if gp_mode else (fmean, fvar, src)):
                 a[...] = allreduce_sum_(t.as_tensor(a)).numpy()
+        if gp_mode:
+            # an activation GP and its component GP may live on different ranks: the source mean (pdgp.py:207) is formed
+            # from the assembled rows — complete only once the sum over ranks has run (a rank on its own sees its rows)
+            src = self.nlinfun(fmean[:P]) * fmean[P:]
         self._pred_memo = (state, xnew.copy(), (fmean, fvar, src))
         return fmean, fvar, src
 
@@ -441,17 +516,20 @@ class Pdgp(Parameterized):
         import torch.distributed as dist
         if not (self._shard and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
+        P = self.num_sources
+        owned = self._gp_shard if self._gp_shard is not None else self._local + [P + i for i in self._local]
         mine = {}
-        for i in self._local:
-            for name, lst in (("kern_act", self.kern_act), ("kern_com", self.kern_com)):
-                mine[(name, i)] = [q.value.copy() for q in lst[i].theta_params()]
-            for name in ("za", "zc", "q_mu_act", "q_mu_com", "q_sqrt_act", "q_sqrt_com"):
+        for g in owned:
+            i, act = (g, True) if g < P else (g - P, False)
+            kname = "kern_act" if act else "kern_com"
+            mine[(kname, i)] = [q.value.copy() for q in getattr(self, kname)[i].theta_params()]
+            for name in (("za", "q_mu_act", "q_sqrt_act") if act else ("zc", "q_mu_com", "q_sqrt_com")):
                 mine[(name, i)] = getattr(self, name)[i].value.copy()
         everyone = [None] * dist.get_world_size()
         dist.all_gather_object(everyone, mine)
         for part in everyone:
             for (name, i), val in part.items():
-                if i in self._local:
+                if (name, i) in mine:
                     continue
                 if name.startswith("kern"):
                     for q, v in zip(getattr(self, name)[i].theta_params(), val):

@@ -231,6 +231,29 @@ gp_status gp_pdgp_elbo_end(gp_pdgp_plan p, const double* params, const double* x
                            double num_data, const double* exchange, double* elbo_dev, double* elbo_host,
                            double* grad);
 
+/* GP-sharded evaluation of ONE Pdgp model over several GPUs (option 2; one process per GPU).  The 2 P
+ * conditionals of Pdgp.build_likelihood are independent (pdgp.py:146-155) and the likelihood needs only (fmean, fvar) of
+ * every latent GP (likelihoods.py:422-447), so the latent GPs themselves are the sharding unit: 24 GPs at P = 12 are 3
+ * per GPU on 8 GPUs (ceiling 8x; the pitch-sharded form above: 6x).
+ *   gp_pdgp_create_subset : a plan over `count` of the model's 2 P latent GPs; gp_index[l] (strictly increasing) is the row
+ *                           in the model's order [g_0..g_{P-1}, f_0..f_{P-1}] (pdgp.py:157-164).  `cfg` describes the WHOLE
+ *                           model.  The parameter vector holds [noise | the listed GPs] (gp_pdgp_layout by local index).
+ *   gp_pdgp_cond_begin    : conditionals of the local GPs -> fmean_local, fvar_local ([count][n], caller's buffers: the
+ *                           send buffer of the exchange) and the sum of the local KL terms -> kl_local_sum[0].
+ *   -- caller: ONE all-gather of 2 n doubles per latent GP (+ the KL scalar) on the handle's stream --
+ *   gp_pdgp_cond_end      : likelihood of the whole model from fmean_full / fvar_full ([2 P][n], model order; computed
+ *                           identically on every rank, so the replicated noise variance stays in step) with kl_total[0]
+ *                           = the KL sum over all ranks; local backward pass.  elbo_dev / elbo_host / grad as in
+ *                           gp_pdgp_elbo (grad covers this plan's parameters; grad[0] is the full noise gradient).
+ * No collective in the backward pass.  gp_pdgp_predict on such a plan takes mean_source = NULL. */
+gp_status gp_pdgp_create_subset(gp_handle h, const gp_pdgp_config* cfg, const int32_t* gp_index, int32_t count,
+                                gp_pdgp_plan* out);
+gp_status gp_pdgp_cond_begin(gp_pdgp_plan p, const double* params, const double* x, int32_t n, double* grad,
+                             double* fmean_local, double* fvar_local, double* kl_local_sum);
+gp_status gp_pdgp_cond_end(gp_pdgp_plan p, const double* params, const double* x, const double* y, int32_t n,
+                           double num_data, const double* fmean_full, const double* fvar_full, const double* kl_total,
+                           double* elbo_dev, double* elbo_host, double* grad);
+
 /* Pdgp.predict_act / predict_com / predict_act_n_com (pdgp.py:172-208): conditionals at xnew for all 2P
  * GPs.  fmean/fvar: 2P x n row-major (row g as in gp_pdgp_layout).  mean_source (P x n, may be NULL)
  * = nlinfun(mean_act_i) * mean_com_i (pdgp.py:207). */

@@ -197,3 +197,94 @@ def test_frame_sharded_sgpr_exchange_gloo():
     assert got[0][1] == got[1][1]
     assert abs(got[0][1] - ref) <= 1e-10 * abs(ref)
     assert (got[0][2], got[0][3], got[1][2], got[1][3]) == (0, 129, 129, 257)     # contiguous, sizes differ by <= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# GP-sharded single model (SURVEY §8e option 2): ranks hold disjoint sets of the 2P LATENT GPs and exchange ONE all-gather
+# of (fmean, fvar) per GP plus the KL scalar; every rank then evaluates the whole likelihood.  The per-GP arithmetic here is
+# the oracle's (no GPU in this container); the assignment, the send-block layout, the all-gather and the re-assembly into
+# the model's row order are the product's (gpitch_amd/dist.py — the same functions Pdgp(shard=("gp", r, w)) calls).
+def _gp_send_block(prob, rank, world):
+    from oracle import gpflow05 as orc
+    from oracle.backend import NP
+    from gpitch_amd import dist as gd
+    P, n = prob["P"], prob["x"].shape[0]
+    per, blk = gd.gp_exchange_layout(2 * P, world, n)
+    send = np.zeros(blk)
+    for l, g in enumerate(gd.gp_assignment(2 * P, world, rank)):
+        act, i = (True, g) if g < P else (False, g - P)
+        z, k, qm, qs = ((prob["za"], prob["kern_act"], prob["q_mu_act"], prob["q_sqrt_act"]) if act else
+                        (prob["zc"], prob["kern_com"], prob["q_mu_com"], prob["q_sqrt_com"]))
+        m, v = orc.conditional(prob["x"], z[i], k[i], qm[i], qs[i], whiten=True, xp=NP)
+        send[l * n:(l + 1) * n] = m.reshape(-1)
+        send[(per + l) * n:(per + l + 1) * n] = v.reshape(-1)
+        send[2 * per * n] += float(orc.gauss_kl(qm[i], qs[i], xp=NP))
+    return send
+
+
+def _gp_worker(rank, world, port, P, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from gpitch_amd import dist as gd
+    from gpitch_amd.synth import make_problem
+    from oracle import gpflow05 as orc
+    d = gd.init_process_group("gloo")
+    prob = make_problem(160, 8, P, num_partials=2, seed=6)
+    n = prob["x"].shape[0]
+    send = torch.as_tensor(_gp_send_block(prob, rank, world))
+    recv = torch.zeros(send.numel() * world, dtype=torch.float64)
+    gd.allgather_(recv, send)
+    fm, fv, kl = gd.gp_assemble(recv, 2 * P, world, n)
+    ve = orc.mpd_variational_expectations(fm.numpy().T.copy(), fv.numpy().T.copy(), prob["y"], prob["noise_var"], P)
+    out.put((rank, float(ve.sum() - kl.item())))
+    d.destroy_process_group()
+
+
+def _run_gp_world(world, P, port_base):
+    from gpitch_amd.synth import make_problem
+    from helpers import oracle_elbo
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = port_base + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gp_worker, args=(r, world, port, P, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = dict(q.get() for _ in range(world))
+    ref = float(oracle_elbo(make_problem(160, 8, P, num_partials=2, seed=6)))
+    assert sorted(got) == list(range(world))
+    for r in range(world):
+        assert abs(got[r] - ref) <= 1e-11 * abs(ref), (r, got[r], ref)        # every rank holds the whole model's ELBO
+
+
+def test_gp_sharded_allgather_exchange_gloo_world2():
+    _run_gp_world(2, 3, 33500)
+
+
+def test_gp_sharded_allgather_exchange_gloo_world3_ragged():
+    """2P = 4 latent GPs on 3 ranks: rank 0 holds two (g_0 and f_1), ranks 1 and 2 one each and a padded slot"""
+    _run_gp_world(3, 2, 35500)
+
+
+def test_gp_assignment_and_layout():
+    from gpitch_amd.dist import gp_assignment, gp_exchange_layout, gp_assemble
+    for G, world in [(24, 8), (24, 5), (4, 3), (10, 10), (6, 1)]:
+        got = sorted(sum((gp_assignment(G, world, r) for r in range(world)), []))
+        assert got == list(range(G))
+        assert max(len(gp_assignment(G, world, r)) for r in range(world)) == gp_exchange_layout(G, world, 7)[0]
+    # 24 GPs on 8 ranks: three each (the pitch-sharded form has 2,2,2,2,1,1,1,1 pitches = 4,4,4,4,2,2,2,2 GPs)
+    assert [len(gp_assignment(24, 8, r)) for r in range(8)] == [3] * 8
+    # re-assembly: rank r's l-th row is GP r + l * world
+    G, world, n = 5, 2, 3
+    per, blk = gp_exchange_layout(G, world, n)
+    buf = torch.zeros(world * blk, dtype=torch.float64)
+    for r in range(world):
+        for l, g in enumerate(gp_assignment(G, world, r)):
+            buf[r * blk + l * n:r * blk + (l + 1) * n] = 100 + g
+            buf[r * blk + (per + l) * n:r * blk + (per + l + 1) * n] = 200 + g
+        buf[r * blk + 2 * per * n] = 0.5 + r
+    fm, fv, kl = gp_assemble(buf, G, world, n)
+    assert fm.shape == (G, n) and torch.equal(fm[:, 0], 100 + torch.arange(G, dtype=torch.float64))
+    assert torch.equal(fv[:, 2], 200 + torch.arange(G, dtype=torch.float64)) and kl.item() == 2.0

@@ -35,16 +35,16 @@ def test_bench_single_process_line():
     assert d["config"]["workload"].startswith("pdgp ELBO step")
 
 
-@pytest.mark.parametrize("shard,scaling", [("window", "weak"), ("pitch", "strong")])
+@pytest.mark.parametrize("shard,scaling", [("window", "weak"), ("pitch", "strong"), ("gp", "strong")])
 def test_bench_two_rank_rehearsal(shard, scaling):
-    port = 29700 + (os.getpid() % 200) + (0 if shard == "window" else 1)
+    port = 29700 + (os.getpid() % 200) + {"window": 0, "pitch": 1, "gp": 2}[shard]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shard", shard] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
-    assert d["config"]["parallelism"].startswith("window-per-gpu" if shard == "window" else "pitch-sharded")
+    assert d["config"]["parallelism"].startswith({"window": "window-per-gpu", "pitch": "pitch-sharded", "gp": "gp-sharded"}[shard])
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():
@@ -57,14 +57,15 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak" and d["value"] > 0
     assert d["pitch_sharded"]["scaling"] == "strong" and d["pitch_sharded"]["value"] > 0
+    assert d["gp_sharded"]["scaling"] == "strong" and d["gp_sharded"]["value"] > 0 and d["gp_sharded"]["ceiling_x"] == 2.0
 
 
-@pytest.mark.parametrize("shard", ["window", "pitch"])
+@pytest.mark.parametrize("shard", ["window", "pitch", "gp"])
 def test_bench_one_rank_through_rccl(shard):
     """the launcher form with ONE rank and the nccl backend: RCCL communicator set-up and the per-step all-reduce (the
     device-resident scalar ELBO in window mode; the 3N+1 exchange vector between gp_pdgp_elbo_begin / _end in pitch mode,
     ordered against the library's streams) run on this one-GPU box; the 2 / 4 / 8-rank runs are the driver's"""
-    port = 29950 + (os.getpid() % 40) + (0 if shard == "window" else 1)
+    port = 29950 + (os.getpid() % 40) + {"window": 0, "pitch": 1, "gp": 2}[shard]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--shard", shard] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)

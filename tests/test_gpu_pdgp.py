@@ -591,3 +591,103 @@ def test_separable_envelope_paths_match_autograd(gp_handle, ls, ktype):
             rg = np.tril(rg[:, :, 0])[:, :, None]
         scale = max(np.abs(rg).max(), 1e-12)
         np.testing.assert_allclose(gg.reshape(rg.shape), rg, rtol=0, atol=tol * scale, err_msg=name)
+
+
+@pytest.mark.parametrize("P,world,whiten", [(3, 2, True), (5, 3, True), (4, 8, True), (2, 3, False)])
+def test_gp_sharded_two_stage_matches_unsharded(gp_handle, P, world, whiten):
+    """SURVEY section 8e option 2: ONE model with its 2P latent GPs dealt over `world` ranks (gp_pdgp_cond_begin -> all-gather of
+    (fmean, fvar) per GP + the KL scalar -> gp_pdgp_cond_end), the ranks emulated in this process (world = 3 with 2P = 10 / 4:
+    ranks with one GP fewer pad their block; world = 8 with P = 4: one GP per rank, an activation GP and its component GP on
+    different ranks).  Every rank must report the whole model's ELBO and its own slice of the unsharded gradient."""
+    import torch
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(900, 24, P, num_partials=3, seed=13)
+    full = pdgp_from_problem(prob, whiten=whiten, handle=gp_handle)
+    full._pack()
+    e_full = full._elbo(whiten)
+    g_full = model_grad_dict(full) if whiten else None
+    kl_full = float(full._elbo_dev[1].item())
+    shards = [pdgp_from_problem(prob, whiten=whiten, handle=gp_handle, shard=("gp", r, world)) for r in range(world)]
+    for s in shards:
+        s._pack()
+    assert sorted(g for s in shards for g in s._gp_shard) == list(range(2 * P))
+    gathered = torch.cat([s._gp_begin(whiten).clone() for s in shards])
+    seen = set()
+    for s in shards:
+        e = s._gp_end(whiten, gathered)
+        assert abs(e - e_full) <= 1e-10 * abs(e_full), (e, e_full)
+        assert abs(float(s._elbo_dev[1].item()) - kl_full) <= 1e-10 * max(1.0, abs(kl_full))
+        if whiten:
+            g = s._grad.cpu().numpy()
+            assert np.allclose(g[0:1], g_full["noise"], rtol=1e-8, atol=1e-9 * max(1.0, abs(g_full["noise"][0])))
+            for l, gi in enumerate(s._gp_shard):
+                act = gi < P
+                i = gi if act else gi - P
+                name = ("act%d" if act else "com%d") % i
+                kern = (s.kern_act if act else s.kern_com)[i]
+                o_th, o_z, o_mu, o_sq = s._layout[l]
+                M, mp = (s.num_inducing_a if act else s.num_inducing_c)[i], int(kern.num_partials)
+                got = {name + ".variance": g[o_th:o_th + 1], name + ".lengthscales": g[o_th + 1:o_th + 2],
+                       ("za%d" if act else "zc%d") % i: g[o_z:o_z + M].reshape(-1, 1),
+                       ("q_mu_act%d" if act else "q_mu_com%d") % i: g[o_mu:o_mu + M].reshape(-1, 1),
+                       ("q_sqrt_act%d" if act else "q_sqrt_com%d") % i: g[o_sq:o_sq + M * M].reshape(M, M, 1)}
+                for j in range(mp):
+                    got["%s.energy%d" % (name, j)] = g[o_th + 2 + j:o_th + 3 + j]
+                    got["%s.frequency%d" % (name, j)] = g[o_th + 2 + mp + j:o_th + 3 + mp + j]
+                for k, v in got.items():
+                    ref = g_full[k]
+                    assert np.allclose(v, ref, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref).max())), (k, gi)
+                    seen.add(k)
+    if whiten:
+        assert seen | {"noise"} == set(g_full.keys())
+    # predictions: each rank fills its own rows; the sum over ranks (the all-reduce of _predict) assembles them
+    xs = prob["x"][::7]
+    ref = full.predict_act_n_com(xs)
+    fm = sum(s._predict(xs, True)[0] for s in shards)
+    for i in range(P):
+        assert np.allclose(fm[i].reshape(-1, 1), ref[0][i], rtol=1e-10, atol=1e-12)
+        assert np.allclose(fm[P + i].reshape(-1, 1), ref[2][i], rtol=1e-10, atol=1e-12)
+    src = shards[0].nlinfun(fm[:P]) * fm[P:]
+    for i in range(P):
+        assert np.allclose(src[i].reshape(-1, 1), ref[4][i], rtol=1e-10, atol=1e-12)
+
+
+def test_gp_sharded_adam_steps_follow_the_unsharded_model(gp_handle):
+    """three Adam steps of a 2-rank GP-sharded model (ranks emulated, the exchange done by hand) against the unsharded
+    model's: each rank updates only its own slice, the replicated noise variance stays in step"""
+    import ctypes as C
+    import torch
+    import gpitch_amd
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(700, 20, 2, num_partials=3, seed=5)
+    full = pdgp_from_problem(prob, handle=gp_handle)
+    full.za.fixed = True
+    full.zc.fixed = True
+    full.optimize(method=gpitch_amd.train.AdamOptimizer(0.01), maxiter=3)
+    shards = [pdgp_from_problem(prob, handle=gp_handle, shard=("gp", r, 2)) for r in range(2)]
+    opt = gpitch_amd.train.AdamOptimizer(0.01)
+    for s in shards:
+        s.za.fixed = True
+        s.zc.fixed = True
+        s._pack()
+    for it in range(3):
+        gathered = torch.cat([s._gp_begin(True).clone() for s in shards])
+        for s in shards:
+            h = s._handle
+            s._gp_end(True, gathered, sync=False)
+            s._adam_t += 1
+            h.check(h.lib.gp_adam_step(h.h, s._free.data_ptr(), s._params.data_ptr(), s._grad.data_ptr(),
+                                       s._tcode.data_ptr(), s._adam_m.data_ptr(), s._adam_v.data_ptr(), s._nparams,
+                                       s._adam_t, opt.learning_rate, opt.beta1, opt.beta2, opt.epsilon))
+    for s in shards:
+        s._unpack()
+        assert abs(s.likelihood.variance.value[0] - full.likelihood.variance.value[0]) <= 1e-12
+        for gi in s._gp_shard:
+            act, i = (True, gi) if gi < 2 else (False, gi - 2)
+            for a, b in zip((s.kern_act if act else s.kern_com)[i].theta_params(),
+                            (full.kern_act if act else full.kern_com)[i].theta_params()):
+                np.testing.assert_allclose(a.value, b.value, rtol=1e-10)
+            np.testing.assert_allclose((s.q_mu_act if act else s.q_mu_com)[i].value,
+                                       (full.q_mu_act if act else full.q_mu_com)[i].value, rtol=0, atol=1e-11)
+            np.testing.assert_allclose((s.q_sqrt_act if act else s.q_sqrt_com)[i].value,
+                                       (full.q_sqrt_act if act else full.q_sqrt_com)[i].value, rtol=0, atol=1e-11)
