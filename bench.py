@@ -123,6 +123,134 @@ def cpu_baseline(args):
     return res
 
 
+def bench_cfg5(args, with_cpu):
+    """BASELINE configs[4]: sgpr_ss source separation, 5 sources, N = 65536 frames, M = 512 inducing points — one evaluation =
+    SGPRSS.build_likelihood (sgpr_ss.py:29-71) + its gradient w.r.t. every kernel hyper-parameter and the noise variance
+    (what one L-BFGS-B function evaluation of model.optimize costs), float64 and float32 strips.  Algorithmic flops per
+    evaluation: forward A = L^-1 Kuf (M^2 N) + A A^T (M^2 N, symmetric); backward twice that: 6 M^2 N."""
+    import torch
+    from gpitch_amd import _lib
+    from gpitch_amd.kernels import Add
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm
+    from gpitch_amd.sgpr_ss import SGPRSS
+    N, M, P, m = 65536, 512, 5, 3
+    rng = np.random.RandomState(0)
+    X = np.linspace(0, (N - 1) / 16000., N).reshape(-1, 1)
+    Y = rng.randn(N, 1)
+    Z = X[:: N // M][:M].copy()
+    h = _lib.default_handle()
+    flops = 6.0 * M * M * N
+    kuf_bytes = P * 8.0 * (float(M) * N + N + M) + P * 8.0 * 2 * m * (M + N)
+    out = {"workload": "sgpr_ss bound + gradient evaluation, N=%d x M=%d, %d Mercer Matern-1/2 SM kernels (m=%d) "
+                       "(BASELINE configs[4])" % (N, M, P, m),
+           "unit": "evaluations/s", "algorithmic_flops_per_evaluation": flops,
+           "kuf_build_bytes_per_evaluation_f64": kuf_bytes}
+
+    def kernels():
+        return [MercerMatern12sm(1, energy=np.full(m, 1.0 / m), frequency=110.0 * (p + 1) * np.arange(1, m + 1),
+                                 variance=1.0, lengthscales=0.05 + 0.01 * p) for p in range(P)]
+    for ft, name, peak in ((np.float64, "f64", PEAK_F64_MFMA_TFLOPS), (np.float32, "f32", PEAK_F32_MFMA_TFLOPS)):
+        model = SGPRSS(X, Y, Add(kernels()), Z, handle=h, float_type=ft)
+        model._compile(); model._pack()
+        g = h.zeros(model._nparams)
+        for _ in range(3):
+            model._bound(grad=g)
+        torch.cuda.synchronize()
+        h.check(h.lib.gp_timers_enable(h.h, 1)); h.check(h.lib.gp_timers_reset(h.h))
+        reps = max(args.steps, 5)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f = model._bound(grad=g)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        h.check(h.lib.gp_timers_enable(h.h, 0))
+        tm = {k: ms / reps for k, (ms, n) in h.timers().items() if n}
+        out[name] = {"value": 1.0 / dt, "ms_per_evaluation": dt * 1e3, "bound": float(f),
+                     "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": flops / dt / 1e12 / peak,
+                                  "note": "whole evaluation (its strip products are a quarter of it: the rest is the chain "
+                                          "of dependent M x M launches)"},
+                     "kernel_ms_per_evaluation": tm}
+        model._destroy()
+    if with_cpu:
+        from oracle import gpflow05 as orc
+        from oracle.backend import TorchBackend
+        tb = TorchBackend()
+        T = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=True)
+        kl = [{"type": "mercer_matern12sm", "variance": T(1.0), "lengthscales": T(0.05 + 0.01 * p),
+               "energy": [T(1.0 / m) for _ in range(m)], "frequency": [T(110.0 * (p + 1) * (q + 1)) for q in range(m)]}
+              for p in range(P)]
+        nv = T(1.0)
+        Xt, Yt, Zt = torch.tensor(X), torch.tensor(Y), torch.tensor(Z)
+        times = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            b = orc.sgpr_bound(Xt, Yt, Zt, kl, nv, xp=tb)
+            b.backward()
+            times.append(time.perf_counter() - t0)
+        t1 = float(np.median(times[1:]))
+        out["cpu_baseline"] = {"value": 1.0 / t1, "unit": "evaluations/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                               "sample": "1 warm-up then median of 3 bound + autograd-gradient evaluations of the oracle's "
+                                         "torch-CPU float64 restatement at the full size (%.2f s each)" % t1}
+        out["vs_cpu_baseline"] = out["f64"]["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def bench_windows(args, with_cpu):
+    """The window loop of AMT.optimize / SoSp.optimize (transcription.py:265-288): independent SGPRSS fits of ws = 2001-frame
+    windows (M = 64 inducing points, 3 pitch kernels of 10 partials, L-BFGS-B maxiter 10), device-batched 256 windows per
+    launch sequence (gp_sgprb_*), scipy's L-BFGS-B per window."""
+    import torch
+    from gpitch_amd.kernels import Add
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm
+    from gpitch_amd.sgpr_ss import SGPRSS
+    from gpitch_amd.synth import make_problem
+    from gpitch_amd.windows import fit_windows_batched
+    ws, M, P, m, maxiter, nwin, B = 2001, 64, 3, 10, 10, 512, 256
+    probs = [make_problem(ws, M, P, num_partials=m, seed=1000 + w) for w in range(nwin)]
+    data = [(q["x"], q["y"], q["zc"][0]) for q in probs]
+
+    def make(hh):
+        ks = [MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=1.0,
+                               lengthscales=d["lengthscales"]) for d in probs[0]["kern_com"]]
+        return SGPRSS(probs[0]["x"], probs[0]["y"], Add(ks), probs[0]["zc"][0], handle=hh)
+    fit_windows_batched(make, data[:B], maxiter=2, batch=B)        # warm-up (plan, graph capture)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = fit_windows_batched(make, data, maxiter=maxiter, batch=B)
+    dt = time.perf_counter() - t0
+    nfev = sum(r["nfev"] for r in res)
+    out = {"workload": "sgpr_ss window fits (transcription.py:265-288): ws=%d frames, M=%d, %d kernels x %d partials, L-BFGS-B "
+                       "maxiter %d, %d windows, %d per launch sequence" % (ws, M, P, m, maxiter, nwin, B),
+           "value": nwin / dt, "unit": "window fits/s", "seconds": dt, "evaluations_per_window": nfev / float(nwin),
+           "failed_windows": sum(1 for r in res if "error" in r)}
+    if with_cpu:
+        from oracle import gpflow05 as orc
+        from oracle.backend import TorchBackend
+        tb = TorchBackend()
+        T = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=True)
+        q = probs[0]
+        kl = [{"type": "mercer_matern12sm", "variance": T(1.0), "lengthscales": T(d["lengthscales"]),
+               "energy": [T(e) for e in d["energy"]], "frequency": [T(f) for f in d["frequency"]]} for d in q["kern_com"]]
+        nv = T(1.0)
+        Xt, Yt, Zt = torch.tensor(q["x"]), torch.tensor(q["y"]), torch.tensor(q["zc"][0])
+        times = []
+        for it in range(12):
+            t0 = time.perf_counter()
+            b = orc.sgpr_bound(Xt, Yt, Zt, kl, nv, xp=tb)
+            b.backward()
+            times.append(time.perf_counter() - t0)
+        te = float(np.median(times[2:]))
+        per_win = te * out["evaluations_per_window"]
+        out["cpu_baseline"] = {"value": 1.0 / per_win, "unit": "window fits/s", "cores": int(torch.get_num_threads()),
+                               "kind": "port",
+                               "sample": "median of 10 bound + autograd-gradient evaluations of one window by the oracle's "
+                                         "torch-CPU restatement (%.1f ms each) x the %.1f evaluations a fit takes"
+                                         % (te * 1e3, out["evaluations_per_window"])}
+        out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) as fresh child processes
     through torch.distributed.run BEFORE this process makes any HIP call (a process that has touched the GPU must
@@ -216,6 +344,8 @@ def main():
                     help="f64 (the headline: the reference's float_type = float64); f32: the M x N strips and the four "
                          "strip products in float32 (BASELINE configs 3 and 5 are quoted at fp32; tolerance in tests/test_gpu_f32.py)")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the extra cfg3 (M=256, fp32) measurement")
+    ap.add_argument("--no-sgpr-lines", action="store_true",
+                    help="skip the extra cfg5 (sgpr_ss N=65536, M=512, 5 sources) and window-loop measurements")
     ap.add_argument("--no-pitch-line", action="store_true",
                     help="multi-GPU window mode: skip the extra pitch-sharded (strong-scaling) measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -472,6 +602,13 @@ def main():
             out["gp_sharded"] = extra_gp
         if cfg3 is not None:
             out["cfg3_fp32"] = cfg3
+        if world == 1 and not args.no_sgpr_lines and not args.no_f32_line and (args.N, args.M, args.P) == (32768, 512, 12):
+            # the other two workloads of the path, same run: BASELINE configs[4] and the reference's window loop
+            model = res = None
+            torch.cuda.empty_cache()
+            out["cfg5_sgpr"] = bench_cfg5(args, not args.no_cpu)
+            torch.cuda.empty_cache()
+            out["windows"] = bench_windows(args, not args.no_cpu)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
             out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -283,8 +283,10 @@ void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const doubl
                    int accumulate, double diag_add, double* feat_ws, int f32out = 0);
 gp_status launch_sm_features_items(gp_handle h, const FeatItem* d_items, int count, int max_n, int mpad,
                                    const double* x_shared, int n_shared);
+// engine_strips != 0: the caller vouches that every item writes an engine strip of the shared frames (item.n2 < 0, 256-byte
+// aligned output, leading dimension gp_strip_ld) — what the lean Mercer form needs to know on the host
 gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem* d_items, int count, int max_n1,
-                                    int max_n2, const double* x2_shared, int n2_shared);
+                                    int max_n2, const double* x2_shared, int n2_shared, int engine_strips = 0);
 gp_status launch_overlap_merge(gp_handle h, const double* y, int nw, int ws, int64_t ldy, int n, int square, double* out);
 // lik.hip
 // whitened KL: each item writes GP_KL_BLOCKS partial sums to out[0..GP_KL_BLOCKS)

@@ -533,6 +533,425 @@ __global__ void __launch_bounds__(1024 / CT, CT == 2 ? 2 : 2) cov_mercer_mfma_ke
   }
 }
 
+// Direct-store form of the kernel above (round 3).  The MFMA operands are SWAPPED: the column (frame) features go in as
+// the first operand — lane lc supplying column pi(lc) of the 16-column tile — and the row (inducing-point) features as the
+// second, so the accumulator holds the TRANSPOSED tile and a lane owns ONE row (lc) and four columns pi(kq + 4 r) of it:
+//     float64 output: pi(c) = 2 (c & 3) + ((c >> 2) & 1) + 8 (c >> 3)   ->  columns 2 kq, 2 kq + 1 | 8 + 2 kq, 9 + 2 kq
+//     float32 output: pi(c) = 4 (c & 3) + (c >> 2)                       ->  columns 4 kq .. 4 kq + 3
+// i.e. 16-byte pieces that leave straight from the accumulator registers, 16 rows x 64 contiguous bytes per instruction:
+// no LDS transposition, no wave barriers, and the separable envelope needs ONE row factor (one exp) per lane and tile
+// instead of four.  The products a * b inside the MFMA commute, so every entry is bit-identical to the other form's.
+// Column factors / scaled inputs of the workgroup's 256 columns live in three small LDS tables (a lane reads the four it
+// needs per tile as two ds_read_b128) so the register count — and four wavefronts per SIMD — stay what they were.
+template <int MPAD, int ENV, int CT, bool PF>
+__global__ void __launch_bounds__(1024 / CT, 8 / CT) cov_mercer_mfma_direct_kernel(const CovItem* __restrict__ items,
+                                                                              const double* __restrict__ x2s, int n2s,
+                                                                              int row_seg) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int NF = 2 * MPAD, KS = NF / 4, FS = NF + 1;
+  constexpr int WCOLS = 16 * CT, NWV = 256 / WCOLS, NTH = 64 * NWV;
+  const CovItem it = items[blockIdx.y];
+  const cov_gcptr x1 = (cov_gcptr)it.x1;
+  const int n1 = it.n1;
+  const cov_gcptr x2 = (cov_gcptr)((it.n2 >= 0) ? it.x2 : x2s);
+  const int n2 = (it.n2 >= 0) ? it.n2 : n2s;
+  const cov_gptr out = (cov_gptr)it.out;
+  const cov_gcptr gf1 = (cov_gcptr)it.f1, gf2 = (cov_gcptr)it.f2, th = (cov_gcptr)it.k.theta;
+  const int64_t ld = it.ld;
+  const bool F32O = it.f32out != 0;          // (uniform over the workgroup: blockIdx.y = item)
+  __shared__ double zf[2 * CVM_ROWS * FS];             // two chunks of row features (double-buffered)
+  __shared__ double rowa[2 * CVM_ROWS];
+  __shared__ double tile_lo[2 * (CVM_ROWS / 16)], tile_hi[2 * (CVM_ROWS / 16)];
+  __shared__ double etab[GP_EXP_TAB];
+  __shared__ __attribute__((aligned(16))) double cfp_t[256], cfn_t[256], bsc_t[256];
+  gp_exp_tab_init(etab);
+  const double var = th[0], ls = th[1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kq = lane >> 4;
+  const int jw = blockIdx.x * 256 + wave * WCOLS;
+  const int rbeg = blockIdx.z * row_seg, rend = min(n1, rbeg + row_seg);
+  if ((int)(blockIdx.x * 256) >= n2 || rbeg >= n1) return;
+  const int pc = F32O ? (4 * (lc & 3) + (lc >> 2)) : (2 * (lc & 3) + ((lc >> 2) & 1) + 8 * (lc >> 3));   // pi(lc)
+  // column-side operands, loop-invariant: fragment [k = 4 s + kq] of column pi(lc) of each column tile
+  double bfr[CT][KS], bsc_l[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    const int j = jw + ct * 16 + pc;
+    const bool on = (j < n2);
+    const int jc = on ? j : n2 - 1;
+#pragma unroll
+    for (int s = 0; s < KS; s++) bfr[ct][s] = on ? gf2[(size_t)(4 * s + kq) * n2 + jc] : 0.0;
+    bsc_l[ct] = x2[jc] / ls;
+  }
+  double bmin_w, bmax_w;
+  {
+    double lo = bsc_l[0], hi = bsc_l[0];
+#pragma unroll
+    for (int ct = 1; ct < CT; ct++) { lo = fmin(lo, bsc_l[ct]); hi = fmax(hi, bsc_l[ct]); }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+    bmin_w = lo; bmax_w = hi;
+  }
+  constexpr double SENV = (ENV == 0) ? 1.0 : 2.23606797749979;
+  const bool sep_ok = (SENV * (bmax_w - bmin_w) < 300.0);
+  __syncthreads();                                                 // etab is ready
+  if (kq == 0) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+      const int c = wave * WCOLS + ct * 16 + pc;
+      bsc_t[c] = bsc_l[ct];
+      cfp_t[c] = var * gp_exp_neg(-SENV * (bmax_w - bsc_l[ct]), etab);
+      cfn_t[c] = var * gp_exp_neg(-SENV * (bsc_l[ct] - bmin_w), etab);
+    }
+  }
+  // this lane's two column pairs inside a 16-column tile, and whether 16-byte stores are legal
+  const int c0 = F32O ? 4 * kq : 2 * kq, c1 = F32O ? 4 * kq + 2 : 8 + 2 * kq;
+  const bool vec = it.vec_ok && (F32O ? ((ld & 3) == 0 && (((uintptr_t)it.out) & 15) == 0) : true);
+  // Row chunks are double-buffered: the next chunk's features travel global -> registers while this chunk's tiles are on
+  // the matrix cores, and go registers -> the other LDS buffer afterwards: one barrier per chunk, no load latency in it.
+  constexpr int ZPT = (CVM_ROWS * NF + NTH - 1) / NTH;          // staged feature values per thread and chunk
+  double zr[ZPT], ar = 0.0, tlo = 0.0, thi = 0.0;
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < ZPT; q++) {
+      const int t = tid + q * NTH, f = t / CVM_ROWS, ii = t % CVM_ROWS;
+      zr[q] = (t < CVM_ROWS * NF && r0 + ii < n1) ? gf1[(size_t)f * n1 + r0 + ii] : 0.0;
+    }
+    if (tid < CVM_ROWS) ar = x1[min(r0 + tid, n1 - 1)] / ls;
+    else if (tid < CVM_ROWS + CVM_ROWS / 16) {
+      const int t16 = (tid - CVM_ROWS) * 16;
+      double lo = x1[min(r0 + t16, n1 - 1)] / ls, hi = lo;
+      for (int q = 1; q < 16; q++) { const double v = x1[min(r0 + t16 + q, n1 - 1)] / ls; lo = fmin(lo, v); hi = fmax(hi, v); }
+      tlo = lo; thi = hi;
+    }
+  };
+  auto stash = [&](int buf) {
+    double* zfb = zf + buf * (CVM_ROWS * FS);
+#pragma unroll
+    for (int q = 0; q < ZPT; q++) {
+      const int t = tid + q * NTH, f = t / CVM_ROWS, ii = t % CVM_ROWS;
+      if (t < CVM_ROWS * NF) zfb[ii * FS + f] = zr[q];
+    }
+    if (tid < CVM_ROWS) rowa[buf * CVM_ROWS + tid] = ar;
+    else if (tid < CVM_ROWS + CVM_ROWS / 16) { tile_lo[buf * (CVM_ROWS / 16) + tid - CVM_ROWS] = tlo; tile_hi[buf * (CVM_ROWS / 16) + tid - CVM_ROWS] = thi; }
+  };
+  fetch(rbeg);
+  stash(0);
+  __syncthreads();                       // (also publishes the column tables)
+  int buf = 0;
+  for (int r0 = rbeg; r0 < rend; r0 += CVM_ROWS, buf ^= 1) {
+    const bool more = (r0 + CVM_ROWS < rend);
+    if (!PF && r0 > rbeg) {              // A/B form without the prefetch: load, store, barrier at the head of every chunk
+      __syncthreads();
+      fetch(r0);
+      stash(buf);
+      __syncthreads();
+    }
+    const double* zfb = zf + buf * (CVM_ROWS * FS);
+    const double* rowab = rowa + buf * CVM_ROWS;
+    const double* tlob = tile_lo + buf * (CVM_ROWS / 16);
+    const double* thib = tile_hi + buf * (CVM_ROWS / 16);
+#pragma unroll
+    for (int rt = 0; rt < CVM_ROWS / 16; rt++) {
+      // the next chunk's loads are issued two tiles before they are needed (short live range: the kernel must stay at 128 VGPRs)
+      if (PF && rt == (CVM_ROWS / 16 >= 2 ? CVM_ROWS / 16 - 2 : 0) && more) fetch(r0 + CVM_ROWS);
+      if (r0 + rt * 16 >= n1) continue;
+      d4 acc[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        const double af = zfb[(rt * 16 + lc) * FS + 4 * s + kq];           // row lc of the tile, k = 4 s + kq
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[ct][s], af, acc[ct], 0, 0, 0);
+      }
+      // element r of acc[ct]: row 16 rt + lc, column 16 ct + pi(kq + 4 r) = 16 ct + (r < 2 ? c0 : c1) + (r & 1)   [float64]
+      //                                                                    = 16 ct + c0 + r                          [float32]
+      const double a = rowab[rt * 16 + lc];
+      const int i = r0 + rt * 16 + lc;
+      const bool above = sep_ok && (tlob[rt] - bmax_w >= CVM_SEP), below = sep_ok && (bmin_w - thib[rt] >= CVM_SEP);
+      double res[CT][4];
+      if (above || below) {                 // (wavefront-uniform)
+        const double rf = gp_exp_neg(-SENV * (above ? a - bmax_w : bmin_w - a), etab);
+        const double* cft = (above ? cfp_t : cfn_t) + wave * WCOLS;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+          const cov_d2 f01 = *reinterpret_cast<const cov_d2*>(cft + ct * 16 + c0), f23 = *reinterpret_cast<const cov_d2*>(cft + ct * 16 + c1);
+          const double cf[4] = {f01.x, f01.y, f23.x, f23.y};
+          cov_d2 b01, b23;
+          if (ENV != 0) {
+            b01 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c0);
+            b23 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c1);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            double e = rf * cf[r];
+            if (ENV != 0) {
+              const double b = (r == 0) ? b01.x : (r == 1) ? b01.y : (r == 2) ? b23.x : b23.y;
+              const double rr = fabs(a - b);
+              e *= 1.0 + SENV * rr + (5.0 / 3.0) * (rr * rr);
+            }
+            res[ct][r] = e * acc[ct][r];
+          }
+        }
+      } else {
+        const double aa = __dmul_rn(a, a), m2a = -2.0 * a;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+          const cov_d2 b01 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c0);
+          const cov_d2 b23 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c1);
+          const double bv[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            // (-2 (a b) + a a) + b b, every operation rounded on its own (scaling by -2 is exact)
+            const double rr = gp_sqrt_pos(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m2a, bv[r]), aa), __dmul_rn(bv[r], bv[r])), 1e-12));
+            double env;
+            if (ENV == 0) env = gp_exp_neg(-rr, etab);
+            else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
+            res[ct][r] = var * env * acc[ct][r];
+          }
+        }
+      }
+      if (i < n1) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+          const int jb = jw + ct * 16;
+          if (F32O) {
+            const cov_gfptr o = (cov_gfptr)out + (size_t)i * ld + jb + c0;
+            if (vec && jb + c0 + 3 < n2) {
+              typedef float cov_f4 __attribute__((ext_vector_type(4)));
+              __builtin_nontemporal_store(cov_f4{(float)res[ct][0], (float)res[ct][1], (float)res[ct][2], (float)res[ct][3]},
+                                          (cov_f4 __attribute__((address_space(1)))*)o);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; r++) if (jb + c0 + r < n2) o[r] = (float)res[ct][r];
+            }
+          } else {
+            const cov_gptr o0 = out + (size_t)i * ld + jb + c0, o1 = out + (size_t)i * ld + jb + c1;
+            if (vec && jb + c0 + 1 < n2) __builtin_nontemporal_store(cov_d2{res[ct][0], res[ct][1]}, (cov_gptr2)o0);
+            else { if (jb + c0 < n2) o0[0] = res[ct][0]; if (jb + c0 + 1 < n2) o0[1] = res[ct][1]; }
+            if (vec && jb + c1 + 1 < n2) __builtin_nontemporal_store(cov_d2{res[ct][2], res[ct][3]}, (cov_gptr2)o1);
+            else { if (jb + c1 < n2) o1[0] = res[ct][2]; if (jb + c1 + 1 < n2) o1[1] = res[ct][3]; }
+          }
+        }
+      }
+    }
+    if (PF) {
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+    }
+  }
+}
+
+// Lean free-running form (round 3).  Measured on MI355X (same box, tools/bench_kuf.py): whatever the staged forms above
+// do to the vector work, the m = 20 build takes 0.45 ms; with its stores removed 0.38 ms; the 20 MFMAs of a tile alone
+// are 0.21 ms.  A float64 MFMA occupies the SIMD's vector ALU for its whole 64 cycles — it runs on the float64 vector
+// lanes — so EVERY vector instruction of any wavefront on that SIMD (integer address arithmetic, v_cndmask, cross-lane
+// moves, the IEEE division of z / lengthscale: ~200 per tile in the forms above) adds to the matrix time instead of
+// hiding under it.  This form keeps the row loop's vector work to the envelope products themselves (~25 per tile):
+//  - no LDS staging of the row features and no workgroup barrier in the loop: a wavefront loads its A fragments itself
+//    (scalar base + 32-bit vector offset, one vector add per tile), one tile ahead, two register sets alternating;
+//  - z / lengthscale of the workgroup's rows, the per-wavefront row factors exp(-s (a - bmax)) / exp(-s (bmin - a))
+//    (tile-permuted so a lane's four rows are one 32-byte read) are LDS tables filled once; which tiles lie off the band
+//    is a 64-bit mask in scalar registers; the column factors are registers as before;
+//  - results leave through the per-wavefront LDS transposition tile as whole row pieces (4 rows x 256 bytes per store
+//    instruction: 16 x 64-byte pieces straight from the accumulators measured 3.3 TB/s against 5.6), all LDS and
+//    global offsets loop-invariant or advanced by one scalar-register stride.
+// Whole tiles of the engine's strips only (n2 a multiple of the workgroup's columns, 16-byte alignment, row segments of
+// at most CVL_MAXR): the launcher falls back to cov_mercer_mfma_kernel otherwise.  Entries are bit-identical to it.
+#define CVL_MAXR 512                 // rows per workgroup the LDS tables hold
+template <int MPAD, int ENV, int CT, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 2) cov_mercer_mfma_lean_kernel(const CovItem* __restrict__ items,
+                                                                          const double* __restrict__ x2s, int n2s, int row_seg) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  typedef const char __attribute__((address_space(1))) * gcbytes;
+  typedef char __attribute__((address_space(1))) * gbytes;
+  constexpr int NF = 2 * MPAD, KS = NF / 4;
+  constexpr int WCOLS = 16 * CT, BCOLS = WCOLS * NWV;
+  constexpr int TS = WCOLS + 2;         // LDS row stride of the transposition tile (doubles): rows stay 16-byte aligned
+  const CovItem it = items[blockIdx.y];
+  const cov_gcptr x1 = (cov_gcptr)it.x1;
+  const int n1 = it.n1;
+  const cov_gcptr x2 = (cov_gcptr)((it.n2 >= 0) ? it.x2 : x2s);
+  const int n2 = (it.n2 >= 0) ? it.n2 : n2s;
+  const cov_gcptr gf1 = (cov_gcptr)it.f1, gf2 = (cov_gcptr)it.f2, th = (cov_gcptr)it.k.theta;
+  const int64_t ld = it.ld;
+  const bool F32O = it.f32out != 0;
+  __shared__ double etab[GP_EXP_TAB];
+  // z_i / lengthscale of this workgroup's rows (rows past the end repeat the last) and, per wavefront, the separable
+  // envelope's row factor of every row — both TILE-PERMUTED: row 16 t + q sits at 16 t + 4 (q & 3) + (q >> 2), so the four
+  // rows kq, kq + 4, kq + 8, kq + 12 a lane owns in the accumulator are contiguous
+  __shared__ __attribute__((aligned(16))) double a_t[CVL_MAXR];
+  __shared__ __attribute__((aligned(16))) double rf_t[NWV][CVL_MAXR];
+  __shared__ __attribute__((aligned(16))) double tbuf[NWV][16 * TS];
+  gp_exp_tab_init(etab);
+  const double var = th[0], ls = th[1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kq = lane >> 4;
+  const int jw = blockIdx.x * BCOLS + wave * WCOLS;
+  const int rbeg = blockIdx.z * row_seg, rend = min(n1, rbeg + row_seg);
+  if ((int)(blockIdx.x * BCOLS) >= n2 || rbeg >= n1) return;
+  const int nrow = rend - rbeg, ntile = (nrow + 15) / 16;
+  for (int r = tid; r < ntile * 16; r += 64 * NWV) {
+    const int q = r & 15;
+    a_t[(r & ~15) + 4 * (q & 3) + (q >> 2)] = x1[min(rbeg + r, n1 - 1)] / ls;
+  }
+  double bfr[CT][KS], bsc[CT], bb[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    const int j = jw + ct * 16 + lc;
+#pragma unroll
+    for (int s = 0; s < KS; s++) bfr[ct][s] = gf2[(size_t)(4 * s + kq) * n2 + j];
+    bsc[ct] = x2[j] / ls;
+    bb[ct] = __dmul_rn(bsc[ct], bsc[ct]);
+  }
+  double bmin_w, bmax_w;
+  {
+    double lo = bsc[0], hi = bsc[0];
+#pragma unroll
+    for (int ct = 1; ct < CT; ct++) { lo = fmin(lo, bsc[ct]); hi = fmax(hi, bsc[ct]); }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+    bmin_w = lo; bmax_w = hi;
+  }
+  constexpr double SENV = (ENV == 0) ? 1.0 : 2.23606797749979;
+  const bool sep_ok = (SENV * (bmax_w - bmin_w) < 300.0);
+  __syncthreads();                                                 // etab and a_t are ready (the only workgroup barrier)
+  double cfp[CT], cfn[CT];                                         // var * exp(-s (bmax - b)),  var * exp(-s (b - bmin))
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    cfp[ct] = var * gp_exp_neg(-SENV * (bmax_w - bsc[ct]), etab);
+    cfn[ct] = var * gp_exp_neg(-SENV * (bsc[ct] - bmin_w), etab);
+  }
+  double* rfw = rf_t[wave];
+  for (int r = lane; r < ntile * 16; r += 64) {      // (a pure function of a: the permuted slots map one to one)
+    const double a = a_t[r];
+    double v = 0.0;
+    if (a >= bmax_w) v = gp_exp_neg(-SENV * (a - bmax_w), etab);
+    else if (a <= bmin_w) v = gp_exp_neg(-SENV * (bmin_w - a), etab);
+    rfw[r] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();          // the table is the wavefront's own: its LDS operations complete in order
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double* tw = tbuf[wave];
+  constexpr int PPR = WCOLS / 2, RPI = 64 / PPR;           // store phase: RPI rows x PPR column pairs per instruction
+  const int srow = lane / PPR, scol = (lane % PPR) * 2;
+  // A fragments: element (4 s + kq) * n1 + row of the feature table = uniform base of k-step s + one 32-bit byte offset
+  const uint32_t frow_last = (uint32_t)(kq * n1 + n1 - 1) * 8u;
+  uint32_t foff = min((uint32_t)(kq * n1 + rbeg + lc) * 8u, frow_last);
+  gcbytes fbs[KS];
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    const uint64_t b = (uint64_t)gf1 + (uint64_t)s * ((uint64_t)n1 * 32u);       // 4 feature rows per k-step
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    fbs[s] = (gcbytes)(((uint64_t)hi << 32) | lo);
+  }
+  // output: one 32-bit byte offset per lane (row rbeg + srow, column jw + scol); store q of a tile adds q * RPI rows
+  // (a scalar stride folded into the scalar base), every tile 16 rows
+  const uint32_t esz = F32O ? 4u : 8u;
+  uint32_t ooff = (uint32_t)(((int64_t)(rbeg + srow) * ld + jw + scol) * esz);
+  const uint32_t ostep = (uint32_t)(16 * ld * esz);
+  gbytes obq[16 / RPI];
+#pragma unroll
+  for (int q = 0; q < 16 / RPI; q++) {
+    const uint64_t b = (uint64_t)it.out + (uint64_t)q * (uint64_t)(RPI * ld * esz);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    obq[q] = (gbytes)(((uint64_t)hi << 32) | lo);
+  }
+  uint64_t amask = 0, bmask = 0;
+  // one tile: the NEXT tile's fragments are requested first (into the other register set), then this tile's MFMAs,
+  // envelope, transposition and stores.  Two register sets alternate (tiles are walked in pairs): no copies.
+  auto do_tile = [&](const int t, const int tbit, const double (&afc)[KS], double (&afn)[KS]) {
+    foff = min(foff + 128u, frow_last);                             // rows past the end repeat the last one (never stored)
+#pragma unroll
+    for (int s = 0; s < KS; s++) afn[s] = *(cov_gcptr)(fbs[s] + foff);
+    d4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; s++)
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(afc[s], bfr[ct][s], acc[ct], 0, 0, 0);
+    // element r of acc[ct]: row 16 t + kq + 4 r, column 16 ct + lc of this wavefront's strip
+    const bool above = (amask >> tbit) & 1, below = (bmask >> tbit) & 1;     // scalar
+    const cov_d2 q01 = *reinterpret_cast<const cov_d2*>((above || below ? rfw : a_t) + t * 16 + 4 * kq);
+    const cov_d2 q23 = *reinterpret_cast<const cov_d2*>((above || below ? rfw : a_t) + t * 16 + 4 * kq + 2);
+    const double rv[4] = {q01.x, q01.y, q23.x, q23.y};              // row factors (off the band) or scaled inputs (inside it)
+    if (above || below) {
+      cov_d2 a01, a23;
+      if (ENV != 0) { a01 = *reinterpret_cast<const cov_d2*>(a_t + t * 16 + 4 * kq); a23 = *reinterpret_cast<const cov_d2*>(a_t + t * 16 + 4 * kq + 2); }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+          double e = rv[r] * (above ? cfp[ct] : cfn[ct]);
+          if (ENV != 0) {
+            const double a = (r == 0) ? a01.x : (r == 1) ? a01.y : (r == 2) ? a23.x : a23.y;
+            const double rr = fabs(a - bsc[ct]);
+            e *= 1.0 + SENV * rr + (5.0 / 3.0) * (rr * rr);
+          }
+          tw[(kq + 4 * r) * TS + ct * 16 + lc] = e * acc[ct][r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const double a = rv[r], aa = __dmul_rn(a, a), m2a = -2.0 * a;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+          // (-2 (a b) + a a) + b b, every operation rounded on its own (scaling by -2 is exact)
+          const double rr = gp_sqrt_pos(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m2a, bsc[ct]), aa), bb[ct]), 1e-12));
+          double env;
+          if (ENV == 0) env = gp_exp_neg(-rr, etab);
+          else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
+          tw[(kq + 4 * r) * TS + ct * 16 + lc] = var * env * acc[ct][r];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();          // LDS operations of one wavefront complete in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 16 / RPI; q++) {
+      const int lr = RPI * q + srow;
+      const cov_d2 v = *reinterpret_cast<const cov_d2*>(tw + lr * TS + scol);
+      if (t * 16 + lr < nrow) {               // (only the last tile of a ragged row range masks lanes)
+        if (F32O) __builtin_nontemporal_store(cov_f2{(float)v.x, (float)v.y}, (cov_gfptr2)(obq[q] + ooff));
+        else __builtin_nontemporal_store(v, (cov_gptr2)(obq[q] + ooff));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();          // the tile is rewritten by the next row tile
+    ooff += ostep;
+  };
+  double afA[KS], afB[KS];
+#pragma unroll
+  for (int s = 0; s < KS; s++) afA[s] = *(cov_gcptr)(fbs[s] + foff);
+  for (int tg = 0; tg < ntile; tg += 64) {
+    // which of the next 64 tiles lie wholly on one side of this wavefront's columns (lane = tile)
+    {
+      const int t = min(tg + lane, ntile - 1);
+      double lo = a_t[t * 16], hi = lo;
+#pragma unroll
+      for (int q = 1; q < 16; q++) { const double v = a_t[t * 16 + q]; lo = fmin(lo, v); hi = fmax(hi, v); }
+      amask = __ballot(sep_ok && (lo - bmax_w >= CVM_SEP));
+      bmask = __ballot(sep_ok && (bmin_w - hi >= CVM_SEP));
+    }
+    const int tend = min(ntile, tg + 64);
+    int t = tg;
+    for (; t + 1 < tend; t += 2) {
+      do_tile(t, t - tg, afA, afB);
+      do_tile(t + 1, t + 1 - tg, afB, afA);
+    }
+    if (t < tend) {                          // odd tile count: one more, then put the prefetched set back in place
+      do_tile(t, t - tg, afA, afB);
+#pragma unroll
+      for (int s = 0; s < KS; s++) afA[s] = afB[s];
+    }
+  }
+}
+
 // ---- grouped launches: all matrices of one kernel family (same type, same padded partial count) in one launch ----
 void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const double* x2, int n2, double* out, int64_t ld,
                    int accumulate, double diag_add, double* feat_ws, int f32out) {
@@ -560,7 +979,8 @@ gp_status launch_sm_features_items(gp_handle h, const FeatItem* d_items, int cou
 
 // type / m describe the whole group (the feature tables of a Mercer group must already be built)
 gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem* d_items, int count, int max_n1,
-                                    int max_n2, const double* x2_shared, int n2_shared) {
+                                    int max_n2, const double* x2_shared, int n2_shared, int engine_strips) {
+  const bool lean_items = engine_strips != 0;
   if (count <= 0 || max_n1 <= 0 || max_n2 <= 0) return GP_OK;
   const bool big = (int64_t)max_n1 * max_n2 >= (1 << 20);
   GpTimerScope ts(h, !big ? GP_TIMER_SMALL_GEMM : (gp_kern_is_mercer(type) ? GP_TIMER_KUF_BUILD_SM : GP_TIMER_KUF_BUILD));
@@ -573,11 +993,30 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
       const int colblk = (max_n2 + 255) / 256;
       int nseg = 1;
       while (nseg < 8 && (int64_t)colblk * count * nseg < 512 && (max_n1 + nseg * 2 - 1) / (nseg * 2) >= 2 * CVM_ROWS) nseg *= 2;
+      static const int direct = getenv("GP_KUF_DIRECT") ? atoi(getenv("GP_KUF_DIRECT")) : 3;   // A/B switch: 0 LDS-transposed stores (round 2), 1 direct stores, 2 direct + prefetched row chunks, 3 lean free-running wavefronts
+      constexpr int FREE_NWV = 4;
+      // the lean form takes whole tiles of the engine's strips only, rows in segments its LDS tables hold
+      // (m <= 8 partials: the build is store-bound either way and the staged form's four wavefronts per SIMD are 6 % ahead)
+      const bool lean_ok = (direct == 3) && lean_items && (n2_shared % (16 * CVM_CT * FREE_NWV) == 0) && sm_mpad(m) >= 12;
+      if (lean_ok) while ((max_n1 + nseg - 1) / nseg > CVL_MAXR) nseg *= 2;
       const int row_seg = ((max_n1 + nseg - 1) / nseg + CVM_ROWS - 1) / CVM_ROWS * CVM_ROWS;
       dim3 gm(colblk, count, (max_n1 + row_seg - 1) / row_seg);
+      const dim3 gfree((max_n2 + 16 * CVM_CT * FREE_NWV - 1) / (16 * CVM_CT * FREE_NWV), count, gm.z);
 #define COV_MFMA(MP)                                                                                                   \
       do {                                                                                                             \
-        if (type == GP_KERN_MERCER_MATERN12SM)                                                                         \
+        if (lean_ok && type == GP_KERN_MERCER_MATERN12SM)                                                              \
+          hipLaunchKernelGGL((cov_mercer_mfma_lean_kernel<MP, 0, CVM_CT, FREE_NWV>), gfree, dim3(64 * FREE_NWV), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+        else if (lean_ok)                                                                                              \
+          hipLaunchKernelGGL((cov_mercer_mfma_lean_kernel<MP, 2, CVM_CT, FREE_NWV>), gfree, dim3(64 * FREE_NWV), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+        else if (direct == 2 && type == GP_KERN_MERCER_MATERN12SM)                                                     \
+          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 0, CVM_CT, true>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+        else if (direct == 2)                                                                                          \
+          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 2, CVM_CT, true>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+        else if (direct && type == GP_KERN_MERCER_MATERN12SM)                                                          \
+          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 0, CVM_CT, false>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+        else if (direct)                                                                                               \
+          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 2, CVM_CT, false>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
+        else if (type == GP_KERN_MERCER_MATERN12SM)                                                                         \
           hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0, CVM_CT>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else                                                                                                           \
           hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 2, CVM_CT>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
