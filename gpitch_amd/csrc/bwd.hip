@@ -1211,7 +1211,11 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     GemmFlags f;
     // H = A diag(2 gv) A^T  (symmetric, split-K over the frames); u = A gm and grad q_mu += u are fused into it
     if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
-    else GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
+    else {
+      int uni = ((n & 1) == 0) ? 1 : 0;
+      for (int g = 0; g < G; g++) if (p->gps[g].M != maxM) uni = 0;
+      GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0, uni));
+    }
     // grad q_sqrt += tril(H Lq)
     f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
     GP_CHECK(launch_gemm_batched(h, D(S_HLQ), G, maxM, maxM, f));
@@ -1320,9 +1324,12 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
         if (s0 < 0 || s0 + (int)i >= (int)p->kgps.size() || p->kgps[s0 + i] != fam.gps[i]) return -1;
       return s0;
     };
+    int kuf_uniform = ((n & 1) == 0) ? 1 : 0;        // every GP of the compacted batch M = maxM (R, A, G: arena buffers, even ld)
+    for (int g : p->kgps) if (p->gps[g].M != maxM) kuf_uniform = 0;
     auto kuf_bar = [&](int slot0, int count) -> gp_status {
       GemmFlags f;
       f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
+      f.uniform_aligned = kuf_uniform;
       if (f32) return launch_gemm_f32_role(h, D(S_G) + slot0, count, maxM, n, f);
       return launch_gemm_batched(h, D(S_G) + slot0, count, maxM, n, f);
     };

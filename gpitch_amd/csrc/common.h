@@ -239,7 +239,11 @@ struct GemmFlags {
   int timer = GP_TIMER_SMALL_GEMM;
   int role = 0;          // 1 cond_A, 2 cond_LTA (needs transA), 3 kuf_bar: dedicated 128x128 instantiations
   int tile_m0 = 0, tile_mcount = 0;   // strip products (big tiles, no split-K): only row-blocks [m0, m0 + mcount) (0 = all)
+  int uniform_aligned = 0;            // the caller vouches: every problem has M = maxM (= K structure), N = maxN, 16-byte
+                                      // aligned operands with even leading dimensions (gemm_strip.hip's lean form)
 };
+bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
+                            gp_status* st);
 enum GemmEpi {
   EPI_STORE = 1,     // C = alpha*acc + beta*C
   EPI_COLSUMSQ = 2,  // o0[rowblk*N + n] = sum over the tile's rows of (alpha*acc)^2
@@ -252,8 +256,11 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
 //   prob.A = X (M x Nlong, lda), prob.B = Y (M x Nlong, ldb), prob.v1 = d (Nlong, when scale_by_k), prob.C = H (M x M, ldc)
 //   prob.M = prob.N = M, prob.K = Nlong; prob.o2 = slab workspace (nsplit * M * M doubles).  Only the lower triangle is computed when sym != 0
 //   (upper mirrored).
+// uniform_aligned != 0: every problem has M = maxM, K = maxNlong, 16-byte aligned rows (gemm_strip.hip's lean form)
 gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
-                                        int nsplit, int sym, int scale_by_k, double alpha);
+                                        int nsplit, int sym, int scale_by_k, double alpha, int uniform_aligned = 0);
+bool launch_gemm_strip_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
+                               int scale_by_k, gp_status* st);
 gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, double* const* d_W, const int* d_M,
                                      const int* d_ld, int batch);
 int gemm_nt_nsplit(int M, int Nlong, int batch);

@@ -100,6 +100,7 @@ struct CondBatch {
   size_t off_diag_mats = 0, off_diag_w = 0, off_diag_M = 0, off_diag_ld = 0;   // all panels' diagonal blocks, one batch
 };
 
+int cond_batch_uniform(const CondBatch& cb, int N);
 size_t cond_task_workspace_doubles(int M, int N, int num_partials, bool whiten, bool f32 = false);
 size_t cond_batch_desc_bytes(int count);
 // carve the per-task buffers out of the arena

@@ -294,6 +294,15 @@ static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb, bool resident)
   return cond_batch_block_row_inverse(h, cb);
 }
 
+// every task the same M (so every strip problem is maxM x N), q_sqrt 16-byte aligned: what gemm_strip.hip's form assumes
+// (W, Kuf, A come out of the 256-byte-aligned arena with even leading dimensions)
+int cond_batch_uniform(const CondBatch& cb, int N) {
+  if (cb.tasks.empty() || (N & 1)) return 0;
+  for (const CondTask& t : cb.tasks)
+    if (t.M != cb.maxM || (t.q_sqrt && (((uintptr_t)t.q_sqrt) & 15))) return 0;
+  return 1;
+}
+
 gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, bool whiten, double jitter,
                          bool reuse_factor) {
   const int G = (int)cb.tasks.size();
@@ -357,6 +366,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     GemmFlags f;
     f.triA = TRI_LOWER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A; f.role = 1;
     f.epilogue = EPI_STORE | EPI_COLSUMSQ | (whiten ? EPI_COLDOT : 0);
+    f.uniform_aligned = cond_batch_uniform(cb, N);
     static const bool early_ok = !(getenv("GP_COND_A_EARLY") && atoi(getenv("GP_COND_A_EARLY")) == 0);   // A/B switch
     const bool early = early_ok && forked && cb.diag_ready && cb.maxM > 128 &&
                        hipStreamWaitEvent(h->stream, h->ev_diag, 0) == hipSuccess;
@@ -391,6 +401,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     GemmFlags f;
     f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_LTA; f.role = 2;
     f.epilogue = EPI_COLSUMSQ;
+    f.uniform_aligned = whiten ? cond_batch_uniform(cb, N) : 0;
     if (cb.f32) GP_CHECK(launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
     else GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
   }

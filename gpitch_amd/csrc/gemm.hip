@@ -607,6 +607,10 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
                               const GemmFlags& f) {
   if (batch <= 0 || maxM <= 0 || maxN <= 0) return GP_OK;
   GpTimerScope ts(h, f.timer);
+  {   // whole aligned strips: the form whose K loop issues no vector-ALU instructions (gemm_strip.hip)
+    gp_status st = GP_OK;
+    if (launch_gemm_strip_lean(h, d_probs, batch, maxM, maxN, f, &st)) return st;
+  }
   GemmDevFlags df = to_dev(f);
   // the three frame-strip products of the hot path get their own symbols
   if (f.role == 1) return launch_one<128, 128, false, false, 1>(h, d_probs, batch, maxM, maxN, df, 1);
@@ -633,10 +637,16 @@ int gemm_nt_nsplit(int M, int Nlong, int batch) {
 }
 
 gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
-                                        int nsplit, int sym, int scale_by_k, double alpha) {
+                                        int nsplit, int sym, int scale_by_k, double alpha, int uniform_aligned) {
   if (batch <= 0 || maxM <= 0) return GP_OK;
-  (void)maxNlong;
-  {
+  bool lean = false;
+  if (uniform_aligned) {
+    GpTimerScope ts(h, GP_TIMER_NT_GEMM);
+    gp_status st = GP_OK;
+    lean = launch_gemm_strip_nt_lean(h, d_probs, batch, maxM, maxNlong, nsplit > 1 ? nsplit : 2, sym, scale_by_k, &st);
+    if (lean) GP_CHECK(st);
+  }
+  if (!lean) {
     GpTimerScope ts(h, GP_TIMER_NT_GEMM);
     GemmFlags f;
     f.transA = 0; f.transB = 1;

@@ -336,13 +336,13 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
     DevKern k = sg_kern(p, params, i);
     GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat + (size_t)i * sgpr_feat_stride(p), 1, f32));
   }
-  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ;
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ; f.uniform_aligned = 1;   /* one problem, arena buffers, ld = gp_strip_ld */
     if (f32) { f.role = 1; GP_CHECK(launch_gemm_f32_role(h, desc->probs + 0, 1, M, N, f)); }
     else GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
   hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, p->scal + 2);
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, h->stream, Y, N, p->scal + 1);
   if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
-  else GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
+  else GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0, 1));
   GP_CHECK(launch_rowdot_batched(h, desc->probs + 2, 1, M));
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
@@ -488,7 +488,7 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
   GP_CHECK(launch_gemm_batched(h, D + Q_R, 1, M, M, f));
   GP_CHECK(launch_matvec_batched(h, D + Q_ALPHA, 1, M, 1));
   hipLaunchKernelGGL(fill_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, p->ones, N, 1.0);
-  f = GemmFlags(); f.big_tiles = (M > 64); f.scale_mode = 1; f.timer = GP_TIMER_KUF_BAR; f.role = (M > 64) ? 3 : 0;
+  f = GemmFlags(); f.big_tiles = (M > 64); f.scale_mode = 1; f.timer = GP_TIMER_KUF_BAR; f.role = (M > 64) ? 3 : 0; f.uniform_aligned = 1;
   if (f32) { f.role = 3; GP_CHECK(launch_gemm_f32_role(h, D + Q_G, 1, M, N, f)); }
   else GP_CHECK(launch_gemm_batched(h, D + Q_G, 1, M, N, f));
   // Kuu side (same Cholesky-adjoint chain as the Pdgp backward)
