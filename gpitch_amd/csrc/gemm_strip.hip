@@ -47,6 +47,25 @@ typedef dbl2 __attribute__((address_space(1))) * gptr2;
 #define GS_MFMA_PRIO 2
 #endif
 
+#ifdef GS_STAMPS
+// diagnostic build (never shipped): per-workgroup s_memtime stamps [entry, prologue done, K loop done, epilogue done] + (tm, nkt)
+__device__ unsigned long long gs_stamps[6 * 65536];
+__device__ unsigned int gs_stamp_count;
+extern "C" int gp_debug_strip_stamps(unsigned long long* host, int max_records) {
+  unsigned int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(gs_stamp_count), sizeof(n)) != hipSuccess) return -1;
+  if ((int)n > max_records) n = max_records;
+  if (n > 65536) n = 65536;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(gs_stamps), (size_t)n * 6 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned int z = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(gs_stamp_count), &z, sizeof(z));
+  return (int)n;
+}
+#define GS_STAMP(i) do { if (threadIdx.x == 0) st_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GS_STAMP(i) do { } while (0)
+#endif
+
 struct StripFlags {
   int tilesM, tilesN, tm0;
   int epi;            // EPI_* bitmask
@@ -57,7 +76,8 @@ template <bool TA> struct StripSmem {
   static constexpr int A_ELEMS = GS_BM * GS_BK;
   static constexpr int B_ELEMS = GS_BK * GS_BN;
   static constexpr int STAGE = A_ELEMS + B_ELEMS;
-  static constexpr size_t BYTES = (size_t)2 * STAGE * sizeof(double);
+  static constexpr int V0_OFF = 2 * STAGE;               // 128 doubles behind the stages: v0[i0 .. i0 + 127] (EPI_COLDOT)
+  static constexpr size_t BYTES = (size_t)(2 * STAGE + GS_BM) * sizeof(double);
 };
 
 __device__ __forceinline__ gcbytes gs_uniform(gcbytes p) {
@@ -88,6 +108,10 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
       bz = log / nx; bid = log - bz * nx;
     }
   }
+#ifdef GS_STAMPS
+  unsigned long long st_[4] = {0, 0, 0, 0};
+#endif
+  GS_STAMP(0);
   const GemmProblem p = probs[bz];
   const int tn = bid / f.tilesM;
   const int tm = f.tm0 + (bid % f.tilesM + tn) % f.tilesM;     // row-blocks of a strip adjacent, rotated over the shader engines
@@ -101,6 +125,9 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
 
+  // the tile's 128 entries of v0 (q_mu for A^T q_mu) go to LDS now: the epilogue's 32 reads per lane are then immediates off
+  // one base instead of 64 global loads with 64-bit addresses (measured: 18 k of the 27 k cycles of role 1's epilogue)
+  if ((f.epi & EPI_COLDOT) && tid < GS_BM) smem[S::V0_OFF + tid] = ((gcptr)p.v0)[i0 + tid];
   // ---- operand staging: constant per-lane byte offsets, scalar bases that walk along K --------------------------
   // A, k-contiguous (TAG 1, 3): thread -> row a_i = tid / 2, eight consecutive k from a_k = 8 (tid & 1)
   // A, transposed   (TAG 2)   : thread -> k row a_k = tid / 16, row pairs a_i + 32 q, a_i = 2 (tid & 15)
@@ -241,6 +268,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
     load_tiles();
     if (npair > 0) store_tiles(0, kt, plain); else store_tiles(0, kt, masked);
     __syncthreads();
+    GS_STAMP(1);
     // (the last plain pair goes to the second loop: its second store is the first masked tile, and a masked store inside
     //  this loop gets if-converted into per-element selects on EVERY iteration)
     int it = 0;
@@ -268,6 +296,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
     }
   }
 
+  GS_STAMP(2);
   // ---- epilogue ---------------------------------------------------------------------------------------------------
   // (every wavefront is past its last fragment read: the final barrier of the K loop)
   if (f.epi & EPI_STORE) {
@@ -302,7 +331,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
   }
   if (f.epi & (EPI_COLSUMSQ | EPI_COLDOT)) {
     // per-column reductions over this tile's rows: sum acc^2 and sum acc * v0[row]  (gemm.hip's order)
-    const gcptr gv0 = (gcptr)p.v0;
+    const double* v0s = smem + S::V0_OFF + kq;          // (written in the prologue; every barrier since orders it)
     const gptr go0 = (gptr)p.o0, go1 = (gptr)p.o1;
 #pragma unroll
     for (int b = 0; b < TN; b++) {
@@ -313,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
         for (int r = 0; r < 4; r++) {
           const double v = acc[a][b][r];
           s2 = fma(v, v, s2);
-          if (f.epi & EPI_COLDOT) sd = fma(v, gv0[i0 + a * 16 + kq + 4 * r], sd);
+          if (f.epi & EPI_COLDOT) sd = fma(v, v0s[a * 16 + 4 * r], sd);
         }
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
@@ -324,6 +353,17 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
       }
     }
   }
+#ifdef GS_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  GS_STAMP(3);
+  if (threadIdx.x == 0) {
+    const unsigned int slot = atomicAdd(&gs_stamp_count, 1u);
+    if (slot < 65536) {
+      unsigned long long* o = gs_stamps + 6 * (size_t)slot;
+      o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = (unsigned long long)(TAG * 100 + tm); o[5] = (unsigned long long)nkt;
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
