@@ -77,13 +77,30 @@ template <bool TA> struct StripSmem {
   static constexpr int B_ELEMS = GS_BK * GS_BN;
   static constexpr int STAGE = A_ELEMS + B_ELEMS;
   static constexpr int V0_OFF = 2 * STAGE;               // 128 doubles behind the stages: v0[i0 .. i0 + 127] (EPI_COLDOT)
-  static constexpr size_t BYTES = (size_t)(2 * STAGE + GS_BM) * sizeof(double);
+  static constexpr int SINK_OFF = V0_OFF + GS_BM;        // 4 x 32 doubles: the L2-warming loads' sink, one per wavefront
+  static constexpr size_t BYTES = (size_t)(2 * STAGE + GS_BM + 4 * 32) * sizeof(double);
 };
 
 __device__ __forceinline__ gcbytes gs_uniform(gcbytes p) {
   const uint64_t b = (uint64_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
   return (gcbytes)(((uint64_t)hi << 32) | lo);
+}
+
+// L2 warming: the strips are streamed from HBM once per product and the K loop fetches only one K-tile ahead — with the
+// HBM round trip (5-8 k cycles under load) longer than a K-tile whose MFMA count is small (the diagonal tiles of the
+// symmetric product: 8.0 k cycles per K-tile measured for 4.6 k of MFMA work) the loop runs at memory latency.  One
+// dword per 128-byte line, GS_PF K-tiles ahead, as an LDS-DMA load (global_load_lds_dword: no destination register — an
+// inline-asm load into a scratch VGPR would land long after the compiler has reused that register) into a 256-byte sink
+// per wavefront that nobody reads: the real loads then hit the XCD's L2.
+// MEASURED (same box, GS_PF = 3 and 6 against 0): the dense product 6.34 -> 6.24 ms, but the symmetric split-K product
+// 4.18 -> 4.49 ms, A = W Kuf 3.97 -> 4.16, Lq^T A +2.5 %: the extra requests cost more than the latency they hide.  Off.
+#ifndef GS_PF
+#define GS_PF 0
+#endif
+typedef __attribute__((address_space(3))) void* gs_ldsptr;
+__device__ __forceinline__ void gs_touch(gcbytes base, uint32_t voff, double* sink) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff), (gs_ldsptr)sink, 4, 0, 0);
 }
 
 // TAG 1: op(A) = W (lower), NN.  TAG 2: op(A) = Lq^T (upper; A read transposed), K walked downwards.  TAG 3: dense, NN,
@@ -148,7 +165,15 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
 #pragma unroll
     for (int e = 0; e < EB; e++) rs[e] = f.alpha * gv1[j0 + b_n + (e >> 1) * 32 + (e & 1)];   // (alpha = 2^k: exact)
   }
+  // B strip rows of a K-tile: 16 rows x 8 lines of 128 bytes; wavefront 0 touches rows 0-7, wavefront 1 rows 8-15
+  const uint32_t voffP = (uint32_t)(((int64_t)((lane >> 3) + 8 * (wc & 1)) * p.ldb + j0 + (lane & 7) * 16) * 8);
+  int nld = 0;                              // K-tiles requested so far (scalar)
+  gcbytes sP = gs_uniform((gcbytes)((int64_t)sB + GS_PF * stepB));
+  const bool toucher = __builtin_amdgcn_readfirstlane(wc) < 2;
   auto load_tiles = [&]() {                 // raw loads only: nothing here consumes a loaded value
+    if (GS_PF > 0 && toucher && nld + GS_PF < nkt) gs_touch(sP, voffP, smem + S::SINK_OFF + 32 * wc);
+    sP = (gcbytes)((int64_t)sP + stepB);
+    nld++;
 #pragma unroll
     for (int e = 0; e < EA; e += 2) {
       const dbl2 v = *(gcptr2)(sA + voffA + (TA ? (e >> 1) * 256 : e * 8));
@@ -390,6 +415,10 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_nt_kernel(const GemmProblem
       bz = log / nx; bid = log - bz * nx;
     }
   }
+#ifdef GS_STAMPS
+  unsigned long long st_[4] = {0, 0, 0, 0};
+#endif
+  GS_STAMP(0);
   const GemmProblem p = probs[bz];
   // lower tiles only (sym) — inside an XCD's range the output tile varies fastest: the workgroups resident together work
   // on the same K-slice of different tiles and share its operand strips in that XCD's L2
@@ -430,7 +459,15 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_nt_kernel(const GemmProblem
   gcbytes sV2 = gs_uniform((gcbytes)p.v2 + (int64_t)kbeg * 8);
   const bool scale = f.scale && (p.v1 != nullptr);
   double ra[EA], rb[EB], rs[EB], rg[EA], udot = 0.0;
+  // a K-tile of either operand: 128 rows x one 128-byte line; wavefronts 0, 1 touch the A rows, 2, 3 the B rows
+  const uint32_t voffP = (wc < 2) ? (uint32_t)(((int64_t)(i0 + 64 * (wc & 1) + lane) * p.lda) * 8)
+                                  : (uint32_t)(((int64_t)(j0 + 64 * (wc & 1) + lane) * p.ldb) * 8);
+  int nld = 0;
+  gcbytes sP = gs_uniform(((wc < 2) ? (gcbytes)p.A : (gcbytes)p.B) + (int64_t)(kbeg + GS_PF * GS_BK) * 8);
   auto load_tiles = [&]() {
+    if (GS_PF > 0 && nld + GS_PF < nkt) gs_touch(sP, voffP, smem + S::SINK_OFF + 32 * wc);
+    sP += GS_BK * 8;
+    nld++;
 #pragma unroll
     for (int e = 0; e < EA; e += 2) { const dbl2 v = *(gcptr2)(sA + voffA + e * 8); ra[e] = v.x; ra[e + 1] = v.y; }
 #pragma unroll
@@ -470,7 +507,10 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_nt_kernel(const GemmProblem
     for (int b = 0; b < TN; b++) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
   const int rA = lane;
   const int rB0 = S::A_ELEMS + ct0 * GS_FRAG + lane, rB1 = S::A_ELEMS + ct1 * GS_FRAG + lane;
-  auto mfma_tile = [&](const int stage_off) {
+  // sym_tag = true_type: a diagonal output tile of the symmetric product — row tiles above a column tile are never read back
+  // and are skipped (wave-uniform scalar branches); false_type: every MFMA tile, straight-line (6 of the 10 lower tiles)
+  auto mfma_tile = [&](const int stage_off, auto sym_tag) {
+    constexpr bool SYM = decltype(sym_tag)::value;
     const double* As = smem + stage_off + rA;
     const double* B0 = smem + stage_off + rB0;
     const double* B1 = smem + stage_off + rB1;
@@ -483,33 +523,38 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_nt_kernel(const GemmProblem
       for (int a = 0; a < TM; a++) af[a] = As[(8 * ks + a) * GS_FRAG];
 #pragma unroll
       for (int a = 0; a < TM; a++) {
-        if (a >= cmin0) acc[a][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf0, acc[a][0], 0, 0, 0);
-        if (a >= cmin1) acc[a][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf1, acc[a][1], 0, 0, 0);
+        if (!SYM || a >= cmin0) acc[a][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf0, acc[a][0], 0, 0, 0);
+        if (!SYM || a >= cmin1) acc[a][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf1, acc[a][1], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  if (nkt > 0) {
+  auto k_loop = [&](auto sym_tag) {
     load_tiles();
     store_tiles(0);
     __syncthreads();
     int it = 0;
     for (; it + 2 <= nkt; it += 2) {
-      load_tiles();                        // (the last pair's second request re-reads in range memory only when more follows)
-      mfma_tile(0);
+      load_tiles();
+      mfma_tile(0, sym_tag);
       store_tiles(S::STAGE);
       __syncthreads();
       const bool more = (it + 2 < nkt);
       if (more) load_tiles();
-      mfma_tile(S::STAGE);
+      mfma_tile(S::STAGE, sym_tag);
       if (more) store_tiles(0);
       __syncthreads();
     }
     if (it < nkt) {                        // odd count: the last K-tile sits in stage 0
-      mfma_tile(0);
+      mfma_tile(0, sym_tag);
       __syncthreads();
     }
+  };
+  GS_STAMP(1);
+  if (nkt > 0) {
+    if (diag_sym) k_loop(std::true_type{}); else k_loop(std::false_type{});
   }
+  GS_STAMP(2);
   // ---- epilogue: the K-slice's slab [ksl][M][N] --------------------------------------------------------------------
   {
     constexpr int TS = 34;
@@ -546,6 +591,17 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_nt_kernel(const GemmProblem
       if ((tid & 1) == 0) ((gptr)p.o1)[(int64_t)ksl * p.M + i0 + s_r] = udot;
     }
   }
+#ifdef GS_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  GS_STAMP(3);
+  if (threadIdx.x == 0) {
+    const unsigned int slot = atomicAdd(&gs_stamp_count, 1u);
+    if (slot < 65536) {
+      unsigned long long* o = gs_stamps + 6 * (size_t)slot;
+      o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = (unsigned long long)(400 + (diag_sym ? 1 : 0) + (tn == 0 ? 10 : 0)); o[5] = (unsigned long long)nkt;
+    }
+  }
+#endif
 }
 
 bool launch_gemm_strip_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
