@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
   const int64_t stepB = (KDOWN ? -1 : 1) * (int64_t)GS_BK * p.ldb * 8;
   gcbytes sA = gs_uniform((gcbytes)p.A + (TA ? (int64_t)kfirst * p.lda * 8 : (int64_t)kfirst * 8));
   gcbytes sB = gs_uniform((gcbytes)p.B + (int64_t)kfirst * p.ldb * 8);
-  double ra[EA], rb[EB], rs[EB];
+  double ra[EA], rbX[EB], rbY[EB], rs[EB];
   if (TAG == 3) {
     const gcptr gv1 = (gcptr)p.v1;
 #pragma unroll
@@ -167,24 +167,30 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
   }
   // B strip rows of a K-tile: 16 rows x 8 lines of 128 bytes; wavefront 0 touches rows 0-7, wavefront 1 rows 8-15
   const uint32_t voffP = (uint32_t)(((int64_t)((lane >> 3) + 8 * (wc & 1)) * p.ldb + j0 + (lane & 7) * 16) * 8);
-  int nld = 0;                              // K-tiles requested so far (scalar)
+  int nld = 0;                              // B K-tiles requested so far (scalar)
   gcbytes sP = gs_uniform((gcbytes)((int64_t)sB + GS_PF * stepB));
   const bool toucher = __builtin_amdgcn_readfirstlane(wc) < 2;
-  auto load_tiles = [&]() {                 // raw loads only: nothing here consumes a loaded value
-    if (GS_PF > 0 && toucher && nld + GS_PF < nkt) gs_touch(sP, voffP, smem + S::SINK_OFF + 32 * wc);
-    sP = (gcbytes)((int64_t)sP + stepB);
-    nld++;
+  // raw loads only: nothing here consumes a loaded value.  op(A) (M x M, L2-resident) is requested one K-tile ahead; the
+  // B strip — streamed from HBM once per product, every row-block of a strip waiting on the same fetch — TWO ahead,
+  // into two register sets that alternate with the (unrolled) LDS stages: with one K-tile of lookahead the K-tiles whose
+  // MFMA count is small (the diagonal block: 7.1 k cycles per K-tile measured for 2.3 k of MFMA work) ran at HBM latency.
+  auto load_A = [&]() {
 #pragma unroll
     for (int e = 0; e < EA; e += 2) {
       const dbl2 v = *(gcptr2)(sA + voffA + (TA ? (e >> 1) * 256 : e * 8));
       ra[e] = v.x; ra[e + 1] = v.y;
     }
+    sA = (gcbytes)((int64_t)sA + stepA);    // (scalar ALU)
+  };
+  auto load_B = [&](double (&rb)[EB]) {
+    if (GS_PF > 0 && toucher && nld + GS_PF < nkt) gs_touch(sP, voffP, smem + S::SINK_OFF + 32 * wc);
+    sP = (gcbytes)((int64_t)sP + stepB);
+    nld++;
 #pragma unroll
     for (int e = 0; e < EB; e += 2) {
       const dbl2 v = *(gcptr2)(sB + voffB + (e >> 1) * 256);
       rb[e] = v.x; rb[e + 1] = v.y;
     }
-    sA = (gcbytes)((int64_t)sA + stepA);    // (scalar ALU)
     sB = (gcbytes)((int64_t)sB + stepB);
   };
   // LDS: per-lane bases of stage 0; stage 1 = + STAGE * 8 bytes (an immediate).  Element (row i, k) of op(A) sits at
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
                     : ((8 * (a_k >> 2) + (a_i >> 4)) * GS_FRAG + (a_i & 15));          // (a_k = 0 or 8: k & 3 = 0)
   const int wB = S::A_ELEMS + (8 * (b_k >> 2) + (b_n >> 4)) * GS_FRAG + 16 * (b_k & 3) + (b_n & 15);
   // mask_tag = false_type: the K-tile lies wholly outside the diagonal block (no structural zeros to write)
-  auto store_tiles = [&](const int stage_off, int kt, auto mask_tag) {       // stage_off: 0 or STAGE (a literal in the unrolled loop)
+  auto store_tiles = [&](const int stage_off, int kt, auto mask_tag, double (&rb)[EB]) {       // stage_off: 0 or STAGE (literals)
     constexpr bool MASK = decltype(mask_tag)::value;
     double* As = smem + stage_off + wA;
     double* Bs = smem + stage_off + wB;
@@ -290,33 +296,43 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
     const std::true_type masked{};
     const std::false_type plain{};
     int kt = kfirst;
-    load_tiles();
-    if (npair > 0) store_tiles(0, kt, plain); else store_tiles(0, kt, masked);
+    load_A();
+    load_B(rbX);
+    if (npair > 0) store_tiles(0, kt, plain, rbX); else store_tiles(0, kt, masked, rbX);
     __syncthreads();
+    if (nkt > 1) load_B(rbY);                 // B of K-tile 1: in flight over the whole first K-tile
     GS_STAMP(1);
-    // (the last plain pair goes to the second loop: its second store is the first masked tile, and a masked store inside
-    //  this loop gets if-converted into per-element selects on EVERY iteration)
+    // (nkt is a multiple of 8: both loops walk pairs of K-tiles, stages and B register sets alternating as literals.  The
+    //  last plain pair goes to the second loop: its second store is the first masked tile, and a masked store inside the
+    //  first loop gets if-converted into per-element selects on EVERY iteration)
     int it = 0;
     for (; it + 2 < npair; it += 2) {
-      load_tiles();
+      load_A();                               // A(it + 1)
+      load_B(rbX);                            // B(it + 2)
       mfma_full(0);
-      store_tiles(S::STAGE, kt + kstep, plain);
+      store_tiles(S::STAGE, kt + kstep, plain, rbY);
       __syncthreads();
       kt += kstep;
-      load_tiles();
+      load_A();                               // A(it + 2)
+      if (it + 3 < nkt) load_B(rbY);          // B(it + 3)
       mfma_full(S::STAGE);
-      store_tiles(0, kt + kstep, plain);
+      store_tiles(0, kt + kstep, plain, rbX);
       __syncthreads();
       kt += kstep;
     }
-    int so = 0;
-    for (; it < nkt; it++) {
-      const bool more = (it + 1 < nkt);
-      if (more) load_tiles();
-      mfma_diag(so, kt);
-      if (more) store_tiles(so ^ S::STAGE, kt + kstep, masked);
+    for (; it < nkt; it += 2) {
+      load_A();
+      if (it + 2 < nkt) load_B(rbX);
+      mfma_diag(0, kt);
+      store_tiles(S::STAGE, kt + kstep, masked, rbY);
       __syncthreads();
-      so ^= S::STAGE;
+      kt += kstep;
+      const bool more = (it + 2 < nkt);
+      if (more) load_A();
+      if (it + 3 < nkt) load_B(rbY);
+      mfma_diag(S::STAGE, kt);
+      if (more) store_tiles(0, kt + kstep, masked, rbX);
+      __syncthreads();
       kt += kstep;
     }
   }
@@ -551,9 +567,9 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_nt_kernel(const GemmProblem
     }
   };
   GS_STAMP(1);
-  if (nkt > 0) {
-    if (diag_sym) k_loop(std::true_type{}); else k_loop(std::false_type{});
-  }
+  // (one instantiation: per-MFMA scalar branches on every tile measured the same 4.14 ms as separate plain / symmetric
+  //  loops, which needed 17 spilled VGPRs)
+  if (nkt > 0) k_loop(std::true_type{});
   GS_STAMP(2);
   // ---- epilogue: the K-slice's slab [ksl][M][N] --------------------------------------------------------------------
   {
