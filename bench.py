@@ -508,15 +508,19 @@ def main():
             sym = {"cond_A": "gemm_f32_kernel<1>", "cond_LTA": "gemm_f32_kernel<2>", "nt_gemm": "gemm_f32_kernel<4>",
                    "kuf_bar": "gemm_f32_kernel<3>"}
         else:
-            sym = {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
-                   "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"}
+            # (whole aligned strips run gemm_strip.hip's lean forms; ragged shapes fall back to gemm_f64_kernel<128,128,...>)
+            lean = (M % 128 == 0) and (N % 128 == 0) and os.environ.get("GP_STRIP_LEAN", "1") != "0"
+            sym = ({"cond_A": "gemm_strip_kernel<1>", "cond_LTA": "gemm_strip_kernel<2>", "nt_gemm": "gemm_strip_nt_kernel",
+                    "kuf_bar": "gemm_strip_kernel<3>"} if lean else
+                   {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
+                    "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"})
         # roofline (by its definition): the dominant kernel's OWN algorithmic flops per launch / its OWN mean launch
         # duration (HIP events on the stream it is launched on).  At overlap level 2 other kernels share the chip with
         # it (the split-K product on the helper stream), which lengthens its launch: that shows up here, undisguised.
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (tools/make_traffic_json.py)
-            tfile = os.path.join("profiles", "r02", "hbm_traffic.json")
+            tfile = os.path.join("profiles", "r03", "hbm_traffic.json")
             tj = json.load(open(os.path.join(ROOT, tfile)))
             if (N, M, G, args.partials) == (32768, 512, 24, 20) and tj.get("overlap_level", 2) == args.overlap and not f32:
                 traffic = tj["kernels"][sym[dom].replace(" ", "")]["hbm_bytes"]

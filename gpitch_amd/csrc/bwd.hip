@@ -1210,11 +1210,11 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
   auto h_chain_head = [&]() -> gp_status {
     GemmFlags f;
     // H = A diag(2 gv) A^T  (symmetric, split-K over the frames); u = A gm and grad q_mu += u are fused into it
-    if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0));
-    else {
-      int uni = ((n & 1) == 0) ? 1 : 0;
+    {
+      int uni = ((n & 3) == 0) ? 1 : 0;
       for (int g = 0; g < G; g++) if (p->gps[g].M != maxM) uni = 0;
-      GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0, uni));
+      if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0, uni));
+      else GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0, uni));
     }
     // grad q_sqrt += tril(H Lq)
     f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;

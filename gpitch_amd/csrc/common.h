@@ -259,6 +259,10 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
 // uniform_aligned != 0: every problem has M = maxM, K = maxNlong, 16-byte aligned rows (gemm_strip.hip's lean form)
 gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
                                         int nsplit, int sym, int scale_by_k, double alpha, int uniform_aligned = 0);
+bool launch_gemm_strip_f32_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
+                                gp_status* st);
+bool launch_gemm_strip_f32_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
+                                   int scale_by_k, gp_status* st);
 bool launch_gemm_strip_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
                                int scale_by_k, gp_status* st);
 gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, double* const* d_W, const int* d_M,
@@ -269,7 +273,7 @@ gp_status launch_slab_reduce(gp_handle h, const GemmProblem* d_probs, int batch,
 // strips, float64 slabs).  Same descriptor struct; ldb / ldc (and lda for nt) count floats.
 gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f);
 gp_status launch_gemm_f32_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
-                                            int nsplit, int sym, int scale_by_k, double alpha);
+                                            int nsplit, int sym, int scale_by_k, double alpha, int uniform_aligned = 0);
 // leading dimension (in elements) of an M x N strip: even for float64, a multiple of 4 for float32 (16-byte rows)
 static inline int64_t gp_strip_ld(int N, bool f32) { return f32 ? (((int64_t)N + 3) & ~(int64_t)3) : (((int64_t)N + 1) & ~(int64_t)1); }
 // doubles that hold an M x ld strip of either type

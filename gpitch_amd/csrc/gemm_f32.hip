@@ -452,6 +452,10 @@ static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, 
 gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& gf) {
   if (batch <= 0 || maxM <= 0 || maxN <= 0) return GP_OK;
   GpTimerScope ts(h, gf.timer);
+  {   // whole aligned strips: gemm_strip_f32.hip's lean form
+    gp_status st = GP_OK;
+    if (launch_gemm_strip_f32_lean(h, d_probs, batch, maxM, maxN, gf, &st)) return st;
+  }
   Gemm32Flags f;
   f.alpha = gf.alpha; f.epi = gf.epilogue; f.scale = gf.scale_mode; f.sym = 0; f.ksplit = 1; f.tilesM = f.tilesN = 1;
   f.tm0 = gf.tile_m0; f.tilesM_req = gf.tile_mcount;
@@ -468,10 +472,16 @@ gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batc
 // float64 (slab_reduce_kernel of gemm.hip, shared)
 gp_status launch_slab_reduce(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int nsplit, int sym, double alpha);
 gp_status launch_gemm_f32_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
-                                            int nsplit, int sym, int scale_by_k, double alpha) {
+                                            int nsplit, int sym, int scale_by_k, double alpha, int uniform_aligned) {
   if (batch <= 0 || maxM <= 0) return GP_OK;
-  (void)maxNlong;
-  {
+  bool lean = false;
+  if (uniform_aligned) {
+    GpTimerScope ts(h, GP_TIMER_NT_GEMM);
+    gp_status st = GP_OK;
+    lean = launch_gemm_strip_f32_nt_lean(h, d_probs, batch, maxM, maxNlong, nsplit > 1 ? nsplit : 2, sym, scale_by_k, &st);
+    if (lean) GP_CHECK(st);
+  }
+  if (!lean) {
     GpTimerScope ts(h, GP_TIMER_NT_GEMM);
     Gemm32Flags f;
     f.alpha = 1.0; f.epi = 1; f.scale = scale_by_k; f.sym = sym; f.ksplit = nsplit > 1 ? nsplit : 2; f.tilesM = f.tilesN = 1;

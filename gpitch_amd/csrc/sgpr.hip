@@ -341,7 +341,7 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
     else GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
   hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, p->scal + 2);
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, h->stream, Y, N, p->scal + 1);
-  if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0));
+  if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0, 1));
   else GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0, 1));
   GP_CHECK(launch_rowdot_batched(h, desc->probs + 2, 1, M));
   GP_HIP_CHECK(h, hipGetLastError());
