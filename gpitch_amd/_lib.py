@@ -27,7 +27,7 @@ TIMER_NAMES = ["kuf_build", "cond_A", "cond_LTA", "nt_gemm", "kuf_bar", "chol", 
 ABI_SYMBOLS = [
     "gp_create", "gp_destroy", "gp_sync", "gp_last_error", "gp_abi_version", "gp_last_not_pd_index",
     "gp_kernel_build", "gp_kernel_build_f32", "gp_kernel_diag", "gp_chol_workspace_bytes", "gp_kuu_cholesky", "gp_cholesky_inplace",
-    "gp_conditional_workspace_bytes", "gp_conditional_diag", "gp_conditional_diag_f32", "gp_conditional_full_workspace_bytes", "gp_conditional_full", "gp_gauss_kl_workspace_bytes", "gp_gauss_kl", "gp_gauss_kl_matrix", "gp_mpd_varexp",
+    "gp_conditional_workspace_bytes", "gp_conditional_diag", "gp_conditional_diag_f32", "gp_conditional_diag_f32w", "gp_conditional_full_workspace_bytes", "gp_conditional_full", "gp_gauss_kl_workspace_bytes", "gp_gauss_kl", "gp_gauss_kl_matrix", "gp_mpd_varexp",
     "gp_pdgp_create", "gp_pdgp_destroy", "gp_pdgp_num_params", "gp_pdgp_layout", "gp_pdgp_workspace_bytes",
     "gp_pdgp_set_workspace", "gp_pdgp_set_precision", "gp_pdgp_set_grad_needs", "gp_pdgp_set_overlap", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_create_subset", "gp_pdgp_cond_begin", "gp_pdgp_cond_end", "gp_pdgp_predict", "gp_pdgp_predict_reuse",
     "gp_overlap_merge", "gp_transform_register_logistic", "gp_transform_forward", "gp_transform_backward", "gp_poll_not_pd", "gp_check_not_pd", "gp_take_not_pd", "gp_adam_step",
@@ -118,6 +118,7 @@ def load_library():
         "gp_conditional_full_workspace_bytes": (sz, [i32, i32]),
         "gp_conditional_full": (i32, [vp, KD, vp, i32, vp, i32, vp, vp, i32, dbl, vp, vp, vp, sz]),
         "gp_conditional_diag_f32": (i32, [vp, KD, vp, i32, vp, i32, vp, vp, dbl, vp, vp, vp, sz]),
+        "gp_conditional_diag_f32w": (i32, [vp, KD, vp, i32, vp, i32, vp, vp, i32, dbl, vp, vp, vp, sz]),
         "gp_gauss_kl_workspace_bytes": (sz, [i32, i32]),
         "gp_gauss_kl": (i32, [vp, vp, vp, i32, KD, vp, dbl, C.POINTER(dbl), vp, sz]),
         "gp_gauss_kl_matrix": (i32, [vp, vp, vp, i32, vp, C.POINTER(dbl), vp, sz]),

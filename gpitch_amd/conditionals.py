@@ -16,7 +16,7 @@ def _kdesc(h, kern):
 def conditional(Xnew, X, kern, f, full_cov=False, q_sqrt=None, whiten=False, float_type=None):
     """mean and variance of f(Xnew) given q(u) = N(f, q_sqrt q_sqrt^T) at inducing inputs X.
     full_cov=True: the variance is the N x N x 1 posterior covariance (GPflow's shape for one latent column).
-    float_type=np.float32 (whiten=True only): the strips and strip products in float32 (gp_conditional_diag_f32)."""
+    float_type=np.float32: the strips and strip products in float32 (gp_conditional_diag_f32)."""
     h = _lib.default_handle()
     Xnew = np.asarray(Xnew, dtype=np.float64).reshape(-1, 1)
     X = np.asarray(X, dtype=np.float64).reshape(-1, 1)
@@ -46,11 +46,9 @@ def conditional(Xnew, X, kern, f, full_cov=False, q_sqrt=None, whiten=False, flo
     fm, fv = h.empty(max(N, 1)), h.empty(max(N, 1))
     ws = h.workspace(h.lib.gp_conditional_workspace_bytes(N, M))
     if _lib.precision_bits(float_type) == 32:
-        if not whiten:
-            raise ValueError("float_type=float32 needs whiten=True")
-        h.check(h.lib.gp_conditional_diag_f32(h.h, C.byref(d), dx.data_ptr(), N, dz.data_ptr(), M, dmu.data_ptr(),
-                                              None if dsq is None else dsq.data_ptr(), 1e-6,
-                                              fm.data_ptr(), fv.data_ptr(), ws.data_ptr(), ws.numel()))
+        h.check(h.lib.gp_conditional_diag_f32w(h.h, C.byref(d), dx.data_ptr(), N, dz.data_ptr(), M, dmu.data_ptr(),
+                                               None if dsq is None else dsq.data_ptr(), int(bool(whiten)), 1e-6,
+                                               fm.data_ptr(), fv.data_ptr(), ws.data_ptr(), ws.numel()))
         return fm[:N].cpu().numpy().reshape(-1, 1), fv[:N].cpu().numpy().reshape(-1, 1)
     h.check(h.lib.gp_conditional_diag(h.h, C.byref(d), dx.data_ptr(), N, dz.data_ptr(), M, dmu.data_ptr(),
                                       None if dsq is None else dsq.data_ptr(), int(bool(whiten)), 1e-6,

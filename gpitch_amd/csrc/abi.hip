@@ -321,6 +321,13 @@ gp_status gp_conditional_diag_f32(gp_handle h, const gp_kernel_desc* kern, const
                                true, "gp_conditional_diag_f32: bad argument");
 }
 
+gp_status gp_conditional_diag_f32w(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N, const double* z,
+                                   int32_t M, const double* q_mu, const double* q_sqrt, int32_t whiten, double jitter,
+                                   double* fmean, double* fvar, void* workspace, size_t workspace_bytes) {
+  return conditional_diag_impl(h, kern, xnew, N, z, M, q_mu, q_sqrt, whiten, jitter, fmean, fvar, workspace, workspace_bytes,
+                               true, "gp_conditional_diag_f32w: bad argument");
+}
+
 // full_cov = True of the same operator (GPflow 0.5 conditionals.conditional): the N x N posterior covariance
 //   K(xnew, xnew) - A^T A + (Lq^T A')^T (Lq^T A'),   A = Lm^-1 Kuf,  A' = A (whitened) or Lm^-T A (unwhitened).
 // Never used by the reference's own callers (its N is a window of frames: N^2 values); here for API parity.

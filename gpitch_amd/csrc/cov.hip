@@ -1002,19 +1002,20 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
       const int row_seg = ((max_n1 + nseg - 1) / nseg + CVM_ROWS - 1) / CVM_ROWS * CVM_ROWS;
       dim3 gm(colblk, count, (max_n1 + row_seg - 1) / row_seg);
       const dim3 gfree((max_n2 + 16 * CVM_CT * FREE_NWV - 1) / (16 * CVM_CT * FREE_NWV), count, gm.z);
+      const int mode = lean_ok ? 3 : (direct == 3 ? 0 : direct);     // (the lean form's fall-back is the staged round-2 kernel)
 #define COV_MFMA(MP)                                                                                                   \
       do {                                                                                                             \
         if (lean_ok && type == GP_KERN_MERCER_MATERN12SM)                                                              \
           hipLaunchKernelGGL((cov_mercer_mfma_lean_kernel<MP, 0, CVM_CT, FREE_NWV>), gfree, dim3(64 * FREE_NWV), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else if (lean_ok)                                                                                              \
           hipLaunchKernelGGL((cov_mercer_mfma_lean_kernel<MP, 2, CVM_CT, FREE_NWV>), gfree, dim3(64 * FREE_NWV), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (direct == 2 && type == GP_KERN_MERCER_MATERN12SM)                                                     \
+        else if (mode == 2 && type == GP_KERN_MERCER_MATERN12SM)                                                       \
           hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 0, CVM_CT, true>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (direct == 2)                                                                                          \
+        else if (mode == 2)                                                                                            \
           hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 2, CVM_CT, true>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (direct && type == GP_KERN_MERCER_MATERN12SM)                                                          \
+        else if (mode == 1 && type == GP_KERN_MERCER_MATERN12SM)                                                       \
           hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 0, CVM_CT, false>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (direct)                                                                                               \
+        else if (mode == 1)                                                                                            \
           hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 2, CVM_CT, false>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else if (type == GP_KERN_MERCER_MATERN12SM)                                                                         \
           hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0, CVM_CT>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \

@@ -63,7 +63,6 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   const int G = (int)cb.tasks.size();
   const int N = cb.N;
   const int64_t ldN = gp_strip_ld(N, cb.f32);
-  if (cb.f32 && !whiten) return gp_fail(h, GP_ERR_UNSUPPORTED, "float32 strips: whitened conditionals only");
   size_t need = cond_batch_desc_bytes(G);
   if (cb.desc_bytes < need || !cb.d_desc) return gp_fail(h, GP_ERR_WORKSPACE, "descriptor workspace too small");
   cb.h_desc.assign(need, 0);
@@ -390,7 +389,9 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     GemmFlags f;
     f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A;
     f.epilogue = EPI_STORE | EPI_COLDOT;
-    GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1u), G, cb.maxM, N, f));
+    // float32 strips: the same product shape as Lq^T A (op(A) = W^T upper, read row-wise), stored: role 2 of gemm_f32.hip
+    if (cb.f32) { f.role = 2; f.timer = GP_TIMER_COND_A; GP_CHECK(launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f1u), G, cb.maxM, N, f)); }
+    else GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1u), G, cb.maxM, N, f));
   }
   // 5. LTA = tril(q_sqrt)^T A  (only its column sums of squares are needed)
   bool any_qsqrt = false;

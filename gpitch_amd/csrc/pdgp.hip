@@ -105,7 +105,6 @@ gp_status gp_pdgp_set_grad_needs(gp_pdgp_plan p, int32_t g, int32_t need_theta, 
 gp_status gp_pdgp_set_precision(gp_pdgp_plan p, int32_t bits) {
   if (!p || (bits != 32 && bits != 64)) return GP_ERR_BAD_ARG;
   if (p->ws) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_pdgp_set_precision: call it before gp_pdgp_set_workspace");
-  if (bits == 32 && !p->whiten) return gp_fail(p->h, GP_ERR_UNSUPPORTED, "gp_pdgp_set_precision: float32 strips need whiten = 1");
   p->f32 = (bits == 32);
   p->cb.f32 = (bits == 32);
   return GP_OK;

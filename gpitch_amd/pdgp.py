@@ -70,10 +70,9 @@ class Pdgp(Parameterized):
         float_type: the reference's `settings.dtypes.float_type` (pdgp.py:13), np.float64 (default) or np.float32.
         With float32 the M x N strips (Kuf, Lm^-1 Kuf, Kuf_bar) and the four O(M^2 N) products are float32 on the
         float32 matrix cores; parameters, Kuu, its Cholesky factor, all reductions, the likelihood and the
-        gradients stay float64 (include/gpitch_abi.h: gp_pdgp_set_precision).  Whitened models only."""
+        gradients stay float64 (include/gpitch_abi.h: gp_pdgp_set_precision); `whiten` and `float_type` are independent, as in
+        the reference (pdgp.py:13,49,122-129)."""
         self._bits = _lib.precision_bits(float_type)
-        if self._bits == 32 and not whiten:
-            raise ValueError("float_type=float32 needs whiten=True")
         x = np.asarray(x, dtype=np.float64).reshape(-1, 1)
         y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
         if minibatch_size is None:

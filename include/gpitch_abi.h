@@ -127,6 +127,13 @@ gp_status gp_conditional_diag_f32(gp_handle h, const gp_kernel_desc* kern, const
                                   const double* z, int32_t M, const double* q_mu, const double* q_sqrt,
                                   double jitter, double* fmean, double* fvar,
                                   void* workspace, size_t workspace_bytes);
+/* ... with the `whiten` argument of conditional(): in the reference `whiten` and `float_type` are independent settings
+ * (gpitch/pdgp.py:13,49,122-129).  whiten = 0 adds A' = Lm^-T A as a third float32 strip product; its rounding is
+ * amplified by cond(Kuu) instead of cond(Kuu)^(1/2) (tolerances: tests/test_gpu_f32.py). */
+gp_status gp_conditional_diag_f32w(gp_handle h, const gp_kernel_desc* kern, const double* xnew, int32_t N,
+                                   const double* z, int32_t M, const double* q_mu, const double* q_sqrt,
+                                   int32_t whiten, double jitter, double* fmean, double* fvar,
+                                   void* workspace, size_t workspace_bytes);
 /* full_cov = True of the same operator (GPflow 0.5 conditionals.conditional; gpitch/pdgp.py never asks for it): fmean (N)
  * and the N x N posterior covariance fcov (row-major, ld N) = K(xnew) - A^T A + (Lq^T A')^T (Lq^T A').
  * workspace: gp_conditional_full_workspace_bytes(N, M). */
