@@ -24,6 +24,18 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define CH_THREADS 512
 #define CH_WAVES (CH_THREADS / 64)
 
+#ifdef CH_STAMPS
+// diagnostic build (never shipped; tools/chol_stamps.py): s_memtime stamps of matrix 0's workgroup, per 32-column panel
+// [panel start, panel product done, trailing update done, look-ahead diagonal block start, end]
+__device__ unsigned long long ch_stamps[5 * 64];
+extern "C" int gp_debug_chol_stamps(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(ch_stamps), sizeof(ch_stamps)) == hipSuccess ? 0 : -1;
+}
+#define CH_STAMP(k, i) do { if (b == 0 && (k) < 64) ch_stamps[5 * (k) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CH_STAMP(k, i) do { } while (0)
+#endif
+
 // broadcast lane `src` (a compile-time constant after unrolling) through SGPRs: v_readlane_b32 x2
 __device__ __forceinline__ double lane_bcast(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -144,6 +156,7 @@ __device__ __forceinline__ void chol_body(PT A, const int M, const int64_t ld, i
     const int r0 = k0 + nb;  // first trailing row
     const int R = M - r0;
     if (R <= 0) break;
+    if (tid == 0) CH_STAMP(k0 / CH_NB, 0);
     // ---- panel: X = A_panel * L_kk^-T on the matrix cores, 16 rows per wavefront step ----------
     for (int rg = wave; rg * 16 < R; rg += CH_WAVES) {
       const int ra = r0 + rg * 16 + lc;
@@ -171,6 +184,7 @@ __device__ __forceinline__ void chol_body(PT A, const int M, const int64_t ld, i
     if (tid == 0) tile_counter = 0;
     __threadfence_block();
     __syncthreads();
+    if (tid == 0) CH_STAMP(k0 / CH_NB, 1);
     // ---- trailing update A22 -= X X^T (lower triangle), 32 x 32 macro tiles handed out dynamically.  Macro tile
     //      0 is the NEXT diagonal block: the wavefront that draws it factorises that block straight away
     //      (look-ahead), overlapping the serial 32-column factorisation with the other waves' updates.
@@ -232,11 +246,14 @@ __device__ __forceinline__ void chol_body(PT A, const int M, const int64_t ld, i
       }
       if (t == 0) {
         __threadfence_block();  // this wave's own updates of the block it is about to read back
+        if (lane == 0) CH_STAMP(k0 / CH_NB, 3);
         chol_diag_block(A, ld, M, r0, lane, D[pb ^ 1], status, b, pivot_base);
+        if (lane == 0) CH_STAMP(k0 / CH_NB, 4);
       }
     }
     __threadfence_block();
     __syncthreads();
+    if (tid == 0) CH_STAMP(k0 / CH_NB, 2);
   }
   // zero the strictly-upper triangle so L can be used as a dense operand
   for (int64_t idx = tid; idx < (int64_t)M * M; idx += CH_THREADS) {

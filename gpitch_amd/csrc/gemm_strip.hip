@@ -98,6 +98,9 @@ __device__ __forceinline__ gcbytes gs_uniform(gcbytes p) {
 #ifndef GS_PF
 #define GS_PF 0
 #endif
+#ifndef GS_EXTRA_VALU
+#define GS_EXTRA_VALU 0
+#endif
 typedef __attribute__((address_space(3))) void* gs_ldsptr;
 __device__ __forceinline__ void gs_touch(gcbytes base, uint32_t voff, double* sink) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff), (gs_ldsptr)sink, 4, 0, 0);
@@ -240,6 +243,16 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
   auto mfma_full = [&](const int stage_off) {
     const double* As = smem + stage_off + rA;
     const double* Bs = smem + stage_off + rB;
+#if GS_EXTRA_VALU > 0
+    // measurement probe (tools/valu_probe.sh): N dependent-free integer vector adds per K-tile.  They cost matrix time
+    // one for one — v_mfma_f64_16x16x4_f64 holds the SIMD's vector ALU for its 64 cycles
+    {
+      int dummy = lane;
+#pragma unroll
+      for (int e = 0; e < GS_EXTRA_VALU; e++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy));
+      asm volatile("" :: "v"(dummy));
+    }
+#endif
     __builtin_amdgcn_s_setprio(GS_MFMA_PRIO);
 #pragma unroll
     for (int ks = 0; ks < GS_BK / 4; ks++) {
