@@ -23,16 +23,26 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define CH_NB 32
 #define CH_THREADS 512
 #define CH_WAVES (CH_THREADS / 64)
+#define CH_LDP 34     // LDS row stride (doubles) of the 32-column panel / inverse blocks: 2 (mod 32), so the 16 x 4 lanes of a ds_read_b64 fragment read (row lc, column 4 kk + kq) hit 32 different bank pairs per half-wavefront
 
 #ifdef CH_STAMPS
 // diagnostic build (never shipped; tools/chol_stamps.py): s_memtime stamps of matrix 0's workgroup, per 32-column panel
 // [panel start, panel product done, trailing update done, look-ahead diagonal block start, end]
-__device__ unsigned long long ch_stamps[5 * 64];
+__device__ unsigned long long ch_stamps[5 * 64 + 8 * 8];
 extern "C" int gp_debug_chol_stamps(unsigned long long* host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(ch_stamps), sizeof(ch_stamps)) == hipSuccess ? 0 : -1;
 }
 #define CH_STAMP(k, i) do { if (b == 0 && (k) < 64) ch_stamps[5 * (k) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// per-wavefront phase sums of panel 0's update loop: [operand reads + next-tile draw / loads issued, MFMAs done, stores done, tiles]
+#define CH_PH_DECL unsigned long long ph_[4] = {0, 0, 0, 0}, pt_ = 0
+#define CH_PH_T0 do { if (b == 0 && k0 == 0) pt_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define CH_PH(i) do { if (b == 0 && k0 == 0) { if ((i) == 1 || (i) == 2) __builtin_amdgcn_s_waitcnt(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_[i] += n_ - pt_; pt_ = n_; } } while (0)
+#define CH_PH_OUT do { if (b == 0 && k0 == 0 && lane == 0) { for (int q_ = 0; q_ < 4; q_++) ch_stamps[5 * 64 + 8 * wave + q_] = ph_[q_]; } } while (0)
 #else
+#define CH_PH_DECL
+#define CH_PH_T0 do { } while (0)
+#define CH_PH(i) do { } while (0)
+#define CH_PH_OUT do { } while (0)
 #define CH_STAMP(k, i) do { } while (0)
 #endif
 
@@ -70,67 +80,143 @@ __device__ __forceinline__ void pivot_sqrt_recip(double x, double& s, double& ri
 typedef double __attribute__((address_space(1))) * ch_gptr;
 typedef const double __attribute__((address_space(1))) * ch_gcptr;
 template <typename PT>
-__device__ __forceinline__ void chol_diag_block(PT A, int64_t ld, int M, int k0, int lane,
-                                                double (*Dinv)[CH_NB + 1], int* __restrict__ status, int b, int pbase) {
+__device__ __noinline__ void chol_diag_block(PT A, int64_t ld, int M, int k0, int lane,
+                                                double (*Dinv)[CH_LDP], int* __restrict__ status, int b, int pbase) {
+  // Factor and inverse in ONE pass over the pivots, the two halves of the wavefront doing one each:
+  //   lanes 0..31  ("low"):  lane i holds row i of the block, v[c] = A[i][c] -> L[i][c];
+  //   lanes 32..63 ("high"): lane 32 + c holds column c of the inverse, v[r] = X[r][c] (starts as the identity).
+  // Step j of the factorisation makes column j of L final; the column-oriented forward substitution X = L^-1 needs
+  // exactly that column at its own step j (x_j *= 1 / L_jj;  x_r -= L_rj x_j for r > j), and the trailing update of the
+  // factor needs the same broadcasts (row_c -= L_ij L_cj for c > j): ONE v_fma per broadcast serves both halves,
+  //   v[c] = fma(-v[j], L_cj, v[c])     with v[j] = L_ij (low lanes) or x_j (high lanes).
+  // The inverse therefore costs nothing beyond the factor (it was a second 496-broadcast pass before: the serial
+  // 32-pivot block is the critical path of the one-workgroup factorisation for all but the first panels).
+  __builtin_amdgcn_s_setprio(3);   // the co-resident wavefront is issuing 64-cycle float64 MFMAs on the same vector ALU
   const int nb = min(CH_NB, M - k0);
-  double row[CH_NB];
-  double rinv[CH_NB];   // 1 / L_jj, wave-uniform (lives in SGPRs)
+  double v[CH_NB];
+  const bool low = lane < 32;
   const int i = lane & 31;
-  // unconditional loads from clamped (always valid) addresses, then select: no divergent branches
-  const auto arow = A + (int64_t)(k0 + min(i, nb - 1)) * ld + k0;
+  const int ie = low ? i : 1 << 20;      // "row index" for the select below: high lanes always scale by 1 / L_jj
+  // unconditional loads from clamped (always valid) addresses, then select: no divergent branches; 32-bit element
+  // offsets off the wave-uniform base (a whole block: one offset register and immediates)
+  const unsigned roff = (unsigned)(k0 + min(i, nb - 1)) * (unsigned)ld + (unsigned)k0;
+  // (every lane loads — the high half the same rows again — and the loaded values are pinned before the select: a load
+  // that only the low half consumes is otherwise sunk into a divergent branch of its own, 32 serial round trips)
 #pragma unroll
-  for (int c = 0; c < CH_NB; c++) {
-    const double v = arow[min(c, nb - 1)];
-    row[c] = (i < nb && c <= i) ? v : (i == c ? 1.0 : 0.0);
-  }
+  for (int c = 0; c < CH_NB; c++) v[c] = A[roff + (unsigned)min(c, nb - 1)];
+#pragma unroll
+  for (int c = 0; c < CH_NB; c++) asm volatile("" : "+v"(v[c]));
+#pragma unroll
+  for (int c = 0; c < CH_NB; c++) v[c] = (low && i < nb && c <= i) ? v[c] : (i == c ? 1.0 : 0.0);
   int bad = -1;        // first non-positive / non-finite pivot (wave-uniform), reported once after the loop
-#pragma unroll
-  for (int j = 0; j < CH_NB; j++) {
-    double djj = lane_bcast(row[j], j);
+  // pivot j's sqrt / reciprocal chain (~15 dependent float64 operations) is started as soon as column j has had its
+  // last update — the FIRST thing step j - 1 does — so that the other 30 - j updates of step j - 1 issue in its shadow
+  double s, ri;
+  auto pivot = [&](int j) {
+    double djj = lane_bcast(v[j], j);
     const bool ok = (djj > 0.0) && (djj <= 1.7976931348623157e308);
     bad = (!ok && bad < 0 && j < nb) ? j : bad;
     djj = ok ? djj : 1.0;                       // keep going finite
-    double s, ri;
     pivot_sqrt_recip(djj, s, ri);
-    rinv[j] = lane_bcast(ri, 0);
-    double lij = (i > j) ? row[j] * ri : (i == j ? s : 0.0);
-    row[j] = lij;
+  };
+  pivot(0);
 #pragma unroll
-    for (int c = j + 1; c < CH_NB; c++) {
-      double lcj = lane_bcast(lij, c);
-      row[c] = fma(-lij, lcj, row[c]);  // meaningful for i >= c only
+  for (int j = 0; j < CH_NB; j++) {
+    const double nv = (ie > j) ? v[j] * ri : (ie == j ? s : 0.0);
+    v[j] = nv;
+    if (j + 1 < CH_NB) {
+      v[j + 1] = fma(-nv, lane_bcast(nv, j + 1), v[j + 1]);
+      pivot(j + 1);
     }
+#pragma unroll
+    for (int c = j + 2; c < CH_NB; c++) v[c] = fma(-nv, lane_bcast(nv, c), v[c]);   // lane c (low half) holds L_cj
   }
   if (bad >= 0 && lane == 0) {
     if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = pbase + k0 + bad; status[2] = b; }
   }
-  if (lane < 32) {
+  // pin v[] here: otherwise the arithmetic is sunk into the lane-conditional stores below while its (convergent) lane
+  // broadcasts stay outside, hundreds of them live at once and spilled
+#pragma unroll
+  for (int c = 0; c < CH_NB; c++) asm volatile("" : "+v"(v[c]));
+  if (low) {
+    const unsigned soff = (unsigned)(k0 + i) * (unsigned)ld + (unsigned)k0;
 #pragma unroll
     for (int c = 0; c < CH_NB; c++)
-      if (i < nb && c <= i) A[(int64_t)(k0 + i) * ld + k0 + c] = row[c];
+      if (i < nb && c <= i) A[soff + (unsigned)c] = v[c];
+  } else {
+#pragma unroll
+    for (int r = 0; r < CH_NB; r++) Dinv[r][i] = v[r];
   }
-  // inverse of the diagonal factor, column c in lane c: x[r] = (L_kk^-1)[r][c], by forward substitution taken
-  // column by column (x[t] final -> 31 - t independent updates).  L_rt is lane r of row[t], the very value the
-  // factor loop broadcast: laundering row[] keeps the compiler from holding all 496 of them live in SGPRs
-  // (it spilled them lane by lane into VGPRs) instead of simply reading the lane again.
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// byte pointer of the matrix pointer's address space, and a wave-uniform (SGPR) copy of one: accesses are written as
+// (uniform byte base) + (32-bit per-lane byte offset, fixed for the whole kernel) + (literal), which is the scalar-base
+// form of global_load / global_store — no vector instruction per access.  The float64 matrix instruction holds the SIMD's
+// vector ALU for its 64 cycles, so every vector instruction a wavefront issues between its matrix phases
+// queues behind the co-resident wavefront's MFMAs: the update loop below ran at 8-9 k cycles per 32 x 32 tile and
+// wavefront for 2 k of matrix time until its address arithmetic, accumulator subtraction and register copies were gone.
+template <typename PT> struct ChBytes;
+template <> struct ChBytes<ch_gptr> { typedef char __attribute__((address_space(1))) * type; };
+template <> struct ChBytes<double*> { typedef char* type; };
+template <typename BT> __device__ __forceinline__ BT ch_uni(BT p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (BT)(((uint64_t)hi << 32) | lo);
+}
+#define CH_TAB 528        // (row, column) table of the update's macro tiles: every panel of a matrix of up to 1056 rows
+
+// One 32 x 32 macro tile of the trailing update in its general form (rows past M, a panel narrower than 32, operands
+// from the matrix instead of the LDS panel, the block diagonal's c <= i mask): everything the fast path of chol_body does
+// not take.  Out of line so that its registers and branches stay out of the hot loop.
+template <typename PT>
+__device__ __noinline__ void chol_tile_slow(PT A, unsigned ldu, int M, int nb, int k0, int r0, int rb, int cb,
+                                            const double* P, int p_lds, int lane) {
+  const int kq = lane >> 4, lc = lane & 15;
+  double af0[8], af1[8], bf0[8], bf1[8];
 #pragma unroll
-  for (int c = 0; c < CH_NB; c++) asm volatile("" : "+v"(row[c]));
-  double x[CH_NB];
-#pragma unroll
-  for (int r = 0; r < CH_NB; r++) x[r] = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-  for (int t = 0; t < CH_NB; t++) {
-    x[t] *= rinv[t];
-#pragma unroll
-    for (int r = t + 1; r < CH_NB; r++) x[r] = fma(-lane_bcast(row[t], r), x[t], x[r]);
+  for (int kk = 0; kk < 8; kk++) {
+    const int kc = kk * 4 + kq;
+    const bool kin = kc < nb;
+    const int ra0 = rb + lc, ra1 = rb + 16 + lc, rb0 = cb + lc, rb1 = cb + 16 + lc;
+    if (p_lds) {   // rows >= M were never written: guard; columns >= nb hold zeros
+      af0[kk] = (ra0 < M) ? P[(ra0 - r0) * CH_LDP + kc] : 0.0;
+      af1[kk] = (ra1 < M) ? P[(ra1 - r0) * CH_LDP + kc] : 0.0;
+      bf0[kk] = (rb0 < M) ? P[(rb0 - r0) * CH_LDP + kc] : 0.0;
+      bf1[kk] = (rb1 < M) ? P[(rb1 - r0) * CH_LDP + kc] : 0.0;
+    } else {
+      af0[kk] = (kin && ra0 < M) ? A[(unsigned)ra0 * ldu + (unsigned)(k0 + kc)] : 0.0;
+      af1[kk] = (kin && ra1 < M) ? A[(unsigned)ra1 * ldu + (unsigned)(k0 + kc)] : 0.0;
+      bf0[kk] = (kin && rb0 < M) ? A[(unsigned)rb0 * ldu + (unsigned)(k0 + kc)] : 0.0;
+      bf1[kk] = (kin && rb1 < M) ? A[(unsigned)rb1 * ldu + (unsigned)(k0 + kc)] : 0.0;
+    }
   }
-  // pin x[] here: otherwise the substitution is sunk into the lane-conditional stores below while its
-  // (convergent) lane broadcasts stay outside, all 496 of them live at once and spilled
+  d4 c[4];
+  const unsigned o0 = (unsigned)(rb + kq) * ldu + (unsigned)(cb + lc);
 #pragma unroll
-  for (int r = 0; r < CH_NB; r++) asm volatile("" : "+v"(x[r]));
-  if (lane < 32) {
+  for (int r = 0; r < 4; r++) {
+    const int rw0 = rb + kq + 4 * r, rw1 = rw0 + 16, cw0 = cb + lc, cw1 = cw0 + 16;
+    const unsigned o = o0 + (unsigned)(4 * r) * ldu;
+    c[0][r] = (rw0 < M && cw0 <= rw0) ? A[o] : 0.0;
+    c[1][r] = (rw0 < M && cw1 <= rw0) ? A[o + 16u] : 0.0;
+    c[2][r] = (rw1 < M && cw0 <= rw1) ? A[o + 16u * ldu] : 0.0;
+    c[3][r] = (rw1 < M && cw1 <= rw1) ? A[o + 16u * ldu + 16u] : 0.0;
+  }
 #pragma unroll
-    for (int r = 0; r < CH_NB; r++) Dinv[r][i] = x[r];
+  for (int kk = 0; kk < 8; kk++) {
+    c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf0[kk], c[0], 0, 0, 1);
+    c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf1[kk], c[1], 0, 0, 1);
+    c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf0[kk], c[2], 0, 0, 1);
+    c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf1[kk], c[3], 0, 0, 1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int rw0 = rb + kq + 4 * r, rw1 = rw0 + 16, cw0 = cb + lc, cw1 = cw0 + 16;
+    const unsigned o = o0 + (unsigned)(4 * r) * ldu;
+    if (rw0 < M && cw0 <= rw0) A[o] = c[0][r];
+    if (rw0 < M && cw1 <= rw0) A[o + 16u] = c[1][r];
+    if (rw1 < M && cw0 <= rw1) A[o + 16u * ldu] = c[2][r];
+    if (rw1 < M && cw1 <= rw1) A[o + 16u * ldu + 16u] = c[3][r];
   }
 }
 
@@ -138,15 +224,37 @@ __device__ __forceinline__ void chol_diag_block(PT A, int64_t ld, int M, int k0,
 template <typename PT>
 __device__ __forceinline__ void chol_body(PT A, const int M, const int64_t ld, int* __restrict__ status,
                                           const int b, const int panel_rows_cap, const int pivot_base) {
+  typedef typename ChBytes<PT>::type BT;
   extern __shared__ __attribute__((aligned(16))) double chol_smem[];
-  // [ D: 2 x 32 x 33 (inverse of the current / next diagonal factor) | P: panel X, (M-32) x 33 when it fits ]
-  double (*D)[CH_NB][CH_NB + 1] = reinterpret_cast<double (*)[CH_NB][CH_NB + 1]>(chol_smem);
-  double* P = chol_smem + 2 * CH_NB * (CH_NB + 1);
+  // [ D: 2 x 32 x CH_LDP (inverse of the current / next diagonal factor) | P: panel X, (M-32) x CH_LDP when it fits ]
+  double (*D)[CH_NB][CH_LDP] = reinterpret_cast<double (*)[CH_NB][CH_LDP]>(chol_smem);
+  double* P = chol_smem + 2 * CH_NB * CH_LDP;
   __shared__ int tile_counter;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __shared__ unsigned tile_tab[CH_TAB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, lc = lane & 15;
   const bool p_lds = (panel_rows_cap >= M - CH_NB);   // operands of the trailing update come from LDS
+  const unsigned ldu = (unsigned)ld;
+  const size_t ld8 = (size_t)ldu * 8;
+  const BT Ab = (BT)A;
+  const uint32_t vC = (uint32_t)((kq * ldu + lc) * 8u);   // lane part of element (row kq, column lc): C tiles, panel stores
+  const uint32_t vA = (uint32_t)((lc * ldu + kq) * 8u);   // lane part of element (row lc, column kq): panel operand loads
+  auto at = [](BT base, uint32_t voff, int imm) -> decltype(auto) { return (*(PT)(base + voff + imm)); };
+  // a lane offset re-defined where it is used: the scalar-base addressing mode is matched per basic block, and a 32-bit
+  // offset hoisted out of the loop arrives there already widened to a 64-bit register pair
+  auto here = [](uint32_t v) { asm volatile("" : "+v"(v)); return v; };
 
+  // macro tile t of a trailing update = (block row mi, block column mj) of the lower triangle, row by row: the same
+  // numbering for every panel, so it is tabulated once
+  const int tmax = (M + 31) / 32;
+  const int ntab = min(tmax * (tmax + 1) / 2, CH_TAB);
+  for (int t = tid; t < ntab; t += CH_THREADS) {
+    int mi = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((mi + 1) * (mi + 2) / 2 <= t) mi++;
+    while (mi * (mi + 1) / 2 > t) mi--;
+    tile_tab[t] = (unsigned)mi | ((unsigned)(t - mi * (mi + 1) / 2) << 16);
+  }
   if (wave == 0) chol_diag_block(A, ld, M, 0, lane, D[0], status, b, pivot_base);
   __syncthreads();
 
@@ -157,109 +265,193 @@ __device__ __forceinline__ void chol_body(PT A, const int M, const int64_t ld, i
     const int R = M - r0;
     if (R <= 0) break;
     if (tid == 0) CH_STAMP(k0 / CH_NB, 0);
-    // ---- panel: X = A_panel * L_kk^-T on the matrix cores, 16 rows per wavefront step ----------
+    // ---- panel: X = A_panel * L_kk^-T on the matrix cores, 16 rows per wavefront step; the operand rows of the next
+    //      step are requested before the products of this one (a dependent L2 round trip per step otherwise) ----------
+    auto panel_load = [&](int rg, double (&af)[8]) {
+      const int rowb = r0 + rg * 16;
+      if (nb == CH_NB && rowb + 16 <= M) {
+        const BT pbase = ch_uni(Ab + ((size_t)rowb * ldu + k0) * 8);
+        const uint32_t va = here(vA);
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) af[kk] = at(pbase, va, kk * 32);
+      } else {
+        const int ra = rowb + lc;
+        const unsigned o = (unsigned)min(ra, M - 1) * ldu + (unsigned)(k0 + kq);
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+          const int kc = kk * 4 + kq;
+          const double a = A[o + (unsigned)(kc < nb ? kk * 4 : 0)];
+          af[kk] = (ra < M && kc < nb) ? a : 0.0;
+        }
+      }
+    };
+    double afc[8];
+    if (wave * 16 < R) panel_load(wave, afc);
     for (int rg = wave; rg * 16 < R; rg += CH_WAVES) {
-      const int ra = r0 + rg * 16 + lc;
-      double af[8];
-#pragma unroll
-      for (int kk = 0; kk < 8; kk++) {
-        const int kc = kk * 4 + kq;
-        af[kk] = (ra < M && kc < nb) ? A[(int64_t)ra * ld + k0 + kc] : 0.0;
-      }
+      double afn[8];
+      const bool more = (rg + CH_WAVES) * 16 < R;      // wave-uniform
+      if (more) panel_load(rg + CH_WAVES, afn);
       d4 o[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+      {
+        const double* Dl = &D[pb][lc][kq];
 #pragma unroll
-      for (int kk = 0; kk < 8; kk++) {  // B[k][j] = (L_kk^-1)[j][k]; two independent accumulators
-        o[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], D[pb][lc][kk * 4 + kq], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], D[pb][16 + lc][kk * 4 + kq], o[1], 0, 0, 0);
+        for (int kk = 0; kk < 8; kk++) {  // B[k][j] = (L_kk^-1)[j][k]; two independent accumulators
+          o[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(afc[kk], Dl[kk * 4], o[0], 0, 0, 0);
+          o[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(afc[kk], Dl[16 * CH_LDP + kk * 4], o[1], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int tj = 0; tj < 2; tj++)
+      const int rowb = r0 + rg * 16;
+      if (nb == CH_NB && rowb + 16 <= M) {
+        const BT pbase = ch_uni(Ab + ((size_t)rowb * ldu + k0) * 8);
+        double* Pl = P + (rowb - r0 + kq) * CH_LDP + lc;
+        const uint32_t vc = here(vC);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int rw = r0 + rg * 16 + kq + 4 * r, cw = tj * 16 + lc;
-          if (rw < M && cw < nb) A[(int64_t)rw * ld + k0 + cw] = o[tj][r];
-          if (p_lds && rw < M) P[(rw - r0) * (CH_NB + 1) + cw] = (cw < nb) ? o[tj][r] : 0.0;
+          const BT rb_ = ch_uni(pbase + (size_t)(4 * r) * ld8);
+          at(rb_, vc, 0) = o[0][r]; at(rb_, vc, 128) = o[1][r];
+          if (p_lds) { Pl[4 * r * CH_LDP] = o[0][r]; Pl[4 * r * CH_LDP + 16] = o[1][r]; }
         }
+      } else {
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int rw = rowb + kq + 4 * r, cw = tj * 16 + lc;
+            if (rw < M && cw < nb) A[(unsigned)rw * ldu + (unsigned)(k0 + cw)] = o[tj][r];
+            if (p_lds && rw < M) P[(rw - r0) * CH_LDP + cw] = (cw < nb) ? o[tj][r] : 0.0;
+          }
+      }
+      if (more) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) afc[kk] = afn[kk];
+      }
     }
     if (tid == 0) tile_counter = 0;
     __threadfence_block();
     __syncthreads();
     if (tid == 0) CH_STAMP(k0 / CH_NB, 1);
-    // ---- trailing update A22 -= X X^T (lower triangle), 32 x 32 macro tiles handed out dynamically.  Macro tile
-    //      0 is the NEXT diagonal block: the wavefront that draws it factorises that block straight away
-    //      (look-ahead), overlapping the serial 32-column factorisation with the other waves' updates.
+    // ---- trailing update A22 -= X X^T, 32 x 32 macro tiles handed out dynamically.  Macro tile 0 is the NEXT diagonal
+    //      block: the wavefront that draws it factorises that block straight away (look-ahead), overlapping the serial
+    //      32-column factorisation with the other waves' updates.
+    //      A wavefront draws its NEXT tile and requests that tile's C block before the products of the current one; the C
+    //      block is loaded straight into the accumulators and the product runs with the A operand negated (the neg
+    //      modifier of the float64 MFMA), so the read-modify-write is load -> 32 MFMAs -> store with no vector arithmetic
+    //      in between; tiles on the block diagonal are updated whole (the part above the diagonal is never read: the
+    //      diagonal-block factorisation selects c <= i, and it is cleared at the end).
     const int nmt = (R + 31) >> 5;
     const int total = nmt * (nmt + 1) / 2;
-    for (;;) {
-      int t = 0;
-      if (lane == 0) t = atomicAdd(&tile_counter, 1);
-      t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= total) break;
-      int mi = (int)((__dsqrt_rn(8.0 * t + 1.0) - 1.0) * 0.5);
-      while ((mi + 1) * (mi + 2) / 2 <= t) mi++;
-      while (mi * (mi + 1) / 2 > t) mi--;
-      const int mj = t - mi * (mi + 1) / 2;
-      const int rbase = r0 + mi * 32, cbase = r0 + mj * 32;
-      double af0[8], af1[8], bf0[8], bf1[8];
+    int t, rbase = 0, cbase = 0;
+    bool fast = false;
+    auto draw = [&]() {       // next tile of this wavefront: t, (rbase, cbase), fast = whole tile, operands in the LDS panel
+      int tt = 0;
+      unsigned pk = 0;
+      if (lane == 0) {
+        tt = atomicAdd(&tile_counter, 1);
+        if (tt < ntab) pk = tile_tab[tt];
+      }
+      t = __builtin_amdgcn_readfirstlane(tt);
+      pk = __builtin_amdgcn_readfirstlane(pk);
+      int mi = (int)(pk & 0xffffu), mj = (int)(pk >> 16);
+      if (t >= CH_TAB) {      // (matrices beyond the table: arithmetic decode)
+        mi = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((mi + 1) * (mi + 2) / 2 <= t) mi++;
+        while (mi * (mi + 1) / 2 > t) mi--;
+        mj = t - mi * (mi + 1) / 2;
+      }
+      rbase = r0 + mi * 32; cbase = r0 + mj * 32;
+      fast = p_lds && (nb == CH_NB) && (rbase + 32 <= M) && (t < total);
+    };
+    // C block of a whole tile (rb, cb) -> c[2 h + w][r] = element (rb + kq + 4 r + 16 h, cb + lc + 16 w); every row base
+    // goes through ch_uni: the compiler otherwise re-associates (base + row step) + lane offset into a 64-bit vector add
+    auto load_c = [&](int rb, int cb, d4 (&c)[4]) {
+      const BT tb = Ab + ((size_t)rb * ldu + cb) * 8;
+      const uint32_t vc = here(vC);
 #pragma unroll
-      for (int kk = 0; kk < 8; kk++) {
-        const int kc = kk * 4 + kq;
-        const bool kin = kc < nb;
-        const int ra0 = rbase + lc, ra1 = rbase + 16 + lc, rb0 = cbase + lc, rb1 = cbase + 16 + lc;
-        if (p_lds) {   // rows >= M were never written: guard; columns >= nb hold zeros
-          af0[kk] = (ra0 < M) ? P[(ra0 - r0) * (CH_NB + 1) + kc] : 0.0;
-          af1[kk] = (ra1 < M) ? P[(ra1 - r0) * (CH_NB + 1) + kc] : 0.0;
-          bf0[kk] = (rb0 < M) ? P[(rb0 - r0) * (CH_NB + 1) + kc] : 0.0;
-          bf1[kk] = (rb1 < M) ? P[(rb1 - r0) * (CH_NB + 1) + kc] : 0.0;
-        } else {
-          af0[kk] = (kin && ra0 < M) ? A[(int64_t)ra0 * ld + k0 + kc] : 0.0;
-          af1[kk] = (kin && ra1 < M) ? A[(int64_t)ra1 * ld + k0 + kc] : 0.0;
-          bf0[kk] = (kin && rb0 < M) ? A[(int64_t)rb0 * ld + k0 + kc] : 0.0;
-          bf1[kk] = (kin && rb1 < M) ? A[(int64_t)rb1 * ld + k0 + kc] : 0.0;
+      for (int r = 0; r < 4; r++) {
+        const BT r0_ = ch_uni(tb + (size_t)(4 * r) * ld8), r1_ = ch_uni(tb + (size_t)(4 * r + 16) * ld8);
+        c[0][r] = at(r0_, vc, 0); c[1][r] = at(r0_, vc, 128); c[2][r] = at(r1_, vc, 0); c[3][r] = at(r1_, vc, 128);
+      }
+    };
+    auto after_tile0 = [&]() {     // the wavefront that has just updated the next diagonal block factorises it
+      __threadfence_block();  // this wave's own updates of the block it is about to read back
+      if (lane == 0) CH_STAMP(k0 / CH_NB, 3);
+      chol_diag_block(A, ld, M, r0, lane, D[pb ^ 1], status, b, pivot_base);
+      if (lane == 0) CH_STAMP(k0 / CH_NB, 4);
+    };
+    CH_PH_DECL;
+    // `cbuf` holds the C block of the tile in hand (requested a tile ago).  The first k-step reads it as the C operand and
+    // writes the accumulators, which frees it for the NEXT tile's block right away: requested before the other 28
+    // products, no register copy, no second buffer.
+    d4 cbuf[4];
+    draw();
+    if (fast) load_c(rbase, cbase, cbuf);
+    while (t < total) {
+      const int tc = t, rb = rbase, cb = cbase;
+      if (!fast) {       // general form, no prefetch
+        chol_tile_slow(A, ldu, M, nb, k0, r0, rb, cb, P, (int)p_lds, lane);
+        if (tc == 0) after_tile0();
+        draw();
+        if (fast) load_c(rbase, cbase, cbuf);
+        continue;
+      }
+      CH_PH_T0;
+      double af0[8], af1[8], bf0[8], bf1[8];
+      {
+        const double* Pa = P + (rb - r0 + lc) * CH_LDP + kq;
+        const double* Pb = P + (cb - r0 + lc) * CH_LDP + kq;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+          af0[kk] = Pa[kk * 4]; af1[kk] = Pa[16 * CH_LDP + kk * 4];
+          bf0[kk] = Pb[kk * 4]; bf1[kk] = Pb[16 * CH_LDP + kk * 4];
         }
       }
-      // C tile: issue the loads now, consume them after the MFMAs
-      double cold[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int rw0 = rbase + kq + 4 * r, rw1 = rw0 + 16, cw0 = cbase + lc, cw1 = cw0 + 16;
-        cold[0][r] = (rw0 < M && cw0 <= rw0) ? A[(int64_t)rw0 * ld + cw0] : 0.0;
-        cold[1][r] = (rw0 < M && cw1 <= rw0) ? A[(int64_t)rw0 * ld + cw1] : 0.0;
-        cold[2][r] = (rw1 < M && cw0 <= rw1) ? A[(int64_t)rw1 * ld + cw0] : 0.0;
-        cold[3][r] = (rw1 < M && cw1 <= rw1) ? A[(int64_t)rw1 * ld + cw1] : 0.0;
+      d4 acc[4];       // C - X X^T: neg:[1,0,0] negates the A operand
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[0], bf0[0], cbuf[0], 0, 0, 1);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[0], bf1[0], cbuf[1], 0, 0, 1);
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[0], bf0[0], cbuf[2], 0, 0, 1);
+      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[0], bf1[0], cbuf[3], 0, 0, 1);
+      // the next tile (the wavefront about to factorise the diagonal block draws its next one afterwards: a tile
+      // claimed now would sit out the whole factorisation)
+      if (tc != 0) {
+        draw();
+        if (fast) load_c(rbase, cbase, cbuf);
       }
-      d4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
+      CH_PH(0);
 #pragma unroll
-      for (int kk = 0; kk < 8; kk++) {
-        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf0[kk], c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf1[kk], c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf0[kk], c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf1[kk], c11, 0, 0, 0);
+      for (int kk = 1; kk < 8; kk++) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf0[kk], acc[0], 0, 0, 1);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[kk], bf1[kk], acc[1], 0, 0, 1);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf0[kk], acc[2], 0, 0, 1);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[kk], bf1[kk], acc[3], 0, 0, 1);
       }
+      CH_PH(1);
+      {
+        const BT tb = Ab + ((size_t)rb * ldu + cb) * 8;
+        const uint32_t vc = here(vC);
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int rw0 = rbase + kq + 4 * r, rw1 = rw0 + 16, cw0 = cbase + lc, cw1 = cw0 + 16;
-        if (rw0 < M && cw0 <= rw0) A[(int64_t)rw0 * ld + cw0] = cold[0][r] - c00[r];
-        if (rw0 < M && cw1 <= rw0) A[(int64_t)rw0 * ld + cw1] = cold[1][r] - c01[r];
-        if (rw1 < M && cw0 <= rw1) A[(int64_t)rw1 * ld + cw0] = cold[2][r] - c10[r];
-        if (rw1 < M && cw1 <= rw1) A[(int64_t)rw1 * ld + cw1] = cold[3][r] - c11[r];
+        for (int r = 0; r < 4; r++) {
+          const BT r0_ = ch_uni(tb + (size_t)(4 * r) * ld8), r1_ = ch_uni(tb + (size_t)(4 * r + 16) * ld8);
+          at(r0_, vc, 0) = acc[0][r]; at(r0_, vc, 128) = acc[1][r]; at(r1_, vc, 0) = acc[2][r]; at(r1_, vc, 128) = acc[3][r];
+        }
       }
-      if (t == 0) {
-        __threadfence_block();  // this wave's own updates of the block it is about to read back
-        if (lane == 0) CH_STAMP(k0 / CH_NB, 3);
-        chol_diag_block(A, ld, M, r0, lane, D[pb ^ 1], status, b, pivot_base);
-        if (lane == 0) CH_STAMP(k0 / CH_NB, 4);
+      CH_PH(2);
+#ifdef CH_STAMPS
+      if (b == 0 && k0 == 0) ph_[3] += 1;
+#endif
+      if (tc == 0) {
+        after_tile0();
+        draw();
+        if (fast) load_c(rbase, cbase, cbuf);
       }
     }
+    CH_PH_OUT;
     __threadfence_block();
     __syncthreads();
     if (tid == 0) CH_STAMP(k0 / CH_NB, 2);
   }
-  // zero the strictly-upper triangle so L can be used as a dense operand
-  for (int64_t idx = tid; idx < (int64_t)M * M; idx += CH_THREADS) {
-    int i = (int)(idx / M), j = (int)(idx % M);
-    if (j > i) A[(int64_t)i * ld + j] = 0.0;
-  }
+  // zero the strictly-upper triangle so L can be used as a dense operand (a row per wavefront: no index division)
+  for (int i = wave; i < M; i += CH_WAVES)
+    for (int j = i + 1 + lane; j < M; j += 64) A[(unsigned)i * ldu + (unsigned)j] = 0.0;
 }
 
 __global__ void __launch_bounds__(CH_THREADS) chol_kernel(double* const* __restrict__ mats, const int* __restrict__ Ms,
@@ -421,7 +613,7 @@ __global__ void __launch_bounds__(CH_THREADS) chol_inverse_kernel(double* const*
 // on an LDS round trip instead of an L2 one.
 #define CHS_M 64
 #define CHS_LD (CHS_M + 1)
-#define CHS_OFF (2 * CH_NB * (CH_NB + 1) + (CHS_M - CH_NB) * (CH_NB + 1))     // chol_body's own D | P region
+#define CHS_OFF (2 * CH_NB * CH_LDP + (CHS_M - CH_NB) * CH_LDP)     // chol_body's own D | P region
 #define CHS_DOUBLES (CHS_OFF + 2 * CHS_M * CHS_LD)
 __global__ void __launch_bounds__(CH_THREADS) chol_inverse_lds_kernel(double* const* __restrict__ mats,
                                                                       double* const* __restrict__ Ws,
@@ -455,9 +647,9 @@ __global__ void __launch_bounds__(CH_THREADS) chol_inverse_lds_kernel(double* co
 }
 
 static size_t chol_smem_bytes(int maxM, int* cap) {
-  const size_t dbytes = (size_t)2 * CH_NB * (CH_NB + 1) * sizeof(double);
+  const size_t dbytes = (size_t)2 * CH_NB * CH_LDP * sizeof(double);
   const int rows = maxM > CH_NB ? maxM - CH_NB : 0;
-  const size_t pbytes = (size_t)rows * (CH_NB + 1) * sizeof(double);
+  const size_t pbytes = (size_t)rows * CH_LDP * sizeof(double);
   if (dbytes + pbytes <= 150 * 1024) { *cap = rows; return dbytes + pbytes; }
   *cap = 0;
   return dbytes;

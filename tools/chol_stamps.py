@@ -18,7 +18,7 @@ def main():
     K = np.exp(-np.abs(z[:, None] - z[None, :]) / 0.1) + 1e-6 * np.eye(M)
     fn = h.lib.gp_debug_chol_stamps
     fn.restype = C.c_int
-    buf = (C.c_ulonglong * (5 * 64))()
+    buf = (C.c_ulonglong * (5 * 64 + 64))()
     for rep in range(3):
         A = h.to_device(K.copy())
         torch.cuda.synchronize()
@@ -30,12 +30,18 @@ def main():
     L = np.tril(A.cpu().numpy())
     print("M=%d  max |L L^T - K| = %.3e   launch %.1f us" % (M, np.abs(L @ L.T - K).max(), t0.elapsed_time(t1) * 1e3))
     fn(buf)
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(64, 5).astype(np.int64)
+    raw = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+    a = raw[:320].reshape(64, 5)
+    ph = raw[320:].reshape(8, 8)
     T = M // 32 - 1
     tot = a[T - 1, 2] - a[0, 0]
     print("panel  product  update  (diag block inside the update)   [ticks of 10 ns]")
     for k in range(T):
         print("%3d   %6d  %6d   %6d" % (k, a[k, 1] - a[k, 0], a[k, 2] - a[k, 1], a[k, 4] - a[k, 3]))
+    print("panel 0 update loop per wavefront: tiles | cycles per tile: operand reads + next draw / C loads issued | matrix products (drained) | stores (drained)")
+    for w in range(8):
+        n = max(ph[w, 3], 1)
+        print("  wave %d: %3d | %6.0f | %6.0f | %6.0f" % (w, ph[w, 3], ph[w, 0] / n, ph[w, 1] / n, ph[w, 2] / n))
     print("sum: product %d  update %d  diag %d  | first panel start -> last update end %d ticks = %.1f us"
           % ((a[:T, 1] - a[:T, 0]).sum(), (a[:T, 2] - a[:T, 1]).sum(), (a[:T, 4] - a[:T, 3]).sum(), tot, tot * 0.01))
 
