@@ -452,8 +452,9 @@ static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, 
 gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& gf) {
   if (batch <= 0 || maxM <= 0 || maxN <= 0) return GP_OK;
   GpTimerScope ts(h, gf.timer);
-  {   // whole aligned strips: gemm_strip_f32.hip's lean form
+  {   // small inducing sets: the M x M operand resident in LDS (gemm_res_f32.hip); whole aligned strips: gemm_strip_f32.hip's lean form
     gp_status st = GP_OK;
+    if (launch_gemm_res_f32(h, d_probs, batch, maxM, maxN, gf, &st)) return st;
     if (launch_gemm_strip_f32_lean(h, d_probs, batch, maxM, maxN, gf, &st)) return st;
   }
   Gemm32Flags f;

@@ -55,10 +55,11 @@ def test_kernel_build_f32_is_the_f64_build_rounded_once(gp_handle):
         np.testing.assert_array_equal(K32, K64.astype(np.float32))
 
 
-@pytest.mark.parametrize("N,M,P,m", [(1000, 48, 2, 3), (4200, 300, 1, 3), (8192, 512, 1, 5)])
+@pytest.mark.parametrize("N,M,P,m", [(1000, 48, 2, 3), (4200, 300, 1, 3), (8192, 512, 1, 5), (2048, 128, 2, 3), (4096, 256, 1, 3)])
 def test_f32_elbo_gradient_and_predictions_against_the_f64_oracle(gp_handle, N, M, P, m):
     """ragged sizes on purpose: M = 48 / 300 leave partial 128-row tiles, N = 1000 / 4200 partial column strips (the
-    guarded staging path of gemm_f32.hip); M = 512 is the bench's tile grid"""
+    guarded staging path of gemm_f32.hip); M = 512 is the bench's tile grid; M = 128 / 256 with whole column tiles take
+    the LDS-resident form (gemm_res_f32.hip: one and two row-blocks, triangular and dense operands)"""
     from gpitch_amd.synth import make_problem
     from oracle import gpflow05 as orc
     prob = make_problem(N, M, P, num_partials=m, seed=3)
