@@ -604,6 +604,247 @@ __global__ void __launch_bounds__(256, 2) hyper_sm_rows_kernel(DevKern k, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Lean form of hyper_sm_rows_kernel (round 3) for the common case: Matern-1/2 envelope, whole 16-row tiles, whole
+// 16-column blocks, 16-byte aligned strips.  Same row-streaming layout, same sums; what changed is everything AROUND the
+// 8 NT matrix instructions of a 16-column block, because on this chip every vector instruction beside a float64 MFMA costs
+// matrix time and the old form issued ~120 of them per block:
+//  - per-COLUMN quantities (scaled input b_j = x_j / l, envelope column factor, gm_j) come from LDS tables built once per
+//    workgroup and segment, not from per-block global loads and per-entry arithmetic; a byte per block says whether the
+//    block is separable to one side (0 / 1) or needs the entry-by-entry envelope (2);
+//  - var is folded into the row factors, l into the final sums: zi - xb = l (a_i - b_j), so an entry is
+//    fma, sub, 4 mul, add, fma — 8 vector instructions instead of 13 + selects;
+//  - feature lanes past the last feature read a real feature row instead of a select to zero: their output columns are
+//    never used;
+//  - G, Kuf and the column features are requested THREE blocks ahead into three register buffers that keep their identity
+//    (loop unrolled over them), with scalar-base addresses (one lane offset per array for the whole kernel).
+#define HYL_CF_MAX 2048
+typedef char __attribute__((address_space(1))) const* hy_gcbytes;
+__device__ __forceinline__ hy_gcbytes hyl_uniform(hy_gcbytes p) {
+  const uint64_t b = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return (hy_gcbytes)(((uint64_t)hi << 32) | lo);
+}
+template <int NT, bool G32>
+__global__ void __launch_bounds__(256, 2) hyper_sm_rows_lean_kernel(DevKern k, const double* __restrict__ x1, int n1,
+                                                                    const double* __restrict__ x2, int n2,
+                                                                    const double* __restrict__ G, int64_t ldg,
+                                                                    const double* __restrict__ alpha,
+                                                                    const double* __restrict__ gm,
+                                                                    const double* __restrict__ Kuf, int64_t ldk,
+                                                                    const double* __restrict__ f1,
+                                                                    const double* __restrict__ f2,
+                                                                    double* __restrict__ partials, int col_seg,
+                                                                    const HyperItem* __restrict__ items) {
+  if (items) {     // one launch for a whole kernel family: blockIdx.y = item (latent GP)
+    const HyperItem it = items[blockIdx.y];
+    k = it.k; x1 = it.x1; n1 = it.n1; G = it.G; ldg = it.ldg; alpha = it.alpha; gm = it.gm;
+    if (it.x2) { x2 = it.x2; n2 = it.n2; }
+    Kuf = it.kvals; ldk = it.ldk; f1 = it.f1; f2 = it.f2; partials = it.partials;
+  }
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  typedef const d2v __attribute__((address_space(1))) * pd2v;
+  typedef const f2v __attribute__((address_space(1))) * pf2v;
+  const int mpad = ((k.m + 3) / 4) * 4;
+  const int NF = 2 * mpad;
+  const hy_gcptr gx1 = (hy_gcptr)x1, gx2 = (hy_gcptr)x2, galpha = (hy_gcptr)alpha, ggm = (hy_gcptr)gm, gf1 = (hy_gcptr)f1,
+                 th = (hy_gcptr)k.theta;
+  __shared__ double etab[GP_EXP_TAB];
+  __shared__ double red[4][2 + 2 * NT * 16];
+  __shared__ __attribute__((aligned(16))) double t_cf[HYL_CF_MAX], t_b[HYL_CF_MAX], t_gm[HYL_CF_MAX];
+  __shared__ unsigned char t_side[HYL_CF_MAX], t_cls[HYL_CF_MAX / 16];
+  __shared__ double wg_lo[4], wg_hi[4];
+  gp_exp_tab_init(etab);
+  const double var = th[0], ls = th[1];
+  const int m = k.m;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lc = lane & 15, kq = lane >> 4;
+  if (blockIdx.x * 64 >= n1) return;           // (uniform per workgroup: the grid is sized for the largest item)
+  const int i0 = (blockIdx.x * 4 + wave) * 16;
+  const bool tile_on = (i0 < n1);              // a whole wavefront past the last row: no columns, joins the final sum
+  const int rowc = tile_on ? i0 + lc : n1 - 1;
+  const double inv_ls = 1.0 / ls;
+  const double al = galpha[rowc];
+  const double ab_i = gx1[rowc] * inv_ls;      // the scaled input as the covariance build forms it (x * (1 / l))
+  const double a_ = gx1[rowc] / ls, aa = __dmul_rn(a_, a_), m2a = -2.0 * a_;    // (entry-by-entry form: cov.hip's arithmetic)
+  int frow[NT]; bool fok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int phi = 16 * t + lc, q = phi >> 1;
+    fok[t] = (phi < NF);
+    frow[t] = fok[t] ? ((phi & 1) ? mpad + q : q) : 0;
+  }
+  const int cw0 = blockIdx.z * col_seg, cw1 = tile_on ? min(n2, cw0 + col_seg) : cw0;
+  const int nseg_cols = min(n2, cw0 + col_seg) - cw0;
+  // ---- tables of the segment's columns ---------------------------------------------------------------------------------
+  {
+    double lo = ab_i, hi = ab_i;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+    if (lane == 0) { wg_lo[wave] = tile_on ? lo : 1e300; wg_hi[wave] = tile_on ? hi : -1e300; }
+  }
+  __syncthreads();
+  const double A = fmin(fmin(wg_lo[0], wg_lo[1]), fmin(wg_lo[2], wg_lo[3]));
+  const double B = fmax(fmax(wg_hi[0], wg_hi[1]), fmax(wg_hi[2], wg_hi[3]));
+  for (int j = tid; j < nseg_cols; j += 256) {
+    const double b = gx2[cw0 + j] * inv_ls;
+    double v = 0.0;
+    unsigned char side = 2;
+    if (A - b >= HYR_SEP) { v = gp_exp_neg(-(A - b), etab); side = 0; }
+    else if (b - B >= HYR_SEP) { v = gp_exp_neg(-(b - B), etab); side = 1; }
+    t_cf[j] = v; t_b[j] = b; t_gm[j] = ggm[cw0 + j]; t_side[j] = side;
+  }
+  __syncthreads();
+  for (int blk = tid; blk * 16 < nseg_cols; blk += 256) {
+    unsigned char c = t_side[blk * 16];
+#pragma unroll
+    for (int u = 1; u < 16; u++) c = (t_side[blk * 16 + u] == c) ? c : (unsigned char)2;
+    t_cls[blk] = c;
+  }
+  const double rfp = var * gp_exp_neg(-(ab_i - A), etab), rfn = var * gp_exp_neg(-(B - ab_i), etab);
+  __syncthreads();
+  // ---- the stream -------------------------------------------------------------------------------------------------------
+  struct Blk { d2v g[2], kv[2], bf[NT][2]; };
+  const hy_gcbytes bG = (hy_gcbytes)G, bK = (hy_gcbytes)Kuf, bF = (hy_gcbytes)f2;
+  constexpr int ES = G32 ? 4 : 8;              // strip element size
+  const uint32_t voG = (uint32_t)(((int64_t)rowc * ldg + 2 * kq) * ES), voK = (uint32_t)(((int64_t)rowc * ldk + 2 * kq) * ES);
+  uint32_t voF[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) voF[t] = (uint32_t)(((int64_t)frow[t] * n2 + 2 * kq) * 8);
+  const int jlast = cw1 - 16;
+  auto request = [&](int jb, Blk& b) {
+    const int jc = min(jb, jlast);             // (past the end: the last block again, never consumed)
+    const hy_gcbytes sG = hyl_uniform(bG + (int64_t)jc * ES), sK = hyl_uniform(bK + (int64_t)jc * ES),
+                     sF = hyl_uniform(bF + (int64_t)jc * 8);
+    uint32_t vg = voG, vk = voK;
+    asm volatile("" : "+v"(vg), "+v"(vk));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      if (G32) {
+        const f2v g = *(pf2v)(sG + vg + s2 * 8 * ES), kk = *(pf2v)(sK + vk + s2 * 8 * ES);
+        b.g[s2] = d2v{(double)g.x, (double)g.y}; b.kv[s2] = d2v{(double)kk.x, (double)kk.y};
+      } else {
+        b.g[s2] = *(pd2v)(sG + vg + s2 * 64); b.kv[s2] = *(pd2v)(sK + vk + s2 * 64);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      uint32_t vf = voF[t];
+      asm volatile("" : "+v"(vf));
+      b.bf[t][0] = *(pd2v)(sF + vf); b.bf[t][1] = *(pd2v)(sF + vf + 64);
+    }
+  };
+  d4 TE[NT], TD[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) { TE[t] = d4{0.0, 0.0, 0.0, 0.0}; TD[t] = d4{0.0, 0.0, 0.0, 0.0}; }
+  double acc_v = 0.0, acc_l = 0.0;
+  auto consume = [&](int jb, const Blk& b) {
+    const int cl = jb - cw0 + 2 * kq;
+    const int cls = __builtin_amdgcn_readfirstlane((int)t_cls[(jb - cw0) >> 4]);
+    const d2v cf0 = *reinterpret_cast<const d2v*>(t_cf + cl), cf1 = *reinterpret_cast<const d2v*>(t_cf + cl + 8);
+    const d2v bs0 = *reinterpret_cast<const d2v*>(t_b + cl), bs1 = *reinterpret_cast<const d2v*>(t_b + cl + 8);
+    const d2v gm0 = *reinterpret_cast<const d2v*>(t_gm + cl), gm1 = *reinterpret_cast<const d2v*>(t_gm + cl + 8);
+    const double cfv[4] = {cf0.x, cf0.y, cf1.x, cf1.y}, bsv[4] = {bs0.x, bs0.y, bs1.x, bs1.y},
+                 gmv[4] = {gm0.x, gm0.y, gm1.x, gm1.y};
+    const double gv[4] = {b.g[0].x, b.g[0].y, b.g[1].x, b.g[1].y}, kv[4] = {b.kv[0].x, b.kv[0].y, b.kv[1].x, b.kv[1].y};
+    double wvE[4], wd[4];
+    if (cls != 2) {
+      const double rf = cls ? rfn : rfp;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const double w = fma(al, gmv[e], gv[e]);
+        const double d = ab_i - bsv[e];
+        const double wk = w * kv[e];
+        wvE[e] = w * (rf * cfv[e]); wd[e] = wvE[e] * d;
+        acc_v += wk;
+        acc_l = fma(wk, fabs(d), acc_l);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const double w = fma(al, gmv[e], gv[e]);
+        const double bsc = bsv[e], bb = __dmul_rn(bsc, bsc);
+        const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(m2a, bsc), aa), bb);
+        double r, rinv;
+        gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), r, rinv);
+        const double E = gp_exp_neg(-r, etab);
+        const double wk = w * kv[e];
+        wvE[e] = w * var * E; wd[e] = wvE[e] * (ab_i - bsc);
+        acc_v += wk;
+        acc_l = fma(wk, r2 * rinv, acc_l);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const double bfe = (e & 1) ? b.bf[t][e >> 1].y : b.bf[t][e >> 1].x;
+        TE[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wvE[e], bfe, TE[t], 0, 0, 0);
+        TD[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wd[e], bfe, TD[t], 0, 0, 0);
+      }
+  };
+  if (cw1 - cw0 >= 16) {
+    Blk b0, b1, b2;
+    request(cw0, b0); request(cw0 + 16, b1); request(cw0 + 32, b2);
+    for (int jb = cw0; jb < cw1;) {
+      consume(jb, b0); request(jb + 48, b0); jb += 16; if (jb >= cw1) break;
+      consume(jb, b1); request(jb + 48, b1); jb += 16; if (jb >= cw1) break;
+      consume(jb, b2); request(jb + 48, b2); jb += 16;
+    }
+  }
+  // ---- finish (as hyper_sm_rows_kernel; TD and the lengthscale sum carry the factors folded out of the loop) ------------
+  const int ns = 2 + 2 * m;
+  auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+  for (int t = lane; t < 2 + 2 * NT * 16; t += 64) red[wave][t] = 0.0;
+  const double rv = wred(acc_v / var), rl = wred(acc_l * inv_ls);
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    double se = 0.0, sd = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int ri = i0 + kq + 4 * r;
+      const double zf = (ri < n1 && fok[t]) ? gf1[(size_t)frow[t] * n1 + ri] : 0.0;
+      se = fma(zf, TE[t][r], se);
+      sd = fma(zf, hyr_swap1(TD[t][r]), sd);
+    }
+    sd *= ls;
+    se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+    sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
+    if (kq == 0) { red[wave][2 + 16 * t + lc] = se; red[wave][2 + NT * 16 + 16 * t + lc] = sd; }
+  }
+  if (lane == 0) { red[wave][0] = rv; red[wave][1] = rl; }
+  __syncthreads();
+  if (tid < ns) {
+    double out;
+    auto tot = [&](int idx) { return (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]); };
+    if (tid < 2) out = tot(tid);
+    else if (tid < 2 + m) {           // d / d e_q ~ (SE[cos_q] + SE[sin_q]) / e_q
+      const int q = tid - 2;
+      out = (tot(2 + 2 * q) + tot(2 + 2 * q + 1)) / th[2 + q];
+    } else {                          // d / d f_q ~ -2 pi (SD[sin_q] - SD[cos_q])
+      const int q = tid - 2 - m;
+      out = -6.283185307179586 * (tot(2 + NT * 16 + 2 * q + 1) - tot(2 + NT * 16 + 2 * q));
+    }
+    partials[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * ns + tid] = out;
+  }
+}
+
+#define HYL_DISPATCH(L, nt, g32)                                                                                   \
+  do {                                                                                                             \
+    switch (nt) {                                                                                                  \
+      case 1: if (g32) L(1, true); else L(1, false); break;                                                         \
+      case 2: if (g32) L(2, true); else L(2, false); break;                                                         \
+      case 3: if (g32) L(3, true); else L(3, false); break;                                                         \
+      default: if (g32) L(4, true); else L(4, false); break;                                                        \
+    }                                                                                                              \
+  } while (0)
+static bool hyl_enabled() {
+  static const bool on = !(getenv("GP_HYPER_LEAN") && atoi(getenv("GP_HYPER_LEAN")) == 0);
+  return on;
+}
 #define HYR_DISPATCH_ENV(L, NT_, m52, g32)                                             \
   do {                                                                                  \
     if (m52) { if (g32) L(NT_, true, true); else L(NT_, true, false); }                 \
@@ -796,6 +1037,16 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
     int col_seg = 0, nseg = 0;
     hyr_geometry(n1, n2, 1, &col_seg, &nseg);
     dim3 gridm((n1 + 63) / 64, 1, nseg);
+    if (hyl_enabled() && (2 * mp + 15) / 16 <= 3 && k.type == GP_KERN_MERCER_MATERN12SM && (n1 % 16) == 0 && (n2 % 16) == 0 && col_seg <= HYL_CF_MAX &&
+        (ldg % 2) == 0 && (ldk % 2) == 0 && ((uintptr_t)G % 16) == 0 && ((uintptr_t)kvals % 16) == 0 && ((uintptr_t)f2 % 16) == 0) {
+#define HYL_ONE(NT_, G32_) hipLaunchKernelGGL((hyper_sm_rows_lean_kernel<NT_, G32_>), gridm, dim3(256), 0, h->stream, k, x1, n1, x2, \
+                                              n2, G, ldg, alpha, gm, kvals, ldk, f1, f2, partials, col_seg, (const HyperItem*)nullptr)
+      HYL_DISPATCH(HYL_ONE, (2 * mp + 15) / 16, g32 != 0);
+#undef HYL_ONE
+      GP_HIP_CHECK(h, hipGetLastError());
+      if (nparts) *nparts = gridm.x * gridm.z;
+      return GP_OK;
+    }
 #define HY_MFMA(NT_, M52_, G32_) hipLaunchKernelGGL((hyper_sm_rows_kernel<NT_, M52_, G32_>), gridm, dim3(256), 0, h->stream, k, x1, \
                                                   n1, x2, n2, G, ldg, alpha, gm, kvals, ldk, f1, f2, partials, g32, col_seg,    \
                                                   (const HyperItem*)nullptr)
@@ -935,7 +1186,7 @@ gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items,
 // Many contractions of one kernel family (same type and partial count, same n1 x n2) in one launch: the generic
 // (vector-pipe) kernels with an item array.  *nparts = partial records each item leaves.
 gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
-                                      int with_gz, int* nparts, int use_mfma, const double* x2_shared, int g32_items) {
+                                      int with_gz, int* nparts, int use_mfma, const double* x2_shared, int g32_items, int lean_items) {
   if (count <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_HYPER);
   if (use_mfma && gp_kern_is_mercer(type) && !with_gz) {
@@ -943,6 +1194,17 @@ gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperI
     hyr_geometry(n1, n2, count, &col_seg, &nseg);
     dim3 gridm((n1 + 63) / 64, count, nseg);
     DevKern k0{type, m, nullptr};
+    if (lean_items && hyl_enabled() && (2 * sm_mpad(m) + 15) / 16 <= 3 && type == GP_KERN_MERCER_MATERN12SM && (n1 % 16) == 0 && (n2 % 16) == 0 && col_seg <= HYL_CF_MAX) {
+#define HYL_ITEMS(NT_, G32_) hipLaunchKernelGGL((hyper_sm_rows_lean_kernel<NT_, G32_>), gridm, dim3(256), 0, h->stream, k0,        \
+                                                (const double*)nullptr, 0, x2_shared, n2, (const double*)nullptr, (int64_t)0,         \
+                                                (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (int64_t)0,   \
+                                                (const double*)nullptr, (const double*)nullptr, (double*)nullptr, col_seg, d_items)
+      HYL_DISPATCH(HYL_ITEMS, (2 * sm_mpad(m) + 15) / 16, g32_items != 0);
+#undef HYL_ITEMS
+      GP_HIP_CHECK(h, hipGetLastError());
+      if (nparts) *nparts = gridm.x * gridm.z;
+      return GP_OK;
+    }
 #define HYI_MFMA(NT_, M52_, G32_) hipLaunchKernelGGL((hyper_sm_rows_kernel<NT_, M52_, G32_>), gridm, dim3(256), 0, h->stream, k0, \
                                                    (const double*)nullptr, 0, x2_shared, n2, (const double*)nullptr, (int64_t)0, \
                                                    (const double*)nullptr, (const double*)nullptr, (const double*)nullptr,       \
@@ -1347,7 +1609,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       if (!fam.batched) { for (int g : fam.gps) GP_CHECK(kuf_contract(g)); return GP_OK; }
       int np = 0;
       GP_CHECK(launch_hyper_contract_items(h, fam.type, fam.m, (const HyperItem*)(p->d_misc + p->off_hy_items) + fam.first,
-                                           fam.count, fam.M, n, 0, &np, fam.mfma, x, f32));
+                                           fam.count, fam.M, n, 0, &np, fam.mfma, x, f32, 1));
       for (int g : fam.gps) np_uf[g] = np;
       return GP_OK;
     };

@@ -53,7 +53,7 @@ struct HyperFinishItem {
 // (g32_items: the items' strips are float32 — all of them, as their g32 fields say)
 gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
                                       int with_gz, int* nparts, int use_mfma = 0, const double* x2_shared = nullptr,
-                                      int g32_items = 0);
+                                      int g32_items = 0, int lean_items = 0);
 gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items, int count, int maxblocks);
 size_t hyper_finish_item_bytes();
 // partial records the Kuf-side contraction of an M x N strip may write (the largest over its kernel variants)
