@@ -292,6 +292,9 @@ struct CovItem {
   int f32out, pad_;     // out is float32 (ld in floats)
 };
 struct FeatItem { DevKern k; const double* x; double* f; int n; int pad; };
+// one pass for K = sum of P MercerMatern12sm kernels (cov.hip; true = taken, status in *st)
+bool launch_kernel_build_sum(gp_handle h, const DevKern* kernels, double* const* feats, int P, const double* x1, int n1,
+                             const double* x2, int n2, double* out, int64_t ld, double diag_add, int f32out, gp_status* st);
 void cov_item_fill(CovItem* it, DevKern k, const double* x1, int n1, const double* x2, int n2, double* out, int64_t ld,
                    int accumulate, double diag_add, double* feat_ws, int f32out = 0);
 gp_status launch_sm_features_items(gp_handle h, const FeatItem* d_items, int count, int max_n, int mpad,

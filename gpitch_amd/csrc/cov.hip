@@ -284,6 +284,132 @@ static int cov_rows_for(int n1, int n2) {
   return 4;
 }
 
+// K = sum_p K_p for up to 8 MercerMatern12sm kernels in ONE pass (SGPRSS: the summed source kernel of sgpr_ss.py:29-71,
+// `kern = sum of per-source kernels`): per entry the arithmetic of cov_build_kernel<1, 2, MPAD, 0> for every kernel, added in
+// kernel order — the value that P accumulate launches leave (float64: bit-identical; float32 output: one rounding instead of P).
+// The accumulate launches re-read and re-write the whole M x N strip P - 1 times (0.34 ms of a 5.1-ms evaluation at
+// N = 65536, M = 512, P = 5).  Row accumulators of the workgroup's COV_ROWS rows stay in registers while the kernels go by.
+struct CovSumArgs { int P; int pad_; DevKern k[8]; const double* f1[8]; const double* f2[8]; };
+template <int MPAD>
+__global__ void __launch_bounds__(COV_THREADS) cov_mercer_sum_kernel(CovSumArgs a, const double* __restrict__ x1, int n1,
+                                                                     const double* __restrict__ x2, int n2,
+                                                                     double* __restrict__ out, int64_t ld, double diag_add,
+                                                                     int vec_ok, int wg_rows, int f32out) {
+  constexpr int CPT = 2;
+  const cov_gcptr gx1 = (cov_gcptr)x1, gx2 = (cov_gcptr)x2;
+  const cov_gptr gout = (cov_gptr)out;
+  __shared__ double fzs[COV_ROWS * 2 * MPAD];
+  __shared__ double row_a[COV_ROWS];
+  __shared__ double etab[GP_EXP_TAB];
+  gp_exp_tab_init(etab);
+  const int j0 = (blockIdx.x * COV_THREADS + threadIdx.x) * CPT;
+  const int i0 = blockIdx.y * wg_rows;
+  const int jb0 = blockIdx.x * COV_THREADS * CPT;
+  const bool self_cov = (x2 == x1) && (diag_add != 0.0) && (jb0 < i0 + wg_rows) && (jb0 + COV_THREADS * CPT > i0);
+  double res[COV_ROWS][CPT];
+#pragma unroll
+  for (int ii = 0; ii < COV_ROWS; ii++)
+#pragma unroll
+    for (int c = 0; c < CPT; c++) res[ii][c] = 0.0;
+  double xb[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; c++) xb[c] = gx2[min(j0 + c, n2 - 1)];
+  for (int p = 0; p < a.P; p++) {
+    const double* th = a.k[p].theta;
+    const double var = th[0], ls = th[1];
+    const cov_gcptr gf1 = (cov_gcptr)a.f1[p], gf2 = (cov_gcptr)a.f2[p];
+    __syncthreads();        // the previous kernel's row tables are still being read
+    if (threadIdx.x < COV_ROWS) row_a[threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? gx1[i0 + threadIdx.x] / ls : 0.0;
+    for (int t = threadIdx.x; t < COV_ROWS * 2 * MPAD; t += COV_THREADS) {
+      const int q = t / COV_ROWS, ii = t % COV_ROWS;
+      fzs[ii * 2 * MPAD + q] = (ii < wg_rows && i0 + ii < n1) ? gf1[(size_t)q * n1 + i0 + ii] : 0.0;
+    }
+    __syncthreads();
+    if (j0 < n2) {
+      double b[CPT], bb[CPT], fx[CPT][2 * MPAD];
+#pragma unroll
+      for (int c = 0; c < CPT; c++) { b[c] = xb[c] / ls; bb[c] = __dmul_rn(b[c], b[c]); }
+#pragma unroll
+      for (int q = 0; q < 2 * MPAD; q++)
+#pragma unroll
+        for (int c = 0; c < CPT; c++) fx[c][q] = gf2[(size_t)q * n2 + min(j0 + c, n2 - 1)];
+#pragma unroll
+      for (int ii = 0; ii < COV_ROWS; ii++) {
+        if (ii < wg_rows) {
+          const double av = row_a[ii], aa = __dmul_rn(av, av);
+          const double* fz = &fzs[ii * 2 * MPAD];
+          double acc[CPT];
+#pragma unroll
+          for (int c = 0; c < CPT; c++) acc[c] = 0.0;
+#pragma unroll
+          for (int q = 0; q < 2 * MPAD; q++) {
+            const double z = fz[q];
+#pragma unroll
+            for (int c = 0; c < CPT; c++) acc[c] = fma(z, fx[c][q], acc[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < CPT; c++) {
+            const double r = gp_sqrt_pos(__dadd_rn(r2_expand(av, aa, b[c], bb[c]), 1e-12));
+            res[ii][c] += var * gp_exp_neg(-r, etab) * acc[c];
+          }
+        }
+      }
+    }
+  }
+  if (j0 >= n2) return;
+#pragma unroll
+  for (int ii = 0; ii < COV_ROWS; ii++) {
+    const int i = i0 + ii;
+    if (ii < wg_rows && i < n1) {
+#pragma unroll
+      for (int c = 0; c < CPT; c++)
+        if (self_cov && i == j0 + c) res[ii][c] += diag_add;
+      if (f32out) { cov_store_f32<CPT>(gout, (size_t)i * ld + j0, n2 - j0, res[ii], 0, vec_ok); continue; }
+      const cov_gptr o = gout + (size_t)i * ld + j0;
+      if (vec_ok && j0 + 1 < n2) *(cov_gptr2)o = cov_d2{res[ii][0], res[ii][1]};
+      else {
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+          if (j0 + c < n2) o[c] = res[ii][c];
+      }
+    }
+  }
+}
+
+// true = taken.  kernels: P MercerMatern12sm kernels of the same padded partial count; feats[p] = the kernel's feature
+// workspace (layout of launch_sm_features: x1 block, then x2 block), already current.
+bool launch_kernel_build_sum(gp_handle h, const DevKern* kernels, double* const* feats, int P, const double* x1, int n1,
+                             const double* x2, int n2, double* out, int64_t ld, double diag_add, int f32out, gp_status* st) {
+  static const bool enabled = !(getenv("GP_COV_SUM") && atoi(getenv("GP_COV_SUM")) == 0);
+  if (!enabled || P < 2 || P > 8 || n1 <= 0 || n2 <= 0) return false;
+  if (x2 == nullptr) { x2 = x1; n2 = n1; }
+  const int mp = sm_mpad(kernels[0].m);
+  if (mp != 4 && mp != 8) return false;
+  for (int p = 0; p < P; p++)
+    if (kernels[p].type != GP_KERN_MERCER_MATERN12SM || sm_mpad(kernels[p].m) != mp || !feats[p]) return false;
+  if (f32out && x2 == x1 && diag_add != 0.0) return false;
+  const bool big = (int64_t)n1 * n2 >= (1 << 20);
+  GpTimerScope ts(h, !big ? GP_TIMER_SMALL_GEMM : GP_TIMER_KUF_BUILD_SM);
+  CovSumArgs a;
+  a.P = P; a.pad_ = 0;
+  for (int p = 0; p < 8; p++) {
+    const int q = p < P ? p : 0;
+    a.k[p] = kernels[q];
+    a.f1[p] = feats[q];
+    a.f2[p] = (x2 == x1) ? feats[q] : feats[q] + gp_align_up((size_t)2 * mp * n1, 32);
+  }
+  const int vec_ok = ((ld % 2) == 0) && ((((uintptr_t)out) & 15) == 0);
+  const int rows = cov_rows_for(n1, n2);
+  dim3 grid((n2 + COV_THREADS * 2 - 1) / (COV_THREADS * 2), (n1 + rows - 1) / rows);
+  if (mp == 4) hipLaunchKernelGGL((cov_mercer_sum_kernel<4>), grid, dim3(COV_THREADS), 0, h->stream, a, x1, n1, x2, n2, out, ld,
+                                  diag_add, vec_ok, rows, f32out);
+  else hipLaunchKernelGGL((cov_mercer_sum_kernel<8>), grid, dim3(COV_THREADS), 0, h->stream, a, x1, n1, x2, n2, out, ld,
+                          diag_add, vec_ok, rows, f32out);
+  hipError_t e = hipGetLastError();
+  *st = (e == hipSuccess) ? GP_OK : gp_fail(h, GP_ERR_HIP, hipGetErrorString(e));
+  return true;
+}
+
 gp_status launch_kernel_build(gp_handle h, DevKern k, const double* x1, int n1, const double* x2, int n2,
                               double* out, int64_t ld, int accumulate, double diag_add, double* feat_ws, int feat_ready,
                               int f32out) {

@@ -324,17 +324,29 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   { GemmProblem& r = probs[2]; r.A = p->A; r.lda = ld; r.M = M; r.N = N; r.v0 = Y; r.o0 = p->u; r.a_f32 = f32; }
   GP_CHECK(sg_upload(p, probs, desc, 0));
   // Kuu, Kuf: GPflow Add kernel = sum over kern_list (sgpr_ss.py:42-43)
+  // (all-Mercer sums of up to eight kernels are built in one pass per matrix: launch_kernel_build_sum)
+  std::vector<DevKern> kerns(p->P);
+  std::vector<double*> feats(p->P);
   for (int i = 0; i < p->P; i++) {
-    DevKern k = sg_kern(p, params, i);
-    double* feat = p->feat + (size_t)i * sgpr_feat_stride(p);
-    GP_CHECK(launch_sm_features(h, k, Z, M, X, N, feat));
-    GP_CHECK(launch_kernel_build(h, k, Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, feat, 1));
+    kerns[i] = sg_kern(p, params, i);
+    feats[i] = p->feat + (size_t)i * sgpr_feat_stride(p);
+    GP_CHECK(launch_sm_features(h, kerns[i], Z, M, X, N, feats[i]));
+  }
+  {
+    gp_status st = GP_OK;
+    if (launch_kernel_build_sum(h, kerns.data(), feats.data(), p->P, Z, M, nullptr, M, p->L, M, p->jitter, 0, &st)) GP_CHECK(st);
+    else
+      for (int i = 0; i < p->P; i++)
+        GP_CHECK(launch_kernel_build(h, kerns[i], Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, feats[i], 1));
   }
   if (p->chol_blocked) GP_CHECK(chol_inverse_blocked_run(h, M, M, p->chol_ws_kuu, p->chol_ws_bytes));
   else GP_CHECK(launch_cholesky_inverse_single(h, p->L, p->W, M, M));
-  for (int i = 0; i < p->P; i++) {
-    DevKern k = sg_kern(p, params, i);
-    GP_CHECK(launch_kernel_build(h, k, Z, M, X, N, p->Kuf, ld, i > 0, 0.0, p->feat + (size_t)i * sgpr_feat_stride(p), 1, f32));
+  {
+    gp_status st = GP_OK;
+    if (launch_kernel_build_sum(h, kerns.data(), feats.data(), p->P, Z, M, X, N, p->Kuf, ld, 0.0, f32, &st)) GP_CHECK(st);
+    else
+      for (int i = 0; i < p->P; i++)
+        GP_CHECK(launch_kernel_build(h, kerns[i], Z, M, X, N, p->Kuf, ld, i > 0, 0.0, feats[i], 1, f32));
   }
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ; f.uniform_aligned = 1;   /* one problem, arena buffers, ld = gp_strip_ld */
     if (f32) { f.role = 1; GP_CHECK(launch_gemm_f32_role(h, desc->probs + 0, 1, M, N, f)); }
@@ -381,18 +393,41 @@ __global__ void __launch_bounds__(256) sgpr_E2_kernel(const double* __restrict__
 // noise-variance gradient and dF/dkd (one block):
 //   dF/ds = -tr(Bbar H)/s^2 - ubar.u/s^2 - tr(H)/(2 s^2) - N/(2s) + |y|^2/(2 s^2) + N kd/(2 s^2),
 //   tr(Bbar H) = -1/2 tr(Binv H) - 1/2 ubar^T H ubar ;   dF/dkd = -N/(2s)      (ubar = Binv u / s)
-__global__ void __launch_bounds__(256) sgpr_noise_grad_kernel(const double* __restrict__ Binv, const double* __restrict__ H,
+// (the two M x M sums come as per-block partials from sgpr_noise_partial_kernel: one block walking M^2 elements with an
+// index division each took 0.37 ms at M = 512, a tenth of the whole evaluation)
+#define SG_NOISE_BLOCKS 64
+__global__ void __launch_bounds__(256) sgpr_noise_partial_kernel(const double* __restrict__ Binv, const double* __restrict__ H,
+                                                                 const double* __restrict__ ubar, int M,
+                                                                 double* __restrict__ part) {
+  __shared__ double red[2][256];
+  double t_bh = 0.0, t_uhu = 0.0;
+  for (int i = blockIdx.x; i < M; i += gridDim.x) {
+    const double ui = ubar[i];
+    const double* __restrict__ hr = H + (int64_t)i * M;
+    const double* __restrict__ br = Binv + (int64_t)i * M;
+    double s_bh = 0.0, s_uh = 0.0;
+    for (int j = threadIdx.x; j < M; j += 256) {
+      const double h = hr[j];
+      s_bh = fma(br[j], h, s_bh);
+      s_uh = fma(ubar[j], h, s_uh);
+    }
+    t_bh += s_bh; t_uhu = fma(ui, s_uh, t_uhu);
+  }
+  red[0][threadIdx.x] = t_bh; red[1][threadIdx.x] = t_uhu;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) for (int q = 0; q < 2; q++) red[q][threadIdx.x] += red[q][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = red[0][0]; part[2 * blockIdx.x + 1] = red[1][0]; }
+}
+__global__ void __launch_bounds__(256) sgpr_noise_grad_kernel(const double* __restrict__ part, int nblocks,
                                                               const double* __restrict__ ubar, const double* __restrict__ u,
                                                               int M, int N, const double* __restrict__ s2,
                                                               double* __restrict__ scal, double* __restrict__ g_noise) {
   __shared__ double red[3][256];
   double t_bh = 0.0, t_uhu = 0.0, t_uu = 0.0;
-  for (int64_t idx = threadIdx.x; idx < (int64_t)M * M; idx += 256) {
-    const int i = (int)(idx / M), j = (int)(idx % M);
-    const double h = H[idx];
-    t_bh = fma(Binv[idx], h, t_bh);
-    t_uhu = fma(ubar[i] * ubar[j], h, t_uhu);
-  }
+  for (int b = threadIdx.x; b < nblocks; b += 256) { t_bh += part[2 * b]; t_uhu += part[2 * b + 1]; }
   for (int i = threadIdx.x; i < M; i += 256) t_uu = fma(ubar[i], u[i], t_uu);
   red[0][threadIdx.x] = t_bh; red[1][threadIdx.x] = t_uhu; red[2][threadIdx.x] = t_uu;
   __syncthreads();
@@ -472,8 +507,12 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
   GP_CHECK(launch_gemm_batched(h, D + Q_BINV, 1, M, M, f));
   GP_CHECK(launch_matvec_batched(h, D + Q_UBAR, 1, M, 1));
   hipLaunchKernelGGL(sgpr_E2_kernel, dim3(64), dim3(256), 0, h->stream, p->Binv, p->ubar, p->E2, M, params);
-  hipLaunchKernelGGL(sgpr_noise_grad_kernel, dim3(1), dim3(256), 0, h->stream, p->Binv, p->H, p->ubar, p->u, M, Ntotal,
-                     params, p->scal, include_replicated ? grad : p->scal + 6);
+  {
+    const int nb = M < SG_NOISE_BLOCKS ? M : SG_NOISE_BLOCKS;       // partials in the (free by now) split-K slab buffer
+    hipLaunchKernelGGL(sgpr_noise_partial_kernel, dim3(nb), dim3(256), 0, h->stream, p->Binv, p->H, p->ubar, M, p->slabs);
+    hipLaunchKernelGGL(sgpr_noise_grad_kernel, dim3(1), dim3(256), 0, h->stream, p->slabs, nb, p->ubar, p->u, M, Ntotal,
+                       params, p->scal, include_replicated ? grad : p->scal + 6);
+  }
   // from here on ubar holds dF/du = ubar / s
   hipLaunchKernelGGL(div_scalar_kernel, dim3((M + 255) / 256), dim3(256), 0, h->stream, p->ubar, M, params);
   // Wbar = tril(E2 H L^T + ubar (L u)^T)
