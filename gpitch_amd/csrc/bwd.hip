@@ -319,6 +319,146 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_kernel(DevKern k, c
 }
 
 
+// Kuf-side contraction of ONE weight matrix G with the derivatives of P MercerMatern12sm kernels of a sum (SGPRSS,
+// sgpr_ss.py:42-43: every kernel of the Add sees the same Kuf_bar) in one pass: G, alpha and gm are read once instead of P
+// times (at N = 65536, M = 512, P = 5 the per-kernel launches read the 268-MB strip five times: 0.72 ms of a 4.8-ms
+// evaluation).  Per kernel the arithmetic and the partial-record layout are hyper_contract_kernel<4, true, false>'s.
+struct HySumArgs { int P; int pad_; DevKern k[8]; const double* f1[8]; const double* f2[8]; double* partials[8]; };
+template <int P>
+__global__ void __launch_bounds__(HY_THREADS) hyper_contract_sum_kernel(HySumArgs a, const double* __restrict__ x1, int n1,
+                                                                        const double* __restrict__ x2, int n2,
+                                                                        const double* __restrict__ G, int64_t ldg,
+                                                                        const double* __restrict__ alpha,
+                                                                        const double* __restrict__ gm, int wg_rows, int g32) {
+  constexpr int MPAD = 4;
+  __shared__ double fzs[P][HY_ROWS * 2 * MPAD];
+  __shared__ double row_a[P][HY_ROWS];
+  __shared__ double red[4 * (2 + 2 * MPAD)];
+  __shared__ double etab[GP_EXP_TAB];
+  gp_exp_tab_init(etab);
+  const int j = blockIdx.x * HY_THREADS + threadIdx.x;
+  const int i0 = blockIdx.y * wg_rows;
+  const int iend = min(i0 + wg_rows, n1);
+  double var[P], inv_ls[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    const double* th = a.k[p].theta;
+    var[p] = th[0]; inv_ls[p] = 1.0 / th[1];
+    if (threadIdx.x < HY_ROWS) row_a[p][threadIdx.x] = (i0 + (int)threadIdx.x < n1) ? x1[i0 + threadIdx.x] / th[1] : 0.0;
+    for (int t = threadIdx.x; t < HY_ROWS * 2 * MPAD; t += HY_THREADS) {
+      const int q = t / HY_ROWS, ii = t % HY_ROWS;
+      fzs[p][ii * 2 * MPAD + q] = (ii < wg_rows && i0 + ii < n1) ? a.f1[p][(size_t)q * n1 + i0 + ii] : 0.0;
+    }
+  }
+  __syncthreads();
+  const bool live = (j < n2);
+  const int jc = live ? j : n2 - 1;
+  const double xb = x2[jc];
+  const double gmj = (gm && live) ? gm[jc] : 0.0;
+  double b[P], bb[P], fxc[P][MPAD], fxs[P][MPAD], acc_v[P], acc_l[P], acc_e[P][MPAD], acc_f[P][MPAD];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    b[p] = xb / a.k[p].theta[1]; bb[p] = __dmul_rn(b[p], b[p]);
+    acc_v[p] = 0.0; acc_l[p] = 0.0;
+#pragma unroll
+    for (int q = 0; q < MPAD; q++) {
+      fxc[p][q] = a.f2[p][(size_t)q * n2 + jc];
+      fxs[p][q] = a.f2[p][(size_t)(q + MPAD) * n2 + jc];
+      acc_e[p][q] = 0.0; acc_f[p][q] = 0.0;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = i0; i < iend; i++) {
+    double w = 0.0;
+    if (live) {
+      w = hy_ld(G, (int64_t)i * ldg + j, g32);
+      if (alpha) w = fma(alpha[i], gmj, w);
+    }
+    const double d = x1[i] - xb;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const double av = row_a[p][i - i0], aa = __dmul_rn(av, av);
+      const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(av, b[p]), aa), bb[p]);
+      double r, rinv;
+      gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), r, rinv);
+      const double E = gp_exp_neg(-r, etab);
+      const double wvE = w * var[p] * E, wvD = -wvE;
+      const double wd = wvE * d;
+      const double* fz = &fzs[p][(i - i0) * 2 * MPAD];
+      double S = 0.0;
+#pragma unroll
+      for (int q = 0; q < MPAD; q++) {
+        const double zc = fz[q], zs = fz[q + MPAD];
+        const double cc = fma(zc, fxc[p][q], zs * fxs[p][q]);   // e_q cos(w_q d)
+        const double ss = fma(zs, fxc[p][q], -zc * fxs[p][q]);  // e_q sin(w_q d)
+        S += cc;
+        acc_e[p][q] = fma(wvE, cc, acc_e[p][q]);
+        acc_f[p][q] = fma(wd, ss, acc_f[p][q]);
+      }
+      acc_v[p] = fma(w * E, S, acc_v[p]);
+      acc_l[p] = fma(-wvD * S, r2 * rinv * inv_ls[p], acc_l[p]);
+    }
+  }
+  auto wred = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    const double* th = a.k[p].theta;
+    const int m = a.k[p].m, ns = 2 + 2 * m;
+    const double rv = wred(acc_v[p]), rl = wred(acc_l[p]);
+    __syncthreads();      // red is reused kernel after kernel
+    if (lane == 0) { red[wave * ns + 0] = rv; red[wave * ns + 1] = rl; }
+#pragma unroll
+    for (int q = 0; q < MPAD; q++) {
+      const double re = wred(acc_e[p][q]), rf = wred(acc_f[p][q]);
+      if (lane == 0 && q < m) {
+        red[wave * ns + 2 + q] = re / th[2 + q];
+        red[wave * ns + 2 + m + q] = -6.283185307179586 * rf;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ns) {
+      const int t = threadIdx.x;
+      const double sum = (red[0 * ns + t] + red[1 * ns + t]) + (red[2 * ns + t] + red[3 * ns + t]);
+      a.partials[p][((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ns + t] = sum;
+    }
+  }
+}
+
+// true = taken.  P MercerMatern12sm kernels with at most four partials each, Kuf side (no inducing-input gradient);
+// partials[p] = kernel p's partial records (hyper_kuf_records(n2, n1) x (2 + 2 m_p) doubles); *nparts = records left each.
+bool launch_hyper_contract_sum(gp_handle h, const DevKern* kernels, double* const* feats, double* const* partials, int P,
+                               const double* x1, int n1, const double* x2, int n2, const double* G, int64_t ldg,
+                               const double* alpha, const double* gm, int g32, int* nparts, gp_status* st) {
+  static const bool enabled = !(getenv("GP_HYPER_SUM") && atoi(getenv("GP_HYPER_SUM")) == 0);
+  if (!enabled || P < 2 || P > 6 || n1 <= 0 || n2 <= 0) return false;
+  for (int p = 0; p < P; p++)
+    if (kernels[p].type != GP_KERN_MERCER_MATERN12SM || kernels[p].m < 1 || kernels[p].m > 4 || !feats[p] || !partials[p]) return false;
+  GpTimerScope ts(h, GP_TIMER_HYPER);
+  HySumArgs a;
+  a.P = P; a.pad_ = 0;
+  const size_t f2off = gp_align_up((size_t)2 * 4 * n1, 32);
+  for (int p = 0; p < 8; p++) {
+    const int q = p < P ? p : 0;
+    a.k[p] = kernels[q]; a.f1[p] = feats[q]; a.f2[p] = (x2 == x1) ? feats[q] : feats[q] + f2off; a.partials[p] = partials[q];
+  }
+  const int wg_rows = hy_rows_for(n1, n2);
+  dim3 grid((n2 + HY_THREADS - 1) / HY_THREADS, (n1 + wg_rows - 1) / wg_rows);
+#define HYS(P_) hipLaunchKernelGGL((hyper_contract_sum_kernel<P_>), grid, dim3(HY_THREADS), 0, h->stream, a, x1, n1, x2, n2, G, ldg, \
+                                   alpha, gm, wg_rows, g32)
+  switch (P) {
+    case 2: HYS(2); break;
+    case 3: HYS(3); break;
+    case 4: HYS(4); break;
+    case 5: HYS(5); break;
+    default: HYS(6); break;
+  }
+#undef HYS
+  hipError_t e = hipGetLastError();
+  *st = (e == hipSuccess) ? GP_OK : gp_fail(h, GP_ERR_HIP, hipGetErrorString(e));
+  if (nparts) *nparts = grid.x * grid.y;
+  return true;
+}
+
 // Kuf side of a Mercer spectral-mixture kernel when the covariance values K themselves are still in memory (the
 // forward pass's Kuf strip) and no inducing-input gradient is wanted.  Two identities remove the per-entry cosine
 // sums:   sum_q e_q cos(w_q d) = K / (var phi(r))   (the variance / lengthscale terms become sums of w K ...), and

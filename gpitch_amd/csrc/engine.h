@@ -54,6 +54,10 @@ struct HyperFinishItem {
 gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperItem* d_items, int count, int n1, int n2,
                                       int with_gz, int* nparts, int use_mfma = 0, const double* x2_shared = nullptr,
                                       int g32_items = 0, int lean_items = 0);
+// one pass over G for the P MercerMatern12sm kernels of a sum (bwd.hip; true = taken)
+bool launch_hyper_contract_sum(gp_handle h, const DevKern* kernels, double* const* feats, double* const* partials, int P,
+                               const double* x1, int n1, const double* x2, int n2, const double* G, int64_t ldg,
+                               const double* alpha, const double* gm, int g32, int* nparts, gp_status* st);
 gp_status launch_hyper_finish_items(gp_handle h, const HyperFinishItem* d_items, int count, int maxblocks);
 size_t hyper_finish_item_bytes();
 // partial records the Kuf-side contraction of an M x N strip may write (the largest over its kernel variants)

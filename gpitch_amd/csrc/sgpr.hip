@@ -24,6 +24,7 @@ struct gp_sgpr_plan_s {
   // backward
   double *E2 = nullptr, *T1 = nullptr, *T2 = nullptr, *Wbar = nullptr, *R = nullptr, *Binv = nullptr, *G = nullptr;
   double *ubar = nullptr, *Lu = nullptr, *alpha = nullptr, *ones = nullptr, *hyp = nullptr, *hyp_uu = nullptr;
+  size_t hyp_stride = 0;    // doubles between the per-kernel partial record sets in hyp
   double *scal = nullptr;   // [0] bound, [1] sum err^2, [2] sum colsumsq(A'), [3] kdiag total per point, [4] dF/dkd, [5] dF/ds
   char* d_desc = nullptr; std::vector<char> h_desc[2];   // two descriptor blocks (training pass / prediction pass)
   int nsplit = 2;
@@ -189,7 +190,7 @@ static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   add(strip); add(M); add(M); add(M); add(p->maxN);
   {
     const size_t ns = hyper_num_sums(p->maxm);
-    add(ns * hyper_kuf_records(p->maxN, (int)M));
+    add(ns * hyper_kuf_records(p->maxN, (int)M) * (size_t)(p->P > 0 ? p->P : 1));     // one record set per kernel of the sum (fused contraction)
     add(ns * hyper_kuf_records((int)M, (int)M));
   }
   if (sgpr_chol_blocked(p)) { add(chol_inverse_blocked_workspace_bytes(p->M) / sizeof(double) + 1); add(chol_inverse_blocked_workspace_bytes(p->M) / sizeof(double) + 1); }
@@ -256,7 +257,8 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   p->ones = ar.take<double>(p->maxN);
   {
     const size_t ns = hyper_num_sums(p->maxm);
-    p->hyp = ar.take<double>(ns * hyper_kuf_records(p->maxN, (int)M));
+    p->hyp_stride = ns * hyper_kuf_records(p->maxN, (int)M);
+    p->hyp = ar.take<double>(p->hyp_stride * (size_t)(p->P > 0 ? p->P : 1));
     p->hyp_uu = ar.take<double>(ns * hyper_kuf_records((int)M, (int)M));
   }
   p->chol_blocked = sgpr_chol_blocked(p);
@@ -543,12 +545,30 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
   f = GemmFlags(); f.triB = TRI_LOWER;
   GP_CHECK(launch_gemm_batched(h, D + Q_S, 1, M, M, f));
   // every kernel of the sum sees the same Kuf_bar / Kuu_bar (K = sum_p K_p)
+  // (Kuf side: all-Mercer sums of up to six kernels with at most four partials each go through ONE pass over Kuf_bar)
+  bool fused = false;
+  int np_fused = 0;
+  {
+    std::vector<DevKern> kerns(p->P);
+    std::vector<double*> feats(p->P), parts(p->P);
+    for (int i = 0; i < p->P; i++) {
+      kerns[i] = sg_kern(p, params, i);
+      feats[i] = p->feat + (size_t)i * sgpr_feat_stride(p);
+      parts[i] = p->hyp + (size_t)i * p->hyp_stride;
+    }
+    gp_status st = GP_OK;
+    fused = launch_hyper_contract_sum(h, kerns.data(), feats.data(), parts.data(), p->P, Z, M, X, N, p->G, ld, p->alpha, Y, f32,
+                                      &np_fused, &st);
+    if (fused) GP_CHECK(st);
+  }
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
     double* feat = p->feat + (size_t)i * sgpr_feat_stride(p);   // this kernel's (Z | X) features, from the forward pass
-    int np_uf = 0, np_uu = 0;
-    GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, feat, p->hyp, &np_uf, nullptr, nullptr, 0, f32));
-    GP_CHECK(launch_hyper_finish(h, k, p->hyp, np_uf, include_replicated ? p->scal + 4 : nullptr, grad + p->off_theta[i],
+    int np_uf = np_fused, np_uu = 0;
+    double* hyp_i = fused ? p->hyp + (size_t)i * p->hyp_stride : p->hyp;
+    if (!fused)
+      GP_CHECK(launch_hyper_contract(h, k, Z, M, X, N, p->G, ld, p->alpha, Y, 0, feat, hyp_i, &np_uf, nullptr, nullptr, 0, f32));
+    GP_CHECK(launch_hyper_finish(h, k, hyp_i, np_uf, include_replicated ? p->scal + 4 : nullptr, grad + p->off_theta[i],
                                  nullptr, 0, M, nullptr));
     if (include_replicated) {
       GP_CHECK(launch_hyper_contract(h, k, Z, M, Z, M, p->E2, M, nullptr, nullptr, 1, feat, p->hyp_uu, &np_uu, nullptr));
