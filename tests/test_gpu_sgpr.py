@@ -20,7 +20,7 @@ def _model(X, Y, Z, kdicts, noise, handle, reg=False, float_type=None):
     return m
 
 
-def _problem(N, M, P, seed):
+def _problem(N, M, P, seed, npart=2):
     rng = np.random.RandomState(seed)
     fs = 16000.
     X = np.linspace(0, (N - 1) / fs, N).reshape(-1, 1)
@@ -30,7 +30,8 @@ def _problem(N, M, P, seed):
         f0 = 220. * 2 ** (p * 4 / 12.)
         Y += np.sin(2 * np.pi * f0 * X) * np.exp(-((X - X.mean()) / (0.3 * np.ptp(X) + 1e-9)) ** 2)
         kl.append({"type": "mercer_matern12sm", "variance": 1.0 + 0.1 * p, "lengthscales": 0.05 + 0.02 * p,
-                   "energy": [0.6, 0.4], "frequency": [f0, 2 * f0]})
+                   "energy": [0.6, 0.4] if npart == 2 else list(np.linspace(1.0, 0.2, npart) / npart),
+                   "frequency": [f0 * (q + 1) for q in range(npart)]})
     Y += 0.05 * rng.randn(N, 1)
     Z = X[:: max(N // M, 1)][:M].copy()
     return X, Y, Z, kl
@@ -108,9 +109,13 @@ def _torch_bound_and_grads(X, Y, Z, kl, noise, reg=False):
     return float(b.detach()), np.array([float(l.grad) for l in leaves])
 
 
-@pytest.mark.parametrize("N,M,P,reg", [(300, 16, 1, False), (1200, 48, 3, True)])
-def test_sgpr_gradient_matches_autograd(gp_handle, N, M, P, reg):
-    X, Y, Z, kl = _problem(N, M, P, N + 1)
+@pytest.mark.parametrize("N,M,P,reg,npart", [(300, 16, 1, False, 2), (1200, 48, 3, True, 2), (1100, 40, 5, False, 4),
+                                             (900, 32, 3, False, 6)])
+def test_sgpr_gradient_matches_autograd(gp_handle, N, M, P, reg, npart):
+    """P >= 2 Mercer kernels: Kuu / Kuf of the sum come from one pass (cov_mercer_sum_kernel: padded partial counts 4 and
+    8) and, with at most four partials per kernel, the Kuf-side contractions of all kernels from one pass over Kuf_bar
+    (hyper_contract_sum_kernel); six partials take the per-kernel contraction"""
+    X, Y, Z, kl = _problem(N, M, P, N + 1, npart)
     m = _model(X, Y, Z, kl, 0.3, gp_handle, reg=reg)
     m._compile(); m._pack()
     ps = m._param_list()
