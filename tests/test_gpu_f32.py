@@ -13,6 +13,7 @@ STATED TOLERANCES (relative; measured on MI355X, each bound has >= 3x headroom o
   gradients (relative to the largest entry of each parameter block): 5e-3, except the activation kernels'
   lengthscale and inducing inputs (the ill-conditioned direction): 2e-1
 """
+import os
 import numpy as np
 import pytest
 
@@ -250,3 +251,15 @@ def test_f32_adam_trajectory_stays_with_the_f64_one_on_cfg3(gp_handle):
           % (d_fun, d_ls, moved, d_hyp, d_q))
     assert moved > 0.05                      # the lengthscales did train (50 steps x lr 0.0025 on the free state)
     assert d_fun <= 5e-5 and d_ls <= 2e-4 and d_hyp <= 2e-4 and d_q <= 1e-2
+
+
+def test_lds_resident_f32_products_opt_in():
+    """gemm_res_f32.hip is off by default (it ties the tiled kernels alone and loses in the overlapped step); its parity is
+    kept by running the M = 128 / 256 cases of this file in a child process with GP_RES32=1 (the switch is read once per
+    process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GP_RES32="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
+                        "-k", "2048-128 or 4096-256"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
