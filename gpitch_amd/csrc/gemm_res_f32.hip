@@ -1,19 +1,18 @@
 // gemm_res_f32.hip — float32 strip products for SMALL inducing sets (M <= 256) with the M x M operand RESIDENT in LDS
-// (gfx950, round 3).  BASELINE configs[2] (12 pitches, M = 256 per pitch, fp32) is the case: with K = M = 256 a
-// 128 x 128 output tile of gemm_f32.hip / gemm_strip_f32.hip lives for only 8 K-tiles, its prologue (first operand round
-// trip) and epilogue are a third of its life, and the products ran at 0.31-0.43 of the float32 matrix peak.
+// (gfx950, round 3; opt-in, GP_RES32=1: see the measurements at launch_gemm_res_f32).
 //
-// Here a workgroup (8 wavefronts, ONE per CU: the LDS is the resource) takes a 128-row block of op(A) — W = Lm^-1
+// A workgroup (8 wavefronts, ONE per CU: the LDS is the resource) takes a 128-row block of op(A) — W = Lm^-1
 // (gpitch/pdgp.py:147 conditional: matrix_triangular_solve as a product), Lq^T, or R = W^T (Lq Lq^T - I) of the backward
 // pass — converts it to float32 ONCE into LDS (128 rows x K <= 256: 128 KiB, already in MFMA fragment order) and then
-// streams the float32 strip B through a 3-slot ring of 16-row K-tiles (24 KiB) for a whole run of column tiles: the
-// stream never stops at a tile boundary (the next column tile's first K-tiles are in flight while the current one
-// finishes), there is no A staging at all, and the epilogue of a column tile is the only thing between two K loops.
-//   wavefront w owns all 128 rows x columns [16 w, 16 w + 16) of the 128-column tile: 8 accumulators of
-//   v_mfma_f32_16x16x4_f32, so the column reductions (sum A^2, A^T q_mu, sum LTA^2) finish inside one wavefront exactly
-//   as in the other strip kernels (row-block partials, fixed order, float64).
-// LDS fragment order: A: [k-step][row-tile half][lane][row tile & 3] so one ds_read_b128 fetches four row tiles' operands;
-//                     B slot: [column tile][lane][k-step & 3] so one ds_read_b128 fetches a K-tile's four k-steps.
+// streams the float32 strip B for a whole run of column tiles.  The strip never touches LDS: wavefront (wr, wc) owns rows
+// [64 wr, +64) x columns [32 wc, +32) of the 128-column tile and loads just its own B fragments straight into the MFMA
+// operand layout (eight dword loads per lane and 16-row K-tile, four K-tiles in flight in four register buffers that keep
+// their identity), so after the resident block is in place NOTHING is shared between the wavefronts and the K loop has no
+// barrier; the stream does not stop at a column-tile boundary either.  Column reductions (sum A^2, A^T q_mu, sum LTA^2:
+// float64, row-block partials as in the other strip kernels) combine the two row halves through LDS in a fixed order,
+// one barrier per column tile.
+// LDS fragment order of the resident block: [k-step][row-tile half][lane][row tile & 3]: one ds_read_b128 fetches a
+// wavefront's four row tiles' operands of a k-step.
 // What is float32 / float64 is gemm_f32.hip's contract; the role-3 column scale (2 gv, folded alpha) is applied to the
 // OUTPUT columns here ((R A) D instead of R (A D): same product, one float32 rounding placed differently).
 #include "common.h"
@@ -33,12 +32,12 @@ typedef float __attribute__((address_space(1))) * gfptr;
 #endif
 #define RS_BT 128
 #define RS_BK 16
-#define RS_RING 3
+#define RS_RING 0                                     // (the strip no longer goes through LDS: see the B stream below)
 #define RS_THREADS 512
 #define RS_MAXK 256
 #define RS_SLOT 2048                                  // floats per ring slot: 8 column tiles x 64 lanes x 4 k-steps
 #define RS_A_FLOATS (RS_MAXK * RS_BT)                 // 32768
-#define RS_BYTES ((size_t)(RS_A_FLOATS + RS_RING * RS_SLOT) * sizeof(float) + RS_BT * sizeof(double))
+#define RS_BYTES ((size_t)RS_A_FLOATS * sizeof(float) + (RS_BT + 2 * 4 * 32 * 2) * sizeof(double))
 
 struct ResFlags {
   int tilesM, tm0;          // row-blocks of this launch: [tm0, tm0 + tilesM)
@@ -60,8 +59,7 @@ __global__ void __launch_bounds__(RS_THREADS) gemm_res_f32_kernel(const GemmProb
   constexpr int TRI = (TAG == 1) ? TRI_LOWER : (TAG == 2) ? TRI_UPPER : TRI_NONE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ares = smem;
-  float* Bring = smem + RS_A_FLOATS;
-  double* v0s = reinterpret_cast<double*>(Bring + RS_RING * RS_SLOT);
+  double* v0s = reinterpret_cast<double*>(smem + RS_A_FLOATS);
   const GemmProblem p = probs[blockIdx.z];
   // item = (row-block, run of column tiles).  Workgroups are dealt round-robin to the 8 XCDs: the row-blocks of one run
   // (same B columns) are given ids 8 apart, i.e. the same L2
@@ -122,30 +120,32 @@ __global__ void __launch_bounds__(RS_THREADS) gemm_res_f32_kernel(const GemmProb
     if ((f.epi & EPI_COLDOT) && tid < RS_BT) v0s[tid] = ((gcptr)p.v0)[i0 + tid];
   }
 
-  // ---- B stream: thread -> column bc of the tile and the four k rows kk, kk + 4, kk + 8, kk + 12 of a K-tile: four dword
-  //      loads (a wavefront reads 256 contiguous bytes of a row) and ONE 16-byte LDS write — the ring slot is
-  //      [column tile][lane = 16 (k & 3) + (column & 15)][k-step], so this thread's four values are adjacent ---------------
-  const int bc = tid & 127, kk = tid >> 7;
-  const uint32_t voffB = (uint32_t)(((int64_t)kk * p.ldb + bc) * 4);
-  const int wB = ((bc >> 4) * 64 + 16 * kk + (bc & 15)) * 4;                               // floats inside a slot
+  // ---- B stream, per WAVEFRONT and through registers only: wavefront w needs just its own 16 columns of a K-tile, in the
+  //      MFMA operand layout (lane = 16 (k & 3) + column): four dword loads per lane and K-tile, RS_NB K-tiles in flight.
+  //      Nothing is shared between the wavefronts after the resident operand is in place, so the K loop has NO barrier:
+  //      the wavefronts drift apart and the matrix pipe of a SIMD always has one of its two wavefronts to run.
+  const int wr = w >> 2, wc = w & 3;            // wavefront tile: rows [64 wr, 64 wr + 64) x columns [32 wc, 32 wc + 32)
+  const uint32_t voffB = (uint32_t)(((int64_t)kq * p.ldb + lc) * 4);
   const int64_t rowB4 = (int64_t)4 * p.ldb * 4;                                          // four k rows further
   const int64_t stepB = (int64_t)RS_BK * p.ldb * 4;
   const int64_t wrapB = (int64_t)RS_BT * 4 - (int64_t)nk * stepB;                       // back to the first K-tile, next column tile
-  gcbytes sB = rs_uniform((gcbytes)p.B + ((int64_t)kbeg * p.ldb + (int64_t)ct0 * RS_BT) * 4);
+  gcbytes sB = rs_uniform((gcbytes)p.B + ((int64_t)kbeg * p.ldb + (int64_t)ct0 * RS_BT + 32 * wc) * 4);
   int gl = 0, gl_kt = 0;                       // next K-tile of the stream to request, its index inside the column tile
   // (an unconditional load — past the end of the stream the last K-tile is simply read again: a load inside a branch
-  // makes every later wait a wait for ALL outstanding loads, and the stream's latency budget is three iterations)
-  auto request = [&](f4& rb) {
+  // makes every later wait a wait for ALL outstanding loads)
+  typedef const float __attribute__((address_space(1))) * gcfptr;
+  struct BBuf { f4 c0, c1; };                   // B fragments of the wavefront's two column tiles, k-steps 0..3
+  auto request = [&](BBuf& rb) {
     uint32_t vo = voffB;
     asm volatile("" : "+v"(vo));
-    typedef const float __attribute__((address_space(1))) * gcfptr;
 #if RS_EXP == 1
     gl++; return;      // measurement variant: no stream loads (results are garbage)
 #endif
-    rb.x = *(gcfptr)(sB + vo);
-    rb.y = *(gcfptr)(rs_uniform(sB + rowB4) + vo);
-    rb.z = *(gcfptr)(rs_uniform(sB + 2 * rowB4) + vo);
-    rb.w = *(gcfptr)(rs_uniform(sB + 3 * rowB4) + vo);
+    const gcbytes s1 = rs_uniform(sB + rowB4), s2 = rs_uniform(sB + 2 * rowB4), s3 = rs_uniform(sB + 3 * rowB4);
+    rb.c0.x = *(gcfptr)(sB + vo); rb.c1.x = *(gcfptr)(sB + vo + 64);       // (the two halves of a 128-byte line, back to back)
+    rb.c0.y = *(gcfptr)(s1 + vo); rb.c1.y = *(gcfptr)(s1 + vo + 64);
+    rb.c0.z = *(gcfptr)(s2 + vo); rb.c1.z = *(gcfptr)(s2 + vo + 64);
+    rb.c0.w = *(gcfptr)(s3 + vo); rb.c1.w = *(gcfptr)(s3 + vo + 64);
     gl++;
     if (gl < G) {
       sB = (gcbytes)((int64_t)sB + stepB);
@@ -153,16 +153,13 @@ __global__ void __launch_bounds__(RS_THREADS) gemm_res_f32_kernel(const GemmProb
       if (gl_kt == nk) { gl_kt = 0; sB = (gcbytes)((int64_t)sB + wrapB); }
     }
   };
-  auto deposit = [&](const f4& rb, int slot) {
-    *reinterpret_cast<f4*>(Bring + slot * RS_SLOT + wB) = rb;
-  };
   // role 3: the sixteen column scales of this wavefront's columns come through the scalar cache (constant address space:
   // 2 gv is not written while this kernel runs), one column tile ahead, and are dealt to the lanes with selects
   typedef const double __attribute__((address_space(4))) * ccptr;
-  auto column_scale = [&](int ctile) -> float {
+  auto column_scale = [&](int ctile, int b) -> float {
     float sc = 1.f;
     if (TAG == 3) {
-      const ccptr cv = (ccptr)p.v1 + ((int64_t)min(ctile, f.tilesN - 1) * RS_BT + 16 * w);
+      const ccptr cv = (ccptr)p.v1 + ((int64_t)min(ctile, f.tilesN - 1) * RS_BT + 32 * wc + 16 * b);
       double dv[16], d = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; c++) dv[c] = cv[c];
@@ -174,39 +171,24 @@ __global__ void __launch_bounds__(RS_THREADS) gemm_res_f32_kernel(const GemmProb
     }
     return sc;
   };
-  f4 rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = rb0, rb2 = rb0;
-  {   // tiles 0, 1 -> slots 0, 1; tiles 2, 3, 4 -> the three register buffers
-    f4 t0 = rb0, t1 = rb0;
-    request(t0); request(t1);
-    request(rb0); request(rb1); request(rb2);
-    deposit(t0, 0); deposit(t1, 1);
-  }
-  float sc = column_scale(ct0);
-  f4 acc[8];
+  BBuf rb0 = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, rb1 = rb0, rb2 = rb0, rb3 = rb0;
+  request(rb0); request(rb1); request(rb2); request(rb3);
+  float sc0 = column_scale(ct0, 0), sc1 = column_scale(ct0, 1);
+  f4 acc[4][2];
 #pragma unroll
-  for (int a = 0; a < 8; a++) acc[a] = f4{0.f, 0.f, 0.f, 0.f};
-  const float* Al = Ares + lane * 4;                          // + (ks * 2 + half) * 256 floats
-  const float* Bl = Bring + (w * 64 + lane) * 4;              // + slot * RS_SLOT
-  int kt = 0, ct = 0, slot = 0, wslot = 2;
-  // one K-tile; `rb` = the register buffer that holds K-tile t + 2 (deposited now) and receives K-tile t + 5
-  auto body = [&](f4& rb) {
-#if RS_EXP != 2
-    __syncthreads();
-#endif
-    // operands of K-tile t: four k-steps of the resident block, one fragment quad of the ring
-    const f4 bq = *reinterpret_cast<const f4*>(Bl + slot * RS_SLOT);
-    f4 af[4][2];
+  for (int a = 0; a < 4; a++) { acc[a][0] = f4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = acc[a][0]; }
+  const float* Al = Ares + lane * 4 + wr * 256;               // + ks * 512 floats: this wavefront's four row tiles
+  double* comb = v0s + RS_BT;                                 // [2][4 wc][32 columns][2]: the lower row half's column sums
+  int kt = 0, ct = 0;
+  __syncthreads();                                            // the resident operand is complete
+  // one K-tile; `rb` holds its B fragments (requested four K-tiles ago) and receives K-tile t + 4
+  auto body = [&](BBuf& rb) {
+    f4 af[4];
     {
       const float* Ak = Al + kt * (4 * 2 * 256);
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        af[ks][0] = *reinterpret_cast<const f4*>(Ak + (ks * 2 + 0) * 256);
-        af[ks][1] = *reinterpret_cast<const f4*>(Ak + (ks * 2 + 1) * 256);
-      }
+      for (int ks = 0; ks < 4; ks++) af[ks] = *reinterpret_cast<const f4*>(Ak + ks * 512);
     }
-    deposit(rb, wslot);
-    request(rb);
-    wslot = (wslot == RS_RING - 1) ? 0 : wslot + 1;
     // structural zeros of the triangular operands: 16-row tiles outside [alo, ahi] are zero for this whole K-tile
     int alo = 0, ahi = 7;
     {
@@ -214,77 +196,102 @@ __global__ void __launch_bounds__(RS_THREADS) gemm_res_f32_kernel(const GemmProb
       if (TRI == TRI_LOWER && krel >= 0) alo = krel >> 4;
       if (TRI == TRI_UPPER) ahi = min(7, (krel + 3) >> 4);
     }
-    const float bqv[4] = {bq.x, bq.y, bq.z, bq.w};
-    if (RS_EXP == 3) { acc[0][0] += af[0][0][0] * bqv[0] + af[3][1][3] * bqv[3]; }
-    else if (TRI == TRI_NONE || (alo == 0 && ahi == 7)) {
+    alo -= 4 * wr; ahi -= 4 * wr;                             // in this wavefront's row tiles 0..3
+    const float b0v[4] = {rb.c0.x, rb.c0.y, rb.c0.z, rb.c0.w}, b1v[4] = {rb.c1.x, rb.c1.y, rb.c1.z, rb.c1.w};
+    if (RS_EXP == 3) { acc[0][0][0] += af[0][0] * b0v[0] + af[3][3] * b1v[3]; }
+    else if (TRI == TRI_NONE || (alo <= 0 && ahi >= 3)) {
 #pragma unroll
       for (int ks = 0; ks < 4; ks++)
 #pragma unroll
-        for (int a = 0; a < 8; a++)
-          acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][a >> 2][a & 3], bqv[ks], acc[a], 0, 0, 0);
+        for (int a = 0; a < 4; a++) {
+          acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][a], b0v[ks], acc[a][0], 0, 0, 0);
+          acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][a], b1v[ks], acc[a][1], 0, 0, 0);
+        }
     } else {
 #pragma unroll
-      for (int a = 0; a < 8; a++)
+      for (int a = 0; a < 4; a++)
         if (a >= alo && a <= ahi) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ks++)
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][a >> 2][a & 3], bqv[ks], acc[a], 0, 0, 0);
+          for (int ks = 0; ks < 4; ks++) {
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][a], b0v[ks], acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][a], b1v[ks], acc[a][1], 0, 0, 0);
+          }
         }
     }
-    slot = (slot == RS_RING - 1) ? 0 : slot + 1;
+    request(rb);
     kt++;
     if (kt == nk) {
-      // ---- epilogue of column tile ct0 + ct: element r of accumulator a = row 16 a + 4 kq + r, column 16 w + lc -------
+      // ---- epilogue of column tile ct0 + ct: element r of accumulator (a, b) = row 64 wr + 16 a + 4 kq + r,
+      //      column 32 wc + 16 b + lc ---------------------------------------------------------------------------------------
       kt = 0;
       const int j0 = (ct0 + ct) * RS_BT;
-      const int j = j0 + 16 * w + lc;
-      const float scn = column_scale(ct0 + ct + 1);     // (requested first: consumed after the stores below)
+      const float scn0 = column_scale(ct0 + ct + 1, 0), scn1 = column_scale(ct0 + ct + 1, 1);   // (consumed after the stores)
       if (f.epi & EPI_STORE) {
         uint32_t vo = (uint32_t)(((int64_t)(4 * kq) * p.ldc + lc) * 4);
         asm volatile("" : "+v"(vo));
-        const gcbytes cb0 = (gcbytes)p.C + ((int64_t)i0 * p.ldc + j0 + 16 * w) * 4;
+        const gcbytes cb0 = (gcbytes)p.C + ((int64_t)(i0 + 64 * wr) * p.ldc + j0 + 32 * wc) * 4;
 #pragma unroll
-        for (int a = 0; a < 8; a++)
+        for (int a = 0; a < 4; a++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const gbytes cb = (gbytes)rs_uniform(cb0 + (int64_t)(16 * a + r) * p.ldc * 4);
-            *(gfptr)(cb + vo) = (TAG == 3) ? acc[a][r] * sc : acc[a][r];
+            *(gfptr)(cb + vo) = (TAG == 3) ? acc[a][0][r] * sc0 : acc[a][0][r];
+            *(gfptr)(cb + vo + 64) = (TAG == 3) ? acc[a][1][r] * sc1 : acc[a][1][r];
           }
       }
       if (f.epi & (EPI_COLSUMSQ | EPI_COLDOT)) {
-        const double* vv = v0s + 4 * kq;
-        double s2 = 0.0, sd = 0.0;
+        const double* vv = v0s + 64 * wr + 4 * kq;
+        double s2[2] = {0.0, 0.0}, sd[2] = {0.0, 0.0};
 #pragma unroll
-        for (int a = 0; a < 8; a++)
+        for (int b = 0; b < 2; b++) {
+          const float scb = b ? sc1 : sc0;
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const double v = (double)((TAG == 3) ? acc[a][r] * sc : acc[a][r]);
-            s2 = fma(v, v, s2);
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const double v = (double)((TAG == 3) ? acc[a][b][r] * scb : acc[a][b][r]);
+              s2[b] = fma(v, v, s2[b]);
+            }
+          if (f.epi & EPI_COLDOT) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                sd[b] = fma((double)((TAG == 3) ? acc[a][b][r] * scb : acc[a][b][r]), vv[a * 16 + r], sd[b]);
           }
-        if (f.epi & EPI_COLDOT) {
-#pragma unroll
-          for (int a = 0; a < 8; a++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) sd = fma((double)((TAG == 3) ? acc[a][r] * sc : acc[a][r]), vv[a * 16 + r], sd);
+          s2[b] += __shfl_xor(s2[b], 16, 64); s2[b] += __shfl_xor(s2[b], 32, 64);
+          sd[b] += __shfl_xor(sd[b], 16, 64); sd[b] += __shfl_xor(sd[b], 32, 64);
         }
-        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-        sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
-        if (kq == 0) {
-          if (f.epi & EPI_COLSUMSQ) ((gptr)p.o0)[(int64_t)tm * p.N + j] = s2;
-          if (f.epi & EPI_COLDOT) ((gptr)p.o1)[(int64_t)tm * p.N + j] = sd;
+        // the two row halves of a column are summed in a fixed order (upper half + lower half) through LDS: one barrier
+        // per column tile, two alternating buffers
+        double* cbuf = comb + (ct & 1) * (4 * 32 * 2) + wc * (32 * 2);
+        if (wr == 1 && kq == 0) {
+#pragma unroll
+          for (int b = 0; b < 2; b++) { cbuf[(16 * b + lc) * 2] = s2[b]; cbuf[(16 * b + lc) * 2 + 1] = sd[b]; }
+        }
+        __syncthreads();
+        if (wr == 0 && kq == 0) {
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            const int j = j0 + 32 * wc + 16 * b + lc;
+            if (f.epi & EPI_COLSUMSQ) ((gptr)p.o0)[(int64_t)tm * p.N + j] = s2[b] + cbuf[(16 * b + lc) * 2];
+            if (f.epi & EPI_COLDOT) ((gptr)p.o1)[(int64_t)tm * p.N + j] = sd[b] + cbuf[(16 * b + lc) * 2 + 1];
+          }
         }
       }
 #pragma unroll
-      for (int a = 0; a < 8; a++) acc[a] = f4{0.f, 0.f, 0.f, 0.f};
-      sc = scn;
+      for (int a = 0; a < 4; a++) { acc[a][0] = f4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = acc[a][0]; }
+      sc0 = scn0; sc1 = scn1;
       ct++;
     }
   };
-  for (int t = 0; t < G;) {       // unrolled over the three register buffers: each keeps its identity, no copies
-    body(rb0); if (++t >= G) break;
-    body(rb1); if (++t >= G) break;
-    body(rb2); ++t;
-  }
+  // unrolled over the four register buffers (each keeps its identity: no copies); a single-exit main loop, then the
+  // remainder as straight-line code
+  int t = 0;
+  for (; t + 4 <= G; t += 4) { body(rb0); body(rb1); body(rb2); body(rb3); }
+  if (t < G) body(rb0);
+  if (t + 1 < G) body(rb1);
+  if (t + 2 < G) body(rb2);
 }
 
 template <int TAG>
@@ -315,13 +322,14 @@ static gp_status launch_res32(gp_handle h, const GemmProblem* d_probs, int batch
 
 // true = taken (status in *st).  Whole aligned strips, M a multiple of 128 and at most 256, every problem M = maxM.
 bool launch_gemm_res_f32(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f, gp_status* st) {
-  // OFF by default (GP_RES32=1 selects it).  MEASURED on cfg3 (N = 32768, M = 256, P = 12, same box): alone on the device it
-  // ties gemm_f32.hip's kernels — Kuf_bar 1.00 vs 0.98 ms per step (0.66 of the float32 matrix peak both), A = W Kuf 0.97 vs
-  // 0.96, Lq^T A 0.86 vs 0.75 — because at this size the products are within 1.6x of their HBM time (6.4 GB of strips per
-  // step), not bound by tile prologues as their in-step timers (inflated by the kernels running beside them) suggested;
-  // and in the overlapped step it LOSES (5.1 vs 4.8 ms): a workgroup that owns a CU's whole LDS keeps the helper stream's
-  // kernels off that CU.  Ablations (-DRS_EXP=1/2/3): without the stream's loads 0.89, without the barrier 0.90, without
-  // the MFMAs 0.46 ms.  Kept as a measured alternative; parity: tests/test_gpu_f32.py (GP_RES32=1).
+  // OFF by default (GP_RES32=1 selects it).  MEASURED on cfg3 (N = 32768, M = 256, P = 12, same box), ms per step, this
+  // kernel / gemm_f32.hip's tiled kernels: ALONE on the device A = W Kuf 0.79 / 1.00, Lq^T A 0.78 / 0.75, Kuf_bar 0.90 /
+  // 0.98 (0.73 / 0.67 of the float32 matrix peak), the whole step with everything serial 5.18 / 5.44; in the OVERLAPPED step
+  // 4.74 / 4.74 — a workgroup that owns a CU's whole LDS keeps the helper stream's kernels (split-K product, M x M chain)
+  // off that CU, and what it gains alone it loses there.  First version (strip through a 3-slot LDS ring with a barrier
+  // per K-tile): 0.97 / 0.86 / 1.00 alone, 5.1 ms overlapped.  Ablations of that version (-DRS_EXP=1/2/3): without the
+  // stream's loads 0.89, without the barrier 0.90, without the MFMAs 0.46 ms.  Parity: tests/test_gpu_f32.py in a
+  // GP_RES32=1 child process.
   static const bool enabled = getenv("GP_RES32") && atoi(getenv("GP_RES32")) != 0;
   if (!enabled || !f.uniform_aligned || f.role < 1 || f.role > 3) return false;
   if (maxM > RS_MAXK || (maxM % RS_BT) != 0 || (maxN % RS_BT) != 0 || f.beta != 0.0 || f.triC != TRI_NONE) return false;
