@@ -256,12 +256,24 @@ class Pdgp(Parameterized):
 
     def _batch(self):
         """fresh minibatch (x and y generators are seeded identically so rows stay paired: pdgp.py:76-77)"""
-        idx = self.x.next_indices()
-        idy = self.y.next_indices()
-        assert np.array_equal(idx, idy)
         # The batch is a SET of frames (the ELBO sums over it): handing it to the engine in time order changes nothing but
         # the order of that sum, and lets the covariance kernels factorise the envelope away from the diagonal band
         # (cov.hip: separable envelope) — with a shuffled batch every 64-column tile straddles the whole signal.
+        n_all = int(self._x_dev.shape[0])
+        if self.x.minibatch_size >= n_all and self.y.minibatch_size >= n_all:
+            # minibatch_size = N (the benchmark configurations): GPflow draws rng.permutation(N)[:N] — every draw is the
+            # whole data set, whatever the order; in time order that is the data as it lies in memory.  No draw, no sort,
+            # no index upload, no gather: at 4-5 ms per step the two 32768-element permutations and the sort were 1.7 ms
+            # of host time per step, as much as the rest of the step's launches (tools/host_profile.py).
+            return self._x_dev, self._y_dev, n_all
+        idx = self.x.next_indices()
+        # the y generator is seeded like x's and drawn in lockstep (pdgp.py:76-77): it is advanced by copying the state
+        # instead of drawing the same indices a second time
+        if self.y.rng is not self.x.rng:
+            if hasattr(self.x.rng, "get_state") and hasattr(self.y.rng, "set_state"):
+                self.y.rng.set_state(self.x.rng.get_state())
+            else:
+                self.y.next_indices()        # a generator object without state access: draw the pair, as before
         idx = np.sort(idx, kind="stable")
         ti = self._upload_indices(idx)
         return self._x_dev.index_select(0, ti).contiguous(), self._y_dev.index_select(0, ti).contiguous(), idx.size
