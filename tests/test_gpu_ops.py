@@ -85,6 +85,25 @@ def test_kuu_cholesky_and_inverse(gp_handle, M):
     np.testing.assert_allclose(Wg @ Lg, np.eye(M), rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("M,ld", [(75, 75), (300, 302), (512, 512), (620, 620), (1100, 1100)])
+def test_cholesky_inplace_one_workgroup(gp_handle, M, ld):
+    """gp_cholesky_inplace = chol_kernel on one matrix: whole 32-row tiles take the lean update (C block loaded into the
+    accumulators, negated-operand MFMA), ragged sizes the general tile; from M = 620 on the panel no longer fits the LDS and
+    the operands come from the matrix itself; 1100 rows also leave the tile table (1056 rows) for the index arithmetic"""
+    h = gp_handle
+    rng = np.random.RandomState(M)
+    z = np.sort(rng.rand(M)) * 2.0
+    K = np.exp(-np.abs(z[:, None] - z[None, :]) / 0.3) + 1e-6 * np.eye(M)
+    A = np.zeros((M, ld))
+    A[:, :M] = K
+    dA = h.to_device(A)
+    h.check(h.lib.gp_cholesky_inplace(h.h, dA.data_ptr(), M, ld))
+    L = dA.cpu().numpy()[:, :M]
+    assert np.all(np.triu(L, 1) == 0)
+    np.testing.assert_allclose(L @ L.T, K, rtol=0, atol=1e-12 * M)
+    np.testing.assert_allclose(L, np.linalg.cholesky(K), rtol=0, atol=1e-8)
+
+
 def test_cholesky_reports_not_pd(gp_handle):
     from gpitch_amd import _lib
     h = gp_handle
