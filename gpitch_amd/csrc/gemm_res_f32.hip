@@ -28,14 +28,12 @@ typedef const f4 __attribute__((address_space(1))) * gcfptr4;
 typedef float __attribute__((address_space(1))) * gfptr;
 
 #ifndef RS_EXP
-#define RS_EXP 0      // measurement variants (tools/build_variant.sh): 1 no stream loads, 2 no barrier, 3 no MFMAs
+#define RS_EXP 0      // measurement variants (tools/build_variant.sh): 1 no stream loads, 3 no MFMAs
 #endif
 #define RS_BT 128
 #define RS_BK 16
-#define RS_RING 0                                     // (the strip no longer goes through LDS: see the B stream below)
 #define RS_THREADS 512
 #define RS_MAXK 256
-#define RS_SLOT 2048                                  // floats per ring slot: 8 column tiles x 64 lanes x 4 k-steps
 #define RS_A_FLOATS (RS_MAXK * RS_BT)                 // 32768
 #define RS_BYTES ((size_t)RS_A_FLOATS * sizeof(float) + (RS_BT + 2 * 4 * 32 * 2) * sizeof(double))
 
