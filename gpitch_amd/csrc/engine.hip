@@ -338,7 +338,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
         GP_CHECK(launch_sm_features_items(h, (const FeatItem*)(cb.d_desc + cb.off_feat_x) + gr.first, cnt, N, mp, x, N));
       }
       GP_CHECK(launch_kernel_build_items(h, gr.type, gr.m, (const CovItem*)(cb.d_desc + cb.off_cov_uf) + gr.first, cnt,
-                                         gr.maxM, N, x, N, 1));
+                                         gr.maxM, N, x, N, cb.f32 ? 2 : 1));     // 2: the strips are float32
     }
     return GP_OK;
   };
