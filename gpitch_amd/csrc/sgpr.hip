@@ -25,6 +25,10 @@ struct gp_sgpr_plan_s {
   double *E2 = nullptr, *T1 = nullptr, *T2 = nullptr, *Wbar = nullptr, *R = nullptr, *Binv = nullptr, *G = nullptr;
   double *ubar = nullptr, *Lu = nullptr, *alpha = nullptr, *ones = nullptr, *hyp = nullptr, *hyp_uu = nullptr;
   size_t hyp_stride = 0;    // doubles between the per-kernel partial record sets in hyp
+  size_t hyp_uu_stride = 0; // the same for the Kuu-side record sets in hyp_uu
+  std::vector<char> h_tail_fin;   // the batched gradient tail's finish items as last uploaded (sgpr_backward)
+  double *upart = nullptr;  // [max(nsplit, 2)][M] row-dot partials of u = A' y, fused into the H = A' A'^T launch
+  double *red = nullptr;    // [2][SG_RED_BLOCKS] partial sums of the two N-long reductions (tr H, sum y^2)
   double *scal = nullptr;   // [0] bound, [1] sum err^2, [2] sum colsumsq(A'), [3] kdiag total per point, [4] dF/dkd, [5] dF/ds
   char* d_desc = nullptr; std::vector<char> h_desc[2];   // two descriptor blocks (training pass / prediction pass)
   int nsplit = 2;
@@ -76,31 +80,50 @@ __global__ void __launch_bounds__(256) sgpr_B_kernel(const double* __restrict__ 
   }
 }
 
-// out[0] = sum_n v[n]^2 (one block)
-__global__ void __launch_bounds__(256) sumsq_kernel(const double* __restrict__ v, int n, double* __restrict__ out) {
-  __shared__ double red[256];
+// The two N-long sums of a bound evaluation — sum over the [rb][N] column partials of A'^2 (= tr H) and sum y^2 — as
+// SG_RED_BLOCKS partial sums each in ONE launch (grid (SG_RED_BLOCKS, 2)) and one small launch that adds them in a fixed
+// order: one block walking 262 144 doubles took 0.34 ms of a 4.5-ms evaluation at N = 65536.
+#define SG_RED_BLOCKS 128
+__global__ void __launch_bounds__(256) sgpr_sums_partial_kernel(const double* __restrict__ s1, int64_t n1,
+                                                                const double* __restrict__ y, int64_t n2,
+                                                                double* __restrict__ part) {
+  const bool sq = (blockIdx.y == 1);
+  const double* v = sq ? y : s1;
+  const int64_t n = sq ? n2 : n1;
+  // contiguous chunk per block (multiple of 256 elements), fixed order inside it
+  const int64_t per = ((n + SG_RED_BLOCKS - 1) / SG_RED_BLOCKS + 255) & ~(int64_t)255;
+  const int64_t beg = (int64_t)blockIdx.x * per, end = (beg + per < n) ? beg + per : n;
   double a = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) a = fma(v[i], v[i], a);
-  red[threadIdx.x] = a;
+  for (int64_t i = beg + threadIdx.x; i < end; i += 256) { const double x = v[i]; a = sq ? fma(x, x, a) : a + x; }
+  __shared__ double red[4];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) out[0] = red[0];
+  if (threadIdx.x == 0) part[blockIdx.y * SG_RED_BLOCKS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// scal[2] = sum of the first SG_RED_BLOCKS partials (tr H), scal[1] = sum of the second (sum y^2): wavefront w does row w
+__global__ void __launch_bounds__(128) sgpr_sums_final_kernel(const double* __restrict__ part, double* __restrict__ scal) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  double a = 0.0;
+  for (int i = l; i < SG_RED_BLOCKS; i += 64) a += part[w * SG_RED_BLOCKS + i];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if (l == 0) scal[w == 0 ? 2 : 1] = a;
 }
 
-// out[0] = sum over [rb][N] partials (one block)
-__global__ void __launch_bounds__(256) sum_all_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
-  __shared__ double red[256];
-  double a = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) a += v[i];
-  red[threadIdx.x] = a;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) out[0] = red[0];
+// c = WB (u / s2): one wavefront per row (coalesced reads of the lower-triangular row)
+__global__ void __launch_bounds__(256) sgpr_c_kernel(const double* __restrict__ WB, const double* __restrict__ u,
+                                                     double* __restrict__ c, int M, const double* __restrict__ params) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (i >= M) return;
+  double acc = 0.0;
+  for (int k = l; k <= i; k += 64) acc = fma(WB[(int64_t)i * M + k], u[k], acc);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (l == 0) c[i] = acc / params[0];
 }
 
-// c = WB (u / s2)  and the bound scalar.  One block.
-__global__ void __launch_bounds__(256) sgpr_finish_kernel(const double* __restrict__ WB, const double* __restrict__ LB,
-                                                          const double* __restrict__ u, double* __restrict__ c, int M,
+// The bound scalar from c = WB (u / s2) (sgpr_c_kernel), diag(LB) and the scalars.  One block.
+__global__ void __launch_bounds__(256) sgpr_finish_kernel(const double* __restrict__ LB,
+                                                          const double* __restrict__ c, int M,
                                                           int N, const double* __restrict__ params, int P,
                                                           const int* __restrict__ toff, const int* __restrict__ ktype,
                                                           const int* __restrict__ km, int reg,
@@ -109,10 +132,7 @@ __global__ void __launch_bounds__(256) sgpr_finish_kernel(const double* __restri
   const double s2 = params[0];
   double csq = 0.0, logd = 0.0;
   for (int i = threadIdx.x; i < M; i += 256) {
-    double acc = 0.0;
-    for (int k = 0; k <= i; k++) acc = fma(WB[(int64_t)i * M + k], u[k], acc);
-    acc /= s2;
-    c[i] = acc;
+    const double acc = c[i];
     csq = fma(acc, acc, csq);
     logd += log(LB[(int64_t)i * M + i]);
   }
@@ -184,14 +204,14 @@ static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   add(strip); add(strip);                            // Kuf, A
   add(sgpr_feat_stride(p) * p->P);                   // one feature table per kernel of the sum
   add((size_t)rb * p->maxN); add((size_t)rb * p->maxN); add((size_t)rb * p->maxN);
-  add(M); add(M); add(64);
+  add(M); add(M); add(64); add((size_t)(p->nsplit > 2 ? p->nsplit : 2) * M); add(2 * SG_RED_BLOCKS);
   add((size_t)p->nsplit * M * M);
   for (int i = 0; i < 6; i++) add(M * M);            // E2, T1, T2, Wbar, R, Binv
   add(strip); add(M); add(M); add(M); add(p->maxN);
   {
     const size_t ns = hyper_num_sums(p->maxm);
     add(ns * hyper_kuf_records(p->maxN, (int)M) * (size_t)(p->P > 0 ? p->P : 1));     // one record set per kernel of the sum (fused contraction)
-    add(ns * hyper_kuf_records((int)M, (int)M));
+    add(ns * hyper_kuf_records((int)M, (int)M) * (size_t)(p->P > 0 ? p->P : 1));
   }
   if (sgpr_chol_blocked(p)) { add(chol_inverse_blocked_workspace_bytes(p->M) / sizeof(double) + 1); add(chol_inverse_blocked_workspace_bytes(p->M) / sizeof(double) + 1); }
   return d;
@@ -250,6 +270,7 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
   p->s1 = ar.take<double>((size_t)rb * p->maxN); p->s2 = ar.take<double>((size_t)rb * p->maxN);
   p->dot = ar.take<double>((size_t)rb * p->maxN);
   p->u = ar.take<double>(M); p->c = ar.take<double>(M); p->scal = ar.take<double>(64);
+  p->upart = ar.take<double>((size_t)(p->nsplit > 2 ? p->nsplit : 2) * M); p->red = ar.take<double>(2 * SG_RED_BLOCKS);
   p->slabs = ar.take<double>((size_t)p->nsplit * M * M);
   p->E2 = ar.take<double>(M * M); p->T1 = ar.take<double>(M * M); p->T2 = ar.take<double>(M * M);
   p->Wbar = ar.take<double>(M * M); p->R = ar.take<double>(M * M); p->Binv = ar.take<double>(M * M);
@@ -259,7 +280,8 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
     const size_t ns = hyper_num_sums(p->maxm);
     p->hyp_stride = ns * hyper_kuf_records(p->maxN, (int)M);
     p->hyp = ar.take<double>(p->hyp_stride * (size_t)(p->P > 0 ? p->P : 1));
-    p->hyp_uu = ar.take<double>(ns * hyper_kuf_records((int)M, (int)M));
+    p->hyp_uu_stride = ns * hyper_kuf_records((int)M, (int)M);
+    p->hyp_uu = ar.take<double>(p->hyp_uu_stride * (size_t)(p->P > 0 ? p->P : 1));
   }
   p->chol_blocked = sgpr_chol_blocked(p);
   if (p->chol_blocked) {
@@ -284,10 +306,13 @@ static DevKern sg_kern(const gp_sgpr_plan_s* p, const double* params, int i) {
 
 // device descriptor upload helper: returns device pointers for up to 6 GemmProblems + 3 int arrays
 struct SgDesc { GemmProblem* probs; int* toff; int* ktype; int* km; };
-static gp_status sg_upload(gp_sgpr_plan p, const std::vector<GemmProblem>& probs, SgDesc* out, int slot) {
+// (`extra`: a blob placed at SG_EXTRA_OFF of the block — the batched gradient tail's item arrays, sgpr_backward)
+static const size_t SG_EXTRA_OFF = 6144, SG_TAIL_MAX = 16, SG_FIN_OFF = SG_EXTRA_OFF + 4096;
+static gp_status sg_upload(gp_sgpr_plan p, const std::vector<GemmProblem>& probs, SgDesc* out, int slot,
+                           const void* extra = nullptr, size_t extra_bytes = 0) {
   const size_t nb = probs.size() * sizeof(GemmProblem);
   const size_t off_int = gp_align_up(20 * sizeof(GemmProblem), 256);
-  if (off_int + 3 * 256 * sizeof(int) > SG_DESC_BYTES || p->P > 256 || probs.size() > 20)
+  if (off_int + 3 * 256 * sizeof(int) > SG_EXTRA_OFF || p->P > 256 || probs.size() > 20 || SG_EXTRA_OFF + extra_bytes > SG_FIN_OFF)
     return gp_fail(p->h, GP_ERR_UNSUPPORTED, "sgpr: too many kernels/problems for the descriptor block");
   std::vector<char>& hd = p->h_desc[slot];
   char* dd = p->d_desc + (size_t)slot * SG_DESC_BYTES;
@@ -295,6 +320,9 @@ static gp_status sg_upload(gp_sgpr_plan p, const std::vector<GemmProblem>& probs
   memcpy(hd.data(), probs.data(), nb);
   int* hi = (int*)(hd.data() + off_int);
   for (int i = 0; i < p->P; i++) { hi[i] = (int)p->off_theta[i]; hi[256 + i] = p->ktype[i]; hi[512 + i] = p->m[i]; }
+  if (extra && extra_bytes) memcpy(hd.data() + SG_EXTRA_OFF, extra, extra_bytes);
+  if (slot == 1 && p->h_tail_fin.size() <= SG_DESC_BYTES - SG_FIN_OFF && !p->h_tail_fin.empty())
+    memcpy(hd.data() + SG_FIN_OFF, p->h_tail_fin.data(), p->h_tail_fin.size());   // (keeps the block's last finish items: re-sent with it)
   if (!p->skip_upload)
     GP_HIP_CHECK(p->h, hipMemcpyAsync(dd, hd.data(), SG_DESC_BYTES, hipMemcpyHostToDevice, p->h->stream));
   out->probs = (GemmProblem*)dd;
@@ -322,7 +350,8 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   std::vector<GemmProblem> probs(3);
   memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
   { GemmProblem& r = probs[0]; r.A = p->W; r.lda = M; r.B = p->Kuf; r.ldb = ld; r.C = p->A; r.ldc = ld; r.M = M; r.N = N; r.K = M; r.o0 = p->s1; }
-  { GemmProblem& r = probs[1]; r.A = p->A; r.lda = ld; r.B = p->A; r.ldb = ld; r.C = p->H; r.ldc = M; r.M = M; r.N = M; r.K = N; r.o2 = p->slabs; }
+  { GemmProblem& r = probs[1]; r.A = p->A; r.lda = ld; r.B = p->A; r.ldb = ld; r.C = p->H; r.ldc = M; r.M = M; r.N = M; r.K = N; r.o2 = p->slabs;
+    r.v2 = Y; r.o1 = p->upart; r.o0 = p->u; }      // u = A' y fused into the product's first tile column (slab_reduce sums the K-slices)
   { GemmProblem& r = probs[2]; r.A = p->A; r.lda = ld; r.M = M; r.N = N; r.v0 = Y; r.o0 = p->u; r.a_f32 = f32; }
   GP_CHECK(sg_upload(p, probs, desc, 0));
   // Kuu, Kuf: GPflow Add kernel = sum over kern_list (sgpr_ss.py:42-43)
@@ -353,11 +382,11 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ; f.uniform_aligned = 1;   /* one problem, arena buffers, ld = gp_strip_ld */
     if (f32) { f.role = 1; GP_CHECK(launch_gemm_f32_role(h, desc->probs + 0, 1, M, N, f)); }
     else GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
-  hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, p->scal + 2);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, h->stream, Y, N, p->scal + 1);
+  hipLaunchKernelGGL(sgpr_sums_partial_kernel, dim3(SG_RED_BLOCKS, 2), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, Y,
+                     (int64_t)N, p->red);
+  hipLaunchKernelGGL(sgpr_sums_final_kernel, dim3(1), dim3(128), 0, h->stream, p->red, p->scal);
   if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0, 1));
   else GP_CHECK(launch_gemm_nt_reduce_batched(h, desc->probs + 1, 1, M, N, p->nsplit, 1, 0, 1.0, 1));
-  GP_CHECK(launch_rowdot_batched(h, desc->probs + 2, 1, M));
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -369,7 +398,8 @@ static gp_status sgpr_global(gp_sgpr_plan p, const double* params, int Ntotal, c
   hipLaunchKernelGGL(sgpr_B_kernel, dim3(64), dim3(256), 0, h->stream, p->H, p->LB, M, params);
   if (p->chol_blocked) GP_CHECK(chol_inverse_blocked_run(h, M, M, p->chol_ws_b, p->chol_ws_bytes));
   else GP_CHECK(launch_cholesky_inverse_single(h, p->LB, p->WB, M, M));
-  hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->WB, p->LB, p->u, p->c, M, Ntotal, params,
+  hipLaunchKernelGGL(sgpr_c_kernel, dim3((M + 3) / 4), dim3(256), 0, h->stream, p->WB, p->u, p->c, M, params);
+  hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->LB, p->c, M, Ntotal, params,
                      p->P, desc->toff, desc->ktype, desc->km, p->reg, p->scal);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
@@ -500,9 +530,24 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
   { GemmProblem& r = sq(Q_P); r.A = p->L; r.B = p->T1; r.C = p->T2; }
   { GemmProblem& r = sq(Q_T3); r.A = p->W; r.B = p->T2; r.C = p->H; }     // H is free once E2 H and the noise terms are done
   { GemmProblem& r = sq(Q_S); r.A = p->H; r.B = p->W; r.C = p->E2; }
+  // The gradient's tail — per kernel of the sum a Kuu-side contraction and two finish launches, 15 launches of a few
+  // workgroups for five kernels — as ONE contraction launch over an item array and ONE finish launch (bwd.hip's item forms,
+  // as the Pdgp plan uses them) when the kernels share type and partial count and the Kuf side went through the fused pass.
+  bool tail_items = include_replicated && p->P >= 1 && (size_t)p->P <= SG_TAIL_MAX && sizeof(HyperItem) * SG_TAIL_MAX <= 4096 &&
+                    sizeof(HyperFinishItem) * SG_TAIL_MAX <= SG_DESC_BYTES - SG_FIN_OFF;
+  for (int i = 1; i < p->P; i++) if (p->ktype[i] != p->ktype[0] || p->m[i] != p->m[0]) tail_items = false;
+  std::vector<HyperItem> uu_items(tail_items ? p->P : 0);
+  for (int i = 0; i < (int)uu_items.size(); i++) {
+    HyperItem& iu = uu_items[i];
+    memset(&iu, 0, sizeof(iu));
+    iu.k = sg_kern(p, params, i); iu.x1 = Z; iu.n1 = M; iu.x2 = Z; iu.n2 = M; iu.G = p->E2; iu.ldg = M; iu.symmetric = 1;
+    iu.partials = p->hyp_uu + (size_t)i * p->hyp_uu_stride;
+    if (gp_kern_is_mercer(p->ktype[i])) { iu.f1 = p->feat + (size_t)i * sgpr_feat_stride(p); iu.f2 = iu.f1; }
+  }
   SgDesc d2;
-  GP_CHECK(sg_upload(p, pr, &d2, 1));
+  GP_CHECK(sg_upload(p, pr, &d2, 1, uu_items.data(), uu_items.size() * sizeof(HyperItem)));
   GemmProblem* D = d2.probs;
+  char* const d_block1 = (char*)d2.probs;
   GemmFlags f;
   // Binv = WB^T WB ; ubar = WB^T c (= Binv u / s)
   f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
@@ -561,6 +606,25 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
                                       &np_fused, &st);
     if (fused) GP_CHECK(st);
   }
+  if (fused && tail_items) {
+    int np_uu = 0;
+    GP_CHECK(launch_hyper_contract_items(h, p->ktype[0], p->m[0], (const HyperItem*)(d_block1 + SG_EXTRA_OFF), p->P, M, M, 0, &np_uu));
+    std::vector<HyperFinishItem> fin(p->P);
+    for (int i = 0; i < p->P; i++) {
+      HyperFinishItem& it = fin[i];
+      memset(&it, 0, sizeof(it));
+      it.k = sg_kern(p, params, i); it.p_uf = p->hyp + (size_t)i * p->hyp_stride; it.np_uf = np_fused;
+      it.p_uu = p->hyp_uu + (size_t)i * p->hyp_uu_stride; it.np_uu = np_uu; it.gv_sum = p->scal + 4;
+      it.g_theta = grad + p->off_theta[i]; it.n1 = M;
+    }
+    const size_t bytes = fin.size() * sizeof(HyperFinishItem);
+    if (p->h_tail_fin.size() != bytes || memcmp(p->h_tail_fin.data(), fin.data(), bytes) != 0) {
+      if (p->skip_upload) return gp_fail(h, GP_ERR_UNSUPPORTED, "sgpr: finish items changed under a recorded launch sequence");
+      p->h_tail_fin.assign((const char*)fin.data(), (const char*)fin.data() + bytes);
+      GP_HIP_CHECK(h, hipMemcpyAsync(d_block1 + SG_FIN_OFF, p->h_tail_fin.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    GP_CHECK(launch_hyper_finish_items(h, (const HyperFinishItem*)(d_block1 + SG_FIN_OFF), p->P, 2 + 2 * p->m[0]));
+  } else
   for (int i = 0; i < p->P; i++) {
     DevKern k = sg_kern(p, params, i);
     double* feat = p->feat + (size_t)i * sgpr_feat_stride(p);   // this kernel's (Z | X) features, from the forward pass

@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--P", type=int, default=5)
     ap.add_argument("--m", type=int, default=3)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", choices=("f64", "f32"), default=None)
     args = ap.parse_args()
     import torch
     from gpitch_amd import _lib
@@ -26,6 +27,8 @@ def main():
     Z = X[:: args.N // args.M][:args.M].copy()
     h = _lib.default_handle()
     for ft in (np.float64, np.float32):
+        if args.only and ft.__name__ != "float" + args.only[1:]:
+            continue
         ks = [MercerMatern12sm(1, energy=np.full(args.m, 1.0 / args.m), frequency=110.0 * (p + 1) * np.arange(1, args.m + 1),
                                variance=1.0, lengthscales=0.05 + 0.01 * p) for p in range(args.P)]
         model = SGPRSS(X, Y, Add(ks), Z, handle=h, float_type=ft)
