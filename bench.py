@@ -30,7 +30,7 @@ def build_model(args, rank):
     import gpitch_amd
     from gpitch_amd.pdgp import Pdgp
     from gpitch_amd.synth import make_problem, pdgp_from_problem
-    ft = np.float32 if args.float_type == "f32" else np.float64
+    ft = {"f32": np.float32, "mixed": (np.float64, np.float32)}.get(args.float_type, np.float64)
     if args.shard in ("pitch", "gp"):
         # ONE model over all ranks: same problem everywhere; rank r holds pitches p = r (mod world) ("pitch": both GPs of a
         # pitch, all-reduce of 3N+1) or latent GPs g = r (mod world) ("gp": all-gather of (fmean, fvar) per GP)
@@ -355,9 +355,10 @@ def main():
     ap.add_argument("--overlap", type=int, choices=[0, 1, 2], default=2,
                     help="gp_pdgp_set_overlap level: 0 one stream (clean single-kernel timings), 1 Kuu-side work on the "
                          "helper stream, 2 (library default) also H = A D A^T next to Kuf_bar")
-    ap.add_argument("--float-type", choices=["f64", "f32"], default="f64",
+    ap.add_argument("--float-type", choices=["f64", "f32", "mixed"], default="f64",
                     help="f64 (the headline: the reference's float_type = float64); f32: the M x N strips and the four "
-                         "strip products in float32 (BASELINE configs 3 and 5 are quoted at fp32; tolerance in tests/test_gpu_f32.py)")
+                         "strip products in float32 (BASELINE configs 3 and 5 are quoted at fp32; tolerance in tests/test_gpu_f32.py); "
+                         "mixed: activation GPs float64, component GPs float32")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the extra cfg3 (M=256, fp32) measurement")
     ap.add_argument("--no-sgpr-lines", action="store_true",
                     help="skip the extra cfg5 (sgpr_ss N=65536, M=512, 5 sources) and window-loop measurements")
@@ -490,8 +491,10 @@ def main():
         model = res = None
         torch.cuda.empty_cache()
         cfg3 = {"workload": "pdgp ELBO step, N=32768 x M=256 x P=12, m=5 partials (BASELINE configs[2])",
-                "tolerance": "ELBO within 2e-4 relative of the float64 oracle (tests/test_gpu_f32.py: 4.7e-5 measured)"}
-        for ft in ("f32", "f64"):
+                "tolerance": "ELBO within 2e-4 relative of the float64 oracle (tests/test_gpu_f32.py: 4.7e-5 measured); "
+                             "'mixed' = activation GPs float64, component GPs float32 (gp_pdgp_set_gp_precision): ELBO within 1e-7, "
+                             "activation posterior means 2e-7, activation-side gradients 2e-6 (test_mixed_precision_*)"}
+        for ft in ("f32", "mixed", "f64"):
             a3 = argparse.Namespace(**vars(args))
             a3.M, a3.partials, a3.float_type = 256, 5, ft
             r3 = run_timed(a3, "window", rank, None)

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "gp_kernel_build", "gp_kernel_build_f32", "gp_kernel_diag", "gp_chol_workspace_bytes", "gp_kuu_cholesky", "gp_cholesky_inplace",
     "gp_conditional_workspace_bytes", "gp_conditional_diag", "gp_conditional_diag_f32", "gp_conditional_diag_f32w", "gp_conditional_full_workspace_bytes", "gp_conditional_full", "gp_gauss_kl_workspace_bytes", "gp_gauss_kl", "gp_gauss_kl_matrix", "gp_mpd_varexp",
     "gp_pdgp_create", "gp_pdgp_destroy", "gp_pdgp_num_params", "gp_pdgp_layout", "gp_pdgp_workspace_bytes",
-    "gp_pdgp_set_workspace", "gp_pdgp_set_precision", "gp_pdgp_set_grad_needs", "gp_pdgp_set_overlap", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_create_subset", "gp_pdgp_cond_begin", "gp_pdgp_cond_end", "gp_pdgp_predict", "gp_pdgp_predict_reuse",
+    "gp_pdgp_set_workspace", "gp_pdgp_set_precision", "gp_pdgp_set_gp_precision", "gp_pdgp_set_grad_needs", "gp_pdgp_set_overlap", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_create_subset", "gp_pdgp_cond_begin", "gp_pdgp_cond_end", "gp_pdgp_predict", "gp_pdgp_predict_reuse",
     "gp_overlap_merge", "gp_transform_register_logistic", "gp_transform_forward", "gp_transform_backward", "gp_poll_not_pd", "gp_check_not_pd", "gp_take_not_pd", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace", "gp_sgpr_set_precision",
     "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_exchange_doubles", "gp_sgpr_bound_begin", "gp_sgpr_bound_end", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_f_full", "gp_sgpr_predict_source_full", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
@@ -130,6 +130,7 @@ def load_library():
         "gp_pdgp_workspace_bytes": (sz, [vp]),
         "gp_pdgp_set_workspace": (i32, [vp, vp, sz]),
         "gp_pdgp_set_precision": (i32, [vp, i32]),
+        "gp_pdgp_set_gp_precision": (i32, [vp, vp, i32]),
         "gp_pdgp_set_grad_needs": (i32, [vp, i32, i32, i32]),
         "gp_pdgp_set_overlap": (i32, [vp, i32]),
         "gp_pdgp_elbo": (i32, [vp, vp, vp, vp, i32, dbl, vp, C.POINTER(dbl), vp]),

@@ -1422,7 +1422,6 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
   p->off_fin_items = p->off_kl2 + pdgp_kl_region_bytes(G);
   p->h_fin_items.clear();       // the descriptor block is rewritten: force a fresh upload of the finish items
   const bool white = p->whiten != 0;
-  const int64_t ldN = gp_strip_ld(n, p->f32 != 0);
   size_t slab_off = 0;
   p->kgps.clear();
   for (int g = 0; g < G; g++)
@@ -1434,6 +1433,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     const CondTask& t = p->cb.tasks[g];
     const BwdBufs& b = p->bw[g];
     const int M = q.M;
+    const int64_t ldN = gp_strip_ld(n, q.f32 != 0);     // this GP's strips: float64 or float32 (per-GP precision)
     // unwhitened model: the chain runs on the equivalent whitened state q' = (W q_mu, W Lq) and its gradient
     // buffers; pdgp_backward maps the result back (see there)
     const double* q_mu = white ? params + q.off_qmu : b.qmu_w;
@@ -1457,7 +1457,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
       r.o2 = p->slabs + slab_off; slab_off += gp_align_up((size_t)p->nsplit * M * M * sizeof(double), 256) / sizeof(double);
       // fused u = A gm: partials per K-slice in o1, result in o0 and accumulated into grad q_mu (xa)
       r.v2 = gm; r.o1 = b.upart; r.o0 = b.u; r.xa = g_mu; }
-    { GemmProblem& r = P(S_U); r.A = t.A; r.lda = ldN; r.N = n; r.v0 = gm; r.o0 = b.u; r.o1 = g_mu; }
+    { GemmProblem& r = P(S_U); r.A = t.A; r.lda = ldN; r.N = n; r.v0 = gm; r.o0 = b.u; r.o1 = g_mu; r.a_f32 = q.f32; }
     { GemmProblem& r = P(S_HLQ); r.A = b.H; r.B = q_sqrt; r.C = g_sqrt; }
     if (!white) {
       const double* qm = params + q.off_qmu;
@@ -1497,8 +1497,8 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     const int key_m = gp_kern_has_partials(q.ktype) ? q.m : 0;
     int fi = -1;
     for (size_t f = 0; f < p->hy_fams.size(); f++)
-      if (p->hy_fams[f].type == q.ktype && p->hy_fams[f].m == key_m) fi = (int)f;
-    if (fi < 0) { gp_pdgp_plan_s::HyFamily nf; nf.type = q.ktype; nf.m = key_m; nf.M = q.M; nf.batched = true; p->hy_fams.push_back(nf); fi = (int)p->hy_fams.size() - 1; }
+      if (p->hy_fams[f].type == q.ktype && p->hy_fams[f].m == key_m && p->hy_fams[f].f32 == q.f32) fi = (int)f;
+    if (fi < 0) { gp_pdgp_plan_s::HyFamily nf; nf.type = q.ktype; nf.m = key_m; nf.M = q.M; nf.f32 = q.f32; nf.batched = true; p->hy_fams.push_back(nf); fi = (int)p->hy_fams.size() - 1; }
     gp_pdgp_plan_s::HyFamily& fam = p->hy_fams[fi];
     fam.gps.push_back(g);
     if (q.M != fam.M || q.need_z || !q.need_theta) fam.batched = false;   // the per-GP path handles those
@@ -1515,9 +1515,10 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
         const BwdBufs& bb = p->bw[g];
         HyperItem& it = items[pos++];
         memset(&it, 0, sizeof(it));
+        const int64_t ldN = gp_strip_ld(n, q.f32 != 0);
         it.k = t.kern; it.x1 = params + q.off_z; it.n1 = q.M; it.x2 = nullptr; it.n2 = n; it.G = bb.G; it.ldg = ldN;
         it.alpha = bb.alpha; it.gm = p->gFmu + (size_t)g * n; it.symmetric = 0; it.partials = bb.hyp_part; it.gz = nullptr;
-        it.kvals = t.Kuf; it.ldk = ldN; it.g32 = p->f32;
+        it.kvals = t.Kuf; it.ldk = ldN; it.g32 = q.f32;
         if (gp_kern_is_mercer(q.ktype) && t.feat) {
           it.f1 = t.feat;
           it.f2 = t.feat + gp_align_up((size_t)2 * sm_mpad(q.m) * q.M, 32);
@@ -1572,8 +1573,7 @@ gp_status pdgp_prefetch_backward(gp_pdgp_plan p, int n, bool* kl_done) {
 gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, int n, double* grad) {
   gp_handle h = p->h;
   const int G = p->G, maxM = p->maxM;
-  const int64_t ldN = gp_strip_ld(n, p->f32 != 0);
-  const int f32 = p->f32;
+  const int n64 = p->n64;     // latent GPs [0, n64): float64 strips, [n64, G): float32 strips
   auto D = [&](int slot) { return (const GemmProblem*)(p->d_misc + p->off_bwd[slot]); };
   GemmFlags f;
   const bool white = p->whiten != 0;
@@ -1615,8 +1615,8 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     {
       int uni = ((n & 3) == 0) ? 1 : 0;
       for (int g = 0; g < G; g++) if (p->gps[g].M != maxM) uni = 0;
-      if (f32) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0, uni));
-      else GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), G, maxM, n, p->nsplit, 1, 1, 2.0, uni));
+      if (n64 > 0) GP_CHECK(launch_gemm_nt_reduce_batched(h, D(S_H), n64, maxM, n, p->nsplit, 1, 1, 2.0, uni));
+      if (n64 < G) GP_CHECK(launch_gemm_f32_nt_reduce_batched(h, D(S_H) + n64, G - n64, maxM, n, p->nsplit, 1, 1, 2.0, uni));
     }
     // grad q_sqrt += tril(H Lq)
     f = GemmFlags(); f.triB = TRI_LOWER; f.triC = TRI_LOWER; f.beta = 1.0;
@@ -1728,12 +1728,17 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     };
     int kuf_uniform = ((n & 1) == 0) ? 1 : 0;        // every GP of the compacted batch M = maxM (R, A, G: arena buffers, even ld)
     for (int g : p->kgps) if (p->gps[g].M != maxM) kuf_uniform = 0;
+    // (slots of the compacted batch keep the GPs' order: its float64 GPs come first, k64 of them)
+    int k64 = 0;
+    for (int g : p->kgps) if (!p->gps[g].f32) k64++;
     auto kuf_bar = [&](int slot0, int count) -> gp_status {
       GemmFlags f;
       f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
       f.uniform_aligned = kuf_uniform;
-      if (f32) return launch_gemm_f32_role(h, D(S_G) + slot0, count, maxM, n, f);
-      return launch_gemm_batched(h, D(S_G) + slot0, count, maxM, n, f);
+      const int c64 = (slot0 < k64) ? ((slot0 + count <= k64) ? count : k64 - slot0) : 0;
+      if (c64 > 0) GP_CHECK(launch_gemm_batched(h, D(S_G) + slot0, c64, maxM, n, f));
+      if (c64 < count) GP_CHECK(launch_gemm_f32_role(h, D(S_G) + slot0 + c64, count - c64, maxM, n, f));
+      return GP_OK;
     };
     auto kuf_contract = [&](int g) -> gp_status {      // one GP (inducing-input gradients, mixed sizes)
       const PdgpGP& q = p->gps[g];
@@ -1742,14 +1747,15 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       const double* z = params + q.off_z;
       const double* gm = p->gFmu + (size_t)g * n;
       double* gz_uf = q.need_z ? bb.gz_part : nullptr;
+      const int64_t ldN = gp_strip_ld(n, q.f32 != 0);
       return launch_hyper_contract(h, t.kern, z, q.M, x, n, bb.G, ldN, bb.alpha, gm, 0, t.feat, bb.hyp_part, &np_uf[g], gz_uf,
-                                   t.Kuf, ldN, f32);
+                                   t.Kuf, ldN, q.f32);
     };
     auto contract_family = [&](const gp_pdgp_plan_s::HyFamily& fam) -> gp_status {
       if (!fam.batched) { for (int g : fam.gps) GP_CHECK(kuf_contract(g)); return GP_OK; }
       int np = 0;
       GP_CHECK(launch_hyper_contract_items(h, fam.type, fam.m, (const HyperItem*)(p->d_misc + p->off_hy_items) + fam.first,
-                                           fam.count, fam.M, n, 0, &np, fam.mfma, x, f32, 1));
+                                           fam.count, fam.M, n, 0, &np, fam.mfma, x, fam.f32, 1));
       for (int g : fam.gps) np_uf[g] = np;
       return GP_OK;
     };

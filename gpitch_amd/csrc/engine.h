@@ -79,6 +79,7 @@ struct CondTask {
   double* feat_uu = nullptr; // the same for the Kuu build (2m x M), separate because the two builds overlap
   double* s1 = nullptr; double* s2 = nullptr; double* dot = nullptr;  // [rowblocks][N] partials
   double* fmean = nullptr; double* fvar = nullptr;                    // N each
+  bool f32 = false;       // this GP's M x N strips (Kuf, A, A2) are float32 (per-GP precision: CondBatch::n64)
 };
 
 struct CondBatch {
@@ -92,9 +93,12 @@ struct CondBatch {
   size_t off_chol_ptrs = 0, off_w_ptrs = 0, off_Ms = 0, off_lds = 0, off_f1 = 0, off_f1u = 0, off_f2 = 0, off_finish = 0;
   bool uploaded = false;
   bool overlap = true;    // run the Kuu factorisation on the handle's helper stream next to the Kuf builds
-  bool f32 = false;       // the M x N strips (Kuf, A) are float32 and the strip products run on the float32 matrix path
+  bool f32 = false;       // every task's M x N strips (Kuf, A) are float32 and the strip products run on the float32 matrix path
+  // per-GP precision: tasks [0, n64) keep float64 strips, tasks [n64, G) have float32 ones (CondTask::f32); -1 = uniform
+  // (all float64 or, with f32 set, all float32).  cond_batch_upload checks the order and sets it.
+  int n64 = -1;
   // grouped covariance builds (one launch per kernel family)
-  struct Group { int type = 0, m = 0, first = 0, maxM = 0; std::vector<int> members; };
+  struct Group { int type = 0, m = 0, first = 0, maxM = 0; bool f32 = false; std::vector<int> members; };
   std::vector<Group> groups;
   size_t off_cov_uu = 0, off_cov_uf = 0, off_feat_zuu = 0, off_feat_zuf = 0, off_feat_x = 0;
   // blocked Kuu factorisation (engine.hip: cond_batch_factorize)

@@ -62,7 +62,13 @@ size_t cond_batch_desc_bytes(int count) {
 gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitter) {
   const int G = (int)cb.tasks.size();
   const int N = cb.N;
-  const int64_t ldN = gp_strip_ld(N, cb.f32);
+  // strip precision per task: a uniform batch (cb.f32) or float64 tasks first, float32 tasks behind them
+  cb.n64 = 0;
+  for (int g = 0; g < G; g++) {
+    CondTask& t = cb.tasks[g];
+    if (cb.f32) t.f32 = true;
+    if (!t.f32) { if (cb.n64 != g) return gp_fail(h, GP_ERR_UNSUPPORTED, "per-GP precision: float64 latent GPs must precede float32 ones"); cb.n64 = g + 1; }
+  }
   size_t need = cond_batch_desc_bytes(G);
   if (cb.desc_bytes < need || !cb.d_desc) return gp_fail(h, GP_ERR_WORKSPACE, "descriptor workspace too small");
   cb.h_desc.assign(need, 0);
@@ -87,6 +93,7 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   cb.maxM = 0;
   for (int g = 0; g < G; g++) {
     const CondTask& t = cb.tasks[g];
+    const int64_t ldN = gp_strip_ld(N, t.f32);
     if (t.M > cb.maxM) cb.maxM = t.M;
     cp[g] = t.L; wp[g] = t.W; Ms[g] = t.M; lds[g] = t.M;
     GemmProblem p;
@@ -120,8 +127,8 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
       const int key_m = gp_kern_has_partials(t.kern.type) ? t.kern.m : 0;
       int gi = -1;
       for (size_t q = 0; q < cb.groups.size(); q++)
-        if (cb.groups[q].type == t.kern.type && cb.groups[q].m == key_m) gi = (int)q;
-      if (gi < 0) { CondBatch::Group ng; ng.type = t.kern.type; ng.m = key_m; cb.groups.push_back(ng); gi = (int)cb.groups.size() - 1; }
+        if (cb.groups[q].type == t.kern.type && cb.groups[q].m == key_m && cb.groups[q].f32 == t.f32) gi = (int)q;
+      if (gi < 0) { CondBatch::Group ng; ng.type = t.kern.type; ng.m = key_m; ng.f32 = t.f32; cb.groups.push_back(ng); gi = (int)cb.groups.size() - 1; }
       cb.groups[gi].members.push_back(g);
     }
     cb.off_cov_uu = region(G * sizeof(CovItem));
@@ -141,7 +148,7 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
         const CondTask& t = cb.tasks[g];
         if (t.M > gr.maxM) gr.maxM = t.M;
         cov_item_fill(&uu[pos], t.kern, t.z, t.M, nullptr, t.M, t.L, t.M, 0, jitter, t.feat_uu);
-        cov_item_fill(&uf[pos], t.kern, t.z, t.M, nullptr, -1, t.Kuf, ldN, 0, 0.0, t.feat, cb.f32 ? 1 : 0);
+        cov_item_fill(&uf[pos], t.kern, t.z, t.M, nullptr, -1, t.Kuf, gp_strip_ld(N, t.f32), 0, 0.0, t.feat, t.f32 ? 1 : 0);
         fzuu[pos] = FeatItem{t.kern, t.z, t.feat_uu, t.M, 0};
         fzuf[pos] = FeatItem{t.kern, t.z, t.feat, t.M, 0};
         const int mp = sm_mpad(t.kern.m);
@@ -338,8 +345,17 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
         GP_CHECK(launch_sm_features_items(h, (const FeatItem*)(cb.d_desc + cb.off_feat_x) + gr.first, cnt, N, mp, x, N));
       }
       GP_CHECK(launch_kernel_build_items(h, gr.type, gr.m, (const CovItem*)(cb.d_desc + cb.off_cov_uf) + gr.first, cnt,
-                                         gr.maxM, N, x, N, cb.f32 ? 2 : 1));     // 2: the strips are float32
+                                         gr.maxM, N, x, N, gr.f32 ? 2 : 1));     // 2: the strips are float32
     }
+    return GP_OK;
+  };
+  // a strip product over the batch: the float64 tasks [0, n64) on the float64 kernels, the float32 tasks behind them on the
+  // float32 ones (f32flags: the flags of the float32 launch where they differ)
+  auto strips = [&](size_t off, const GemmFlags& f, const GemmFlags* f32flags = nullptr) -> gp_status {
+    const GemmProblem* d = (const GemmProblem*)(cb.d_desc + off);
+    const int n64 = (cb.n64 < 0) ? (cb.f32 ? 0 : G) : cb.n64;
+    if (n64 > 0) GP_CHECK(launch_gemm_batched(h, d, n64, cb.maxM, N, f));
+    if (n64 < G) GP_CHECK(launch_gemm_f32_role(h, d + n64, G - n64, cb.maxM, N, f32flags ? *f32flags : f));
     return GP_OK;
   };
   gp_status st = GP_OK;
@@ -372,8 +388,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     auto cond_a = [&](int m0, int mcount) -> gp_status {
       GemmFlags g = f;
       g.tile_m0 = m0; g.tile_mcount = mcount;
-      if (cb.f32) return launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, g);
-      return launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1), G, cb.maxM, N, g);
+      return strips(cb.off_f1, g);
     };
     if (early) {
       gp_status s1 = cond_a(0, 1);
@@ -390,8 +405,8 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A;
     f.epilogue = EPI_STORE | EPI_COLDOT;
     // float32 strips: the same product shape as Lq^T A (op(A) = W^T upper, read row-wise), stored: role 2 of gemm_f32.hip
-    if (cb.f32) { f.role = 2; f.timer = GP_TIMER_COND_A; GP_CHECK(launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f1u), G, cb.maxM, N, f)); }
-    else GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f1u), G, cb.maxM, N, f));
+    GemmFlags f3 = f; f3.role = 2;
+    GP_CHECK(strips(cb.off_f1u, f, &f3));
   }
   // 5. LTA = tril(q_sqrt)^T A  (only its column sums of squares are needed)
   bool any_qsqrt = false;
@@ -403,8 +418,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_LTA; f.role = 2;
     f.epilogue = EPI_COLSUMSQ;
     f.uniform_aligned = whiten ? cond_batch_uniform(cb, N) : 0;
-    if (cb.f32) GP_CHECK(launch_gemm_f32_role(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
-    else GP_CHECK(launch_gemm_batched(h, (const GemmProblem*)(cb.d_desc + cb.off_f2), G, cb.maxM, N, f));
+    GP_CHECK(strips(cb.off_f2, f));
   }
   // 6. fmean / fvar
   GP_CHECK(launch_cond_finish(h, cb.d_desc + cb.off_finish, G, N));

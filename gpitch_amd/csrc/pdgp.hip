@@ -11,7 +11,7 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
   for (int g = 0; g < p->G; g++) {
     const size_t M = p->gps[g].M;
     for (int i = 0; i < 6; i++) add(M * M);
-    add(gp_strip_doubles(M, p->maxN, p->f32 != 0));
+    add(gp_strip_doubles(M, p->maxN, p->gps[g].f32 != 0));
     add(M); add(M); add(M); add((size_t)65 * M);
     const size_t ns = hyper_num_sums(p->gps[g].m);
     const size_t colblocks = (p->maxN + 255) / 256 + 1;
@@ -48,6 +48,7 @@ static gp_status pdgp_create_impl(gp_handle h, const gp_pdgp_config* cfg, const 
   p->subset = gp_index != nullptr;
   if (gp_index) p->grow.assign(gp_index, gp_index + count);
   p->gps.resize(p->G);
+  p->n64 = p->G;
   int64_t off = 1;  // [0] = noise variance
   for (int l = 0; l < p->G; l++) {
     PdgpGP& q = p->gps[l];
@@ -107,6 +108,25 @@ gp_status gp_pdgp_set_precision(gp_pdgp_plan p, int32_t bits) {
   if (p->ws) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_pdgp_set_precision: call it before gp_pdgp_set_workspace");
   p->f32 = (bits == 32);
   p->cb.f32 = (bits == 32);
+  for (auto& q : p->gps) q.f32 = p->f32;
+  p->n64 = p->f32 ? 0 : p->G;
+  return GP_OK;
+}
+// Per-GP strip precision: bits[g] in {32, 64} for the plan's latent GPs in engine order [g_0..g_{P-1}, f_0..f_{P-1}] (a subset
+// plan: its own rows, same order); float64 GPs must precede float32 ones — the transcription model's use is "activation
+// GPs (Matern-3/2 on a 16-kHz grid: cond(Kuu) ~ 1e9) float64, component GPs float32".
+gp_status gp_pdgp_set_gp_precision(gp_pdgp_plan p, const int32_t* bits, int32_t count) {
+  if (!p || !bits || count != p->G) return GP_ERR_BAD_ARG;
+  if (p->ws) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_pdgp_set_gp_precision: call it before gp_pdgp_set_workspace");
+  int n64 = 0;
+  for (int g = 0; g < count; g++) {
+    if (bits[g] != 32 && bits[g] != 64) return gp_fail(p->h, GP_ERR_BAD_ARG, "gp_pdgp_set_gp_precision: bits must be 32 or 64");
+    if (bits[g] == 64) { if (n64 != g) return gp_fail(p->h, GP_ERR_UNSUPPORTED, "gp_pdgp_set_gp_precision: float64 latent GPs must precede float32 ones"); n64 = g + 1; }
+  }
+  for (int g = 0; g < count; g++) p->gps[g].f32 = (bits[g] == 32);
+  p->n64 = n64;
+  p->f32 = (n64 == 0);
+  p->cb.f32 = (n64 == 0);
   return GP_OK;
 }
 gp_status gp_pdgp_set_overlap(gp_pdgp_plan p, int32_t level) {
@@ -135,7 +155,7 @@ static size_t pdgp_misc_bytes(const gp_pdgp_plan_s* p) {
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p) {
   if (!p) return 0;
   size_t d = 0;
-  for (int g = 0; g < p->G; g++) d += cond_task_workspace_doubles(p->gps[g].M, p->maxN, p->gps[g].m, p->whiten != 0, p->f32 != 0);
+  for (int g = 0; g < p->G; g++) d += cond_task_workspace_doubles(p->gps[g].M, p->maxN, p->gps[g].m, p->whiten != 0, p->gps[g].f32 != 0);
   auto addd = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   for (int i = 0; i < 4; i++) addd((size_t)p->G * p->maxN);
   if (p->subset) for (int i = 0; i < 2; i++) addd((size_t)2 * p->P * p->maxN);
@@ -179,7 +199,8 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
     CondTask& t = p->cb.tasks[g];
     t.M = p->gps[g].M;
     t.kern = DevKern{p->gps[g].ktype, p->gps[g].m, nullptr};
-    if (!cond_task_carve(ar, t, p->maxN, p->whiten != 0, p->f32 != 0)) return gp_fail(p->h, GP_ERR_WORKSPACE, "workspace carve failed");
+    t.f32 = p->gps[g].f32 != 0;
+    if (!cond_task_carve(ar, t, p->maxN, p->whiten != 0, t.f32)) return gp_fail(p->h, GP_ERR_WORKSPACE, "workspace carve failed");
   }
   p->bw.assign(p->G, BwdBufs());
   p->tr_part.assign(p->G, nullptr);
@@ -193,7 +214,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       BwdBufs& b = p->bw[g];
       b.H = ar.take<double>(M * M); b.E = ar.take<double>(M * M); b.T1 = ar.take<double>(M * M);
       b.T2 = ar.take<double>(M * M); b.Wbar = ar.take<double>(M * M); b.R = ar.take<double>(M * M);
-      b.G = ar.take<double>(gp_strip_doubles(M, p->maxN, p->f32 != 0));
+      b.G = ar.take<double>(gp_strip_doubles(M, p->maxN, p->gps[g].f32 != 0));
       b.u = ar.take<double>(M); b.Lu = ar.take<double>(M); b.alpha = ar.take<double>(M);
       b.upart = ar.take<double>((size_t)p->nsplit * M);
       const size_t ns = hyper_num_sums(p->gps[g].m);

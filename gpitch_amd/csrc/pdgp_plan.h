@@ -15,6 +15,7 @@ static inline size_t pdgp_kltr_offset(int G) {
 struct PdgpGP {
   int M = 0, ktype = 0, m = 0;
   int need_theta = 1, need_z = 1;   // gp_pdgp_set_grad_needs
+  int f32 = 0;                      // this GP's M x N strips are float32 (gp_pdgp_set_precision / gp_pdgp_set_gp_precision)
   int64_t off_theta = 0, off_z = 0, off_qmu = 0, off_qsqrt = 0;
 };
 
@@ -42,7 +43,9 @@ struct BwdBufs {  // per-GP backward workspace (device)
 struct gp_pdgp_plan_s {
   gp_handle h = nullptr;
   int P = 0, G = 0, whiten = 1, nlin = 0, maxN = 0;
-  int f32 = 0;               // gp_pdgp_set_precision: the M x N strips (Kuf, A, Kuf_bar) are float32 (gemm_f32.hip)
+  int f32 = 0;               // gp_pdgp_set_precision: the M x N strips (Kuf, A, Kuf_bar) of EVERY latent GP are float32 (gemm_f32.hip)
+  int n64 = 0;               // latent GPs [0, n64) keep float64 strips, [n64, G) have float32 ones (PdgpGP::f32): G, 0, or —
+                             // gp_pdgp_set_gp_precision — in between (activation GPs float64, component GPs float32)
   double jitter = 1e-6;
   std::vector<PdgpGP> gps;
   int64_t nparams = 0;
@@ -65,7 +68,7 @@ struct gp_pdgp_plan_s {
   // Kuf-side and Kuu-side contractions grouped by kernel family: one launch per family and side over an item array
   // (bwd.hip; G Kuf-side items, then G Kuu-side items, same order)
   size_t off_hy_items = 0;
-  struct HyFamily { int type = 0, m = 0, first = 0, count = 0, M = 0, mfma = 0; bool batched = false; std::vector<int> gps; };
+  struct HyFamily { int type = 0, m = 0, first = 0, count = 0, M = 0, mfma = 0, f32 = 0; bool batched = false; std::vector<int> gps; };
   std::vector<HyFamily> hy_fams;
   size_t off_kl2 = 0;         // unwhitened backward: KL items of the equivalent whitened state
   double* qw_block = nullptr; size_t qw_doubles = 0;   // [q' | grad q'] of all GPs, contiguous (one memset)

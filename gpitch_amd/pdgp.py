@@ -71,8 +71,19 @@ class Pdgp(Parameterized):
         With float32 the M x N strips (Kuf, Lm^-1 Kuf, Kuf_bar) and the four O(M^2 N) products are float32 on the
         float32 matrix cores; parameters, Kuu, its Cholesky factor, all reductions, the likelihood and the
         gradients stay float64 (include/gpitch_abi.h: gp_pdgp_set_precision); `whiten` and `float_type` are independent, as in
-        the reference (pdgp.py:13,49,122-129)."""
-        self._bits = _lib.precision_bits(float_type)
+        the reference (pdgp.py:13,49,122-129).
+        A pair `(float_type_act, float_type_com)` sets the strips' precision per group of latent GPs — activation GPs,
+        component GPs — and `(np.float64, np.float32)` is the useful one: the activation GPs (Matern-3/2 on a 16-kHz
+        grid, cond(Kuu) ~ 1e9) keep float64 strips, the component GPs run in float32 (gp_pdgp_set_gp_precision; float64
+        latent GPs must precede float32 ones in the engine's order, so (float32, float64) is refused)."""
+        if isinstance(float_type, (tuple, list)):
+            if len(float_type) != 2:
+                raise ValueError("float_type: one type or a pair (activation GPs, component GPs)")
+            self._bits = tuple(_lib.precision_bits(f) for f in float_type)
+            if self._bits[0] == self._bits[1]:
+                self._bits = self._bits[0]
+        else:
+            self._bits = _lib.precision_bits(float_type)
         x = np.asarray(x, dtype=np.float64).reshape(-1, 1)
         y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
         if minibatch_size is None:
@@ -175,6 +186,10 @@ class Pdgp(Parameterized):
         self._plan = plan
         if self._bits == 32:
             h.check(h.lib.gp_pdgp_set_precision(plan, 32))
+        elif isinstance(self._bits, tuple):
+            rows = list(range(2 * P)) if self._gp_shard is None else list(self._gp_shard)
+            bits = [self._bits[0] if r < P else self._bits[1] for r in rows]
+            h.check(h.lib.gp_pdgp_set_gp_precision(plan, (C.c_int32 * len(bits))(*bits), len(bits)))
         n = self._nparams = int(h.lib.gp_pdgp_num_params(plan))
         self._layout = []
         for g in range(2 * P if self._gp_shard is None else len(self._gp_shard)):

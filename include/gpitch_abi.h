@@ -194,6 +194,13 @@ gp_status gp_pdgp_layout(gp_pdgp_plan p, int32_t g, int64_t* off_theta, int64_t*
  * float64, so the ABI's buffers do not change type.  Whitened models only.  Call before gp_pdgp_workspace_bytes /
  * gp_pdgp_set_workspace (the workspace is smaller).  Tolerance held against the float64 oracle: tests/test_gpu_f32.py. */
 gp_status gp_pdgp_set_precision(gp_pdgp_plan p, int32_t bits);
+/* The same per latent GP: bits[g] in {32, 64} for the plan's `count` latent GPs in engine order ([g_0..g_{P-1}, f_0..f_{P-1}],
+ * a subset plan: its own rows in that order).  The reference's float_type is one global setting (pdgp.py:13); this is the
+ * finer form the transcription model wants: its activation GPs (Matern-3/2 over a 16-kHz grid, cond(Kuu) ~ 1e9) are where
+ * float32 strips cost accuracy (posterior mean 5e-2, lengthscale gradient 2e-1 of their scale), its component GPs are not,
+ * so bits = [64 x P, 32 x P] keeps the float64 tolerances on the former and the float32 speed on the latter.  Float64
+ * latent GPs must precede float32 ones (GP_ERR_UNSUPPORTED otherwise).  Call before gp_pdgp_workspace_bytes. */
+gp_status gp_pdgp_set_gp_precision(gp_pdgp_plan p, const int32_t* bits, int32_t count);
 size_t gp_pdgp_workspace_bytes(gp_pdgp_plan p);
 gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes);
 
