@@ -370,8 +370,16 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
       for (int i = 0; i < p->P; i++)
         GP_CHECK(launch_kernel_build(h, kerns[i], Z, M, nullptr, M, p->L, M, i > 0, i == 0 ? p->jitter : 0.0, feats[i], 1));
   }
-  if (p->chol_blocked) GP_CHECK(chol_inverse_blocked_run(h, M, M, p->chol_ws_kuu, p->chol_ws_bytes));
-  else GP_CHECK(launch_cholesky_inverse_single(h, p->L, p->W, M, M));
+  // Long batches: the factorisation of Kuu (one workgroup, then a chain of small launches: 0.6 ms at M = 512) goes to the
+  // handle's helper stream and the Kuf strip build (device-filling, 0.3 ms at N = 65536) runs beside it, as in the Pdgp
+  // engine (engine.hip: cond_batch_run); they meet before A' = W Kuf.  Event fork / join only: it records into a hipGraph.
+  const bool forked = (N >= 4096) && gp_aux_fork(h);
+  {
+    gp_status st = p->chol_blocked ? chol_inverse_blocked_run(h, M, M, p->chol_ws_kuu, p->chol_ws_bytes)
+                                   : launch_cholesky_inverse_single(h, p->L, p->W, M, M);
+    if (forked) { gp_status s2 = gp_aux_end(h); if (st == GP_OK) st = s2; }
+    GP_CHECK(st);
+  }
   {
     gp_status st = GP_OK;
     if (launch_kernel_build_sum(h, kerns.data(), feats.data(), p->P, Z, M, X, N, p->Kuf, ld, 0.0, f32, &st)) GP_CHECK(st);
@@ -379,6 +387,7 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
       for (int i = 0; i < p->P; i++)
         GP_CHECK(launch_kernel_build(h, kerns[i], Z, M, X, N, p->Kuf, ld, i > 0, 0.0, feats[i], 1, f32));
   }
+  GP_CHECK(gp_aux_join(h));
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ; f.uniform_aligned = 1;   /* one problem, arena buffers, ld = gp_strip_ld */
     if (f32) { f.role = 1; GP_CHECK(launch_gemm_f32_role(h, desc->probs + 0, 1, M, N, f)); }
     else GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
@@ -573,22 +582,35 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
   f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER;
   GP_CHECK(launch_gemm_batched(h, D + Q_R, 1, M, M, f));
   GP_CHECK(launch_matvec_batched(h, D + Q_ALPHA, 1, M, 1));
+  // Kuu side (same Cholesky-adjoint chain as the Pdgp backward): five dependent M x M products that end in Kuu_bar (in E2).
+  // Nothing on the Kuf side reads what they write (T1, T2, H, E2 — R = W^T E2 is already there), so for long batches the
+  // chain runs on the helper stream underneath the Kuf_bar product and its contraction.
+  auto kuu_chain = [&]() -> gp_status {
+    GemmFlags f;
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D + Q_T2, 1, M, M, f));
+    f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
+    GP_CHECK(launch_gemm_batched(h, D + Q_LBAR, 1, M, M, f));
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D + Q_P, 1, M, M, f));
+    GP_CHECK(launch_phi_batched(h, D + Q_P, 1, M));
+    f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D + Q_T3, 1, M, M, f));
+    f = GemmFlags(); f.triB = TRI_LOWER;
+    GP_CHECK(launch_gemm_batched(h, D + Q_S, 1, M, M, f));
+    return GP_OK;
+  };
+  const bool forked = (N >= 4096) && gp_aux_fork(h);
+  if (forked) {
+    gp_status st = kuu_chain();
+    gp_status s2 = gp_aux_end(h);
+    GP_CHECK(st); GP_CHECK(s2);
+  }
   hipLaunchKernelGGL(fill_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, p->ones, N, 1.0);
   f = GemmFlags(); f.big_tiles = (M > 64); f.scale_mode = 1; f.timer = GP_TIMER_KUF_BAR; f.role = (M > 64) ? 3 : 0; f.uniform_aligned = 1;
   if (f32) { f.role = 3; GP_CHECK(launch_gemm_f32_role(h, D + Q_G, 1, M, N, f)); }
   else GP_CHECK(launch_gemm_batched(h, D + Q_G, 1, M, N, f));
-  // Kuu side (same Cholesky-adjoint chain as the Pdgp backward)
-  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D + Q_T2, 1, M, M, f));
-  f = GemmFlags(); f.transB = 1; f.triB = TRI_UPPER; f.triC = TRI_LOWER; f.alpha = -1.0;
-  GP_CHECK(launch_gemm_batched(h, D + Q_LBAR, 1, M, M, f));
-  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D + Q_P, 1, M, M, f));
-  GP_CHECK(launch_phi_batched(h, D + Q_P, 1, M));
-  f = GemmFlags(); f.transA = 1; f.triA = TRI_UPPER; f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D + Q_T3, 1, M, M, f));
-  f = GemmFlags(); f.triB = TRI_LOWER;
-  GP_CHECK(launch_gemm_batched(h, D + Q_S, 1, M, M, f));
+  if (!forked) GP_CHECK(kuu_chain());
   // every kernel of the sum sees the same Kuf_bar / Kuu_bar (K = sum_p K_p)
   // (Kuf side: all-Mercer sums of up to six kernels with at most four partials each go through ONE pass over Kuf_bar)
   bool fused = false;
@@ -606,6 +628,7 @@ static gp_status sgpr_backward(gp_sgpr_plan p, const double* params, const doubl
                                       &np_fused, &st);
     if (fused) GP_CHECK(st);
   }
+  GP_CHECK(gp_aux_join(h));      // Kuu_bar is needed from here on
   if (fused && tail_items) {
     int np_uu = 0;
     GP_CHECK(launch_hyper_contract_items(h, p->ktype[0], p->m[0], (const HyperItem*)(d_block1 + SG_EXTRA_OFF), p->P, M, M, 0, &np_uu));
