@@ -1478,7 +1478,9 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     { GemmProblem& r = P(S_RANK1); r.C = b.Wbar; r.v0 = q_mu; r.v1 = b.Lu; }
     { GemmProblem& r = P(S_R); r.A = t.W; r.B = b.E; r.C = b.R; }
     { GemmProblem& r = P(S_ALPHA); r.A = t.W; r.v0 = q_mu; r.o0 = b.alpha; }
-    { GemmProblem& r = P(S_G); r.A = b.R; r.B = t.A; r.ldb = ldN; r.N = n; r.v1 = gv; r.C = b.G; r.ldc = ldN; }
+    { GemmProblem& r = P(S_G); r.A = b.R; r.B = t.A; r.ldb = ldN; r.N = n; r.v1 = gv; r.C = b.G; r.ldc = ldN;
+      // (read only by the form that contracts Kuf_bar with dK/dtheta in its epilogue — gemm_strip.hip role 5)
+      r.kern = t.kern; r.xa = params + q.off_z; r.v0 = b.alpha; r.v2 = gm; r.o0 = b.hyp_part; }
     { GemmProblem& r = P(S_T2); r.A = t.W; r.B = b.Wbar; r.C = b.T2; }
     { GemmProblem& r = P(S_LBAR); r.A = b.T2; r.B = t.W; r.C = b.T1; }
     { GemmProblem& r = P(S_P); r.A = t.L; r.B = b.T1; r.C = b.T2; }
@@ -1731,10 +1733,14 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     // (slots of the compacted batch keep the GPs' order: its float64 GPs come first, k64 of them)
     int k64 = 0;
     for (int g : p->kgps) if (!p->gps[g].f32) k64++;
-    auto kuf_bar = [&](int slot0, int count) -> gp_status {
+    auto kuf_bar = [&](int slot0, int count, int fused_ktype = -1) -> gp_status {
       GemmFlags f;
       f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
       f.uniform_aligned = kuf_uniform;
+      if (fused_ktype >= 0) {      // the family's Kuf-side contraction as the product's epilogue, nothing stored (float64 GPs only)
+        f.role = 5; f.epilogue = 0; f.aux_x = x; f.aux_ktype = fused_ktype;
+        return launch_gemm_batched(h, D(S_G) + slot0, count, maxM, n, f);
+      }
       const int c64 = (slot0 < k64) ? ((slot0 + count <= k64) ? count : k64 - slot0) : 0;
       if (c64 > 0) GP_CHECK(launch_gemm_batched(h, D(S_G) + slot0, c64, maxM, n, f));
       if (c64 < count) GP_CHECK(launch_gemm_f32_role(h, D(S_G) + slot0 + c64, count - c64, maxM, n, f));
@@ -1752,6 +1758,9 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
                                    t.Kuf, ldN, q.f32);
     };
     auto contract_family = [&](const gp_pdgp_plan_s::HyFamily& fam) -> gp_status {
+#ifdef GP_EXP_SKIP_STAT
+      if (!fam.mfma) return GP_OK;     // timing experiment only (wrong gradients): the stationary family's contraction left out
+#endif
       if (!fam.batched) { for (int g : fam.gps) GP_CHECK(kuf_contract(g)); return GP_OK; }
       int np = 0;
       GP_CHECK(launch_hyper_contract_items(h, fam.type, fam.m, (const HyperItem*)(p->d_misc + p->off_hy_items) + fam.first,
@@ -1759,6 +1768,32 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       for (int g : fam.gps) np_uf[g] = np;
       return GP_OK;
     };
+    // A stationary family with fixed inducing inputs wants Kuf_bar for two sums per GP only: they come out of the product's
+    // epilogue (gemm_strip.hip role 5; float64 strips, whole 128-tiles) and neither the strip nor the separate contraction
+    // exists.  The choice depends on shapes and kernel types alone — never on the overlap level, whose settings must give
+    // bit-identical results — and needs every family in one contiguous run of the compacted batch.
+    const int nfam = (int)p->hy_fams.size();
+    std::vector<int> fslot(nfam, -1), ffuse(nfam, 0);
+    {
+      bool contiguous = (white && nfam > 0);
+      for (int fi = 0; fi < nfam; fi++) { fslot[fi] = fam_slot0(p->hy_fams[fi]); if (fslot[fi] < 0) contiguous = false; }
+      for (int fi = 0; fi < nfam && contiguous; fi++) {
+        const auto& fam = p->hy_fams[fi];
+        bool ok = kuf_uniform && fam.batched && !fam.f32 && !fam.mfma && fam.M == maxM &&
+                  gemm_strip_fused_contraction_ok(maxM, n, fam.type);
+        for (int g : fam.gps) if (p->gps[g].need_z || !p->gps[g].need_theta) ok = false;
+        ffuse[fi] = ok ? 1 : 0;
+      }
+    }
+    auto kuf_bar_family = [&](int fi) -> gp_status {          // one family's product (contiguous slots), fused form if chosen
+      const auto& fam = p->hy_fams[fi];
+      if (!ffuse[fi]) return kuf_bar(fslot[fi], fam.count);
+      GP_CHECK(kuf_bar(fslot[fi], fam.count, fam.type));
+      for (int g : fam.gps) np_uf[g] = (maxM / 128) * (n / 128);
+      return GP_OK;
+    };
+    bool any_fused = false;
+    for (int fi = 0; fi < nfam; fi++) any_fused |= (ffuse[fi] != 0);
     int sm_fam = -1, other_fam = -1, sm_slot = -1, other_slot = -1;
     static const int split_mode = getenv("GP_KUFBAR_SPLIT") ? atoi(getenv("GP_KUFBAR_SPLIT")) : 2;   // 0 / 1: A/B switches
     if (split_mode >= 1 && p->hy_fams.size() == 2 && forked && p->overlap >= 2) {
@@ -1772,15 +1807,20 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       // spectral-mixture family's product, and the long contraction has the device to itself afterwards
       const auto& fs = p->hy_fams[sm_fam];
       const auto& fo = p->hy_fams[other_fam];
-      GP_CHECK(kuf_bar(other_slot, fo.count));
-      const bool side = gp_side_begin(h);
-      if (side) {
-        gp_status st2 = contract_family(fo);
-        gp_status s3 = gp_side_end(h);
-        GP_CHECK(st2); GP_CHECK(s3);
+      if (ffuse[other_fam]) {
+        GP_CHECK(kuf_bar_family(other_fam));
+        GP_CHECK(kuf_bar(sm_slot, fs.count));
+      } else {
+        GP_CHECK(kuf_bar(other_slot, fo.count));
+        const bool side = gp_side_begin(h);
+        if (side) {
+          gp_status st2 = contract_family(fo);
+          gp_status s3 = gp_side_end(h);
+          GP_CHECK(st2); GP_CHECK(s3);
+        }
+        GP_CHECK(kuf_bar(sm_slot, fs.count));
+        if (!side) GP_CHECK(contract_family(fo));
       }
-      GP_CHECK(kuf_bar(sm_slot, fs.count));
-      if (!side) GP_CHECK(contract_family(fo));
       GP_CHECK(contract_family(fs));
     } else if (sm_slot >= 0 && other_slot >= 0) {
       const auto& fs = p->hy_fams[sm_fam];
@@ -1792,11 +1832,12 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
         gp_status s3 = gp_side_end(h);
         GP_CHECK(st2); GP_CHECK(s3);
       }
-      GP_CHECK(kuf_bar(other_slot, fo.count));
+      GP_CHECK(kuf_bar_family(other_fam));
       if (!side) GP_CHECK(contract_family(fs));
-      GP_CHECK(contract_family(fo));
+      if (!ffuse[other_fam]) GP_CHECK(contract_family(fo));
     } else {
-      GP_CHECK(kuf_bar(0, nK));
+      if (any_fused) { for (int fi = 0; fi < nfam; fi++) GP_CHECK(kuf_bar_family(fi)); }
+      else GP_CHECK(kuf_bar(0, nK));
       if (!forked) {
         if (early_fork) { GP_CHECK(h_chain_head()); GP_CHECK(wbar_chain()); }   // (no helper stream to be had)
         GP_CHECK(kuu_side());
@@ -1806,11 +1847,11 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       const bool side = (p->hy_fams.size() > 1) && forked && p->overlap >= 2 && gp_side_begin(h);
       if (side) {
         gp_status st2 = GP_OK;
-        for (const auto& fam : p->hy_fams) if (!fam.mfma && st2 == GP_OK) st2 = contract_family(fam);
+        for (int fi = 0; fi < nfam; fi++) if (!p->hy_fams[fi].mfma && !ffuse[fi] && st2 == GP_OK) st2 = contract_family(p->hy_fams[fi]);
         gp_status s3 = gp_side_end(h);
         GP_CHECK(st2); GP_CHECK(s3);
       }
-      for (const auto& fam : p->hy_fams) if (!side || fam.mfma) GP_CHECK(contract_family(fam));
+      for (int fi = 0; fi < nfam; fi++) if ((!side || p->hy_fams[fi].mfma) && !ffuse[fi]) GP_CHECK(contract_family(p->hy_fams[fi]));
     }
     if (!white) {
       GP_CHECK(launch_matvec_batched(h, D(S_GQ_MU), G, maxM, 1));

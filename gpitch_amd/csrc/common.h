@@ -239,11 +239,14 @@ struct GemmFlags {
   int timer = GP_TIMER_SMALL_GEMM;
   int role = 0;          // 1 cond_A, 2 cond_LTA (needs transA), 3 kuf_bar: dedicated 128x128 instantiations
   int tile_m0 = 0, tile_mcount = 0;   // strip products (big tiles, no split-K): only row-blocks [m0, m0 + mcount) (0 = all)
+  const double* aux_x = nullptr;      // role 5 (gemm_strip.hip): the frames x of the batch; aux_ktype: the stationary kernel type
+  int aux_ktype = -1;
   int uniform_aligned = 0;            // the caller vouches: every problem has M = maxM (= K structure), N = maxN, 16-byte
                                       // aligned operands with even leading dimensions (gemm_strip.hip's lean form)
 };
 bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                             gp_status* st);
+bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype);
 enum GemmEpi {
   EPI_STORE = 1,     // C = alpha*acc + beta*C
   EPI_COLSUMSQ = 2,  // o0[rowblk*N + n] = sum over the tile's rows of (alpha*acc)^2

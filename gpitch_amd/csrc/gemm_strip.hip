@@ -70,6 +70,7 @@ struct StripFlags {
   int tilesM, tilesN, tm0;
   int epi;            // EPI_* bitmask
   double alpha;       // role 3 only, a power of two: folded into the column scales (exact)
+  const double* xcols; // role 5 only: the frames x (the B strip's columns; not part of any descriptor: pdgp.hip pdgp_bind)
 };
 
 template <bool TA> struct StripSmem {
@@ -107,9 +108,14 @@ __device__ __forceinline__ void gs_touch(gcbytes base, uint32_t voff, double* si
 }
 
 // TAG 1: op(A) = W (lower), NN.  TAG 2: op(A) = Lq^T (upper; A read transposed), K walked downwards.  TAG 3: dense, NN,
-// B(k, n) *= v1[n].
-template <int TAG>
+// B(k, n) *= v1[n].  TAG 5 (KT = a stationary kernel type): TAG 3's product with the Kuf-side hyper-gradient contraction of
+// a stationary kernel as its epilogue — Kuf_bar = R (A D) of a latent GP whose inducing inputs are fixed is wanted for
+// nothing but  sum_ij (Kuf_bar_ij + alpha_i gm_j) dK_ij/d(variance, lengthscale)  (bwd.hip: hyper_contract_kernel), so the
+// tile is contracted straight out of the accumulators and never stored: one partial record (2 sums) per tile instead of
+// a 134-MB strip written and read back per GP.  Same per-entry arithmetic as hyper_contract_kernel<1, false, false, KT>.
+template <int TAG, int KT = -1>
 __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* __restrict__ probs, StripFlags f) {
+  constexpr bool SCALE = (TAG == 3 || TAG == 5);
   constexpr bool TA = (TAG == 2);
   constexpr bool KDOWN = (TAG == 2);
   constexpr int TRI = (TAG == 1) ? TRI_LOWER : (TAG == 2) ? TRI_UPPER : TRI_NONE;
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
   gcbytes sA = gs_uniform((gcbytes)p.A + (TA ? (int64_t)kfirst * p.lda * 8 : (int64_t)kfirst * 8));
   gcbytes sB = gs_uniform((gcbytes)p.B + (int64_t)kfirst * p.ldb * 8);
   double ra[EA], rbX[EB], rbY[EB], rs[EB];
-  if (TAG == 3) {
+  if (SCALE) {
     const gcptr gv1 = (gcptr)p.v1;
 #pragma unroll
     for (int e = 0; e < EB; e++) rs[e] = f.alpha * gv1[j0 + b_n + (e >> 1) * 32 + (e & 1)];   // (alpha = 2^k: exact)
@@ -215,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
 #pragma unroll
       for (int e = 0; e < EA; e++) if (kt + a_k < i0 + a_i + (e >> 1) * 32 + (e & 1)) ra[e] = 0.0;
     }
-    if (TAG == 3) {
+    if (SCALE) {
 #pragma unroll
       for (int e = 0; e < EB; e++) rb[e] *= rs[e];
     }
@@ -405,6 +411,64 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_kernel(const GemmProblem* _
         if (f.epi & EPI_COLSUMSQ) go0[(int64_t)tm * p.N + j] = s2;
         if (f.epi & EPI_COLDOT) go1[(int64_t)tm * p.N + j] = sd;
       }
+    }
+  }
+  if (TAG == 5) {
+    // acc[a][b][r] = Kuf_bar(i0 + 16 a + kq + 4 r, j0 + 32 wc + 16 b + lc).  Row tables (z_i / l, alpha_i) and the exp table go
+    // to the (now free) LDS stages; sums over the tile in a fixed order: lanes by shuffles, wavefronts through LDS.
+    double* etab = smem;                 // GP_EXP_TAB = 64
+    double* row_a = smem + 64;           // 128
+    double* row_al = smem + 192;         // 128
+    double* red = smem + 320;            // 4 x 2
+    const gcptr th = (gcptr)p.kern.theta;
+    const double var = th[0], ls = th[1];
+    gp_exp_tab_init(etab);
+    if (tid < GS_BM) { row_a[tid] = ((gcptr)p.xa)[i0 + tid] / ls; row_al[tid] = ((gcptr)p.v0)[i0 + tid]; }
+    __syncthreads();
+    const double inv_ls = 1.0 / ls;
+    double acc_v = 0.0, acc_l = 0.0;
+    const gcptr gx = (gcptr)f.xcols, ggm = (gcptr)p.v2;
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+      const int j = j0 + wc * 32 + b * 16 + lc;
+      const double bcol = gx[j] / ls, bb = __dmul_rn(bcol, bcol), gmj = ggm[j];
+#pragma unroll
+      for (int a = 0; a < TM; a++) {
+        __builtin_amdgcn_sched_barrier(0);       // one 16-row tile at a time: hoisting all 64 table reads spilled 36 VGPRs
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int ii = a * 16 + kq + 4 * r;
+          const double av = row_a[ii], aa = __dmul_rn(av, av);
+          const double w = fma(row_al[ii], gmj, acc[a][b][r]);
+          const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(av, bcol), aa), bb);
+          if (KT == GP_KERN_RBF) {
+            const double e = gp_exp_neg(-0.5 * r2, etab);
+            acc_v = fma(w, e, acc_v);
+            acc_l = fma(w, var * e * r2 * inv_ls, acc_l);
+          } else {
+            double rr, rinv;
+            gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), rr, rinv);
+            double phi, dphi;
+            if (KT == GP_KERN_MATERN12) { phi = gp_exp_neg(-rr, etab); dphi = -phi; }
+            else if (KT == GP_KERN_MATERN32) {
+              const double s3 = 1.7320508075688772, e = gp_exp_neg(-s3 * rr, etab);
+              phi = (1.0 + s3 * rr) * e; dphi = -3.0 * rr * e;
+            } else {
+              const double s5 = 2.23606797749979, e = gp_exp_neg(-s5 * rr, etab);
+              phi = (1.0 + s5 * rr + (5.0 / 3.0) * rr * rr) * e; dphi = -(5.0 / 3.0) * rr * (1.0 + s5 * rr) * e;
+            }
+            acc_v = fma(w, phi, acc_v);
+            acc_l = fma(w * var * dphi, -r2 * rinv * inv_ls, acc_l);
+          }
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { acc_v += __shfl_down(acc_v, o, 64); acc_l += __shfl_down(acc_l, o, 64); }
+    if (lane == 0) { red[wc * 2 + 0] = acc_v; red[wc * 2 + 1] = acc_l; }
+    __syncthreads();
+    if (tid < 2) {
+      const double sacc = (red[0 * 2 + tid] + red[1 * 2 + tid]) + (red[2 * 2 + tid] + red[3 * 2 + tid]);
+      ((gptr)p.o0)[((int64_t)tm * f.tilesN + tn) * 2 + tid] = sacc;
     }
   }
 #ifdef GS_STAMPS
@@ -653,11 +717,11 @@ bool launch_gemm_strip_nt_lean(gp_handle h, const GemmProblem* d_probs, int batc
   return true;
 }
 
-template <int TAG>
+template <int TAG, int KT = -1>
 static gp_status launch_strip(gp_handle h, const GemmProblem* d_probs, int batch, int M, int N, const GemmFlags& f) {
   using S = StripSmem<TAG == 2>;
   StripFlags sf;
-  sf.tilesM = M / GS_BM; sf.tilesN = N / GS_BN; sf.tm0 = f.tile_m0; sf.epi = f.epilogue; sf.alpha = f.alpha;
+  sf.tilesM = M / GS_BM; sf.tilesN = N / GS_BN; sf.tm0 = f.tile_m0; sf.epi = f.epilogue; sf.alpha = f.alpha; sf.xcols = f.aux_x;
   if (f.tile_m0 > 0 || f.tile_mcount > 0) {
     const int all = sf.tilesM;
     if (f.tile_m0 >= all) return GP_OK;
@@ -666,13 +730,22 @@ static gp_status launch_strip(gp_handle h, const GemmProblem* d_probs, int batch
   static std::atomic<uint32_t> attr_devs{0};
   const uint32_t bit = 1u << (h->device & 31);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_strip_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_strip_kernel<TAG, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
     attr_devs.fetch_or(bit, std::memory_order_release);
   }
   dim3 grid(sf.tilesM * sf.tilesN, 1, batch);
-  hipLaunchKernelGGL((gemm_strip_kernel<TAG>), grid, dim3(256), S::BYTES, h->stream, d_probs, sf);
+  hipLaunchKernelGGL((gemm_strip_kernel<TAG, KT>), grid, dim3(256), S::BYTES, h->stream, d_probs, sf);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
+}
+
+// role 5 (Kuf_bar with the stationary hyper-gradient contraction as its epilogue) exists in the lean form only: whether a
+// launch of that shape would take it (pdgp_backward asks before it decides to skip the separate contraction)
+bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype) {
+  static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0);
+  static const bool fuse = !(getenv("GP_HYPER_FUSE") && atoi(getenv("GP_HYPER_FUSE")) == 0);      // A/B switch
+  const bool stat = (ktype == GP_KERN_MATERN12 || ktype == GP_KERN_MATERN32 || ktype == GP_KERN_MATERN52 || ktype == GP_KERN_RBF);
+  return enabled && fuse && stat && maxM > 0 && (maxM % GS_BM) == 0 && (maxN % GS_BN) == 0;
 }
 
 // Returns true when the lean form took the launch (*st = its status); false: run gemm.hip's kernel.  `uniform` = the caller
@@ -680,10 +753,21 @@ static gp_status launch_strip(gp_handle h, const GemmProblem* d_probs, int batch
 bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                             gp_status* st) {
   static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0);    // A/B switch
-  if (!enabled || !f.uniform_aligned || f.role < 1 || f.role > 3) return false;
+  if (!enabled || !f.uniform_aligned || f.role < 1 || (f.role > 3 && f.role != 5)) return false;
   if ((maxM % GS_BM) != 0 || (maxN % GS_BN) != 0 || f.beta != 0.0 || f.triC != TRI_NONE) return false;
-  if (f.role == 3 ? !(f.alpha == 1.0 || f.alpha == 2.0 || f.alpha == 0.5 || f.alpha == 4.0) : (f.alpha != 1.0)) return false;
-  if (f.role == 3 && f.scale_mode != 1) return false;
+  if (f.role >= 3 ? !(f.alpha == 1.0 || f.alpha == 2.0 || f.alpha == 0.5 || f.alpha == 4.0) : (f.alpha != 1.0)) return false;
+  if (f.role >= 3 && f.scale_mode != 1) return false;
+  if (f.role == 5) {       // (the caller has asked gemm_strip_fused_contraction_ok first: it cannot fall back from here)
+    if (!f.aux_x || f.tile_m0 || f.tile_mcount) { *st = gp_fail(h, GP_ERR_BAD_ARG, "fused Kuf_bar contraction: bad launch"); return true; }
+    switch (f.aux_ktype) {
+      case GP_KERN_MATERN12: *st = launch_strip<5, GP_KERN_MATERN12>(h, d_probs, batch, maxM, maxN, f); break;
+      case GP_KERN_MATERN32: *st = launch_strip<5, GP_KERN_MATERN32>(h, d_probs, batch, maxM, maxN, f); break;
+      case GP_KERN_MATERN52: *st = launch_strip<5, GP_KERN_MATERN52>(h, d_probs, batch, maxM, maxN, f); break;
+      case GP_KERN_RBF: *st = launch_strip<5, GP_KERN_RBF>(h, d_probs, batch, maxM, maxN, f); break;
+      default: *st = gp_fail(h, GP_ERR_BAD_ARG, "fused Kuf_bar contraction: not a stationary kernel");
+    }
+    return true;
+  }
   if (f.role == 1) *st = launch_strip<1>(h, d_probs, batch, maxM, maxN, f);
   else if (f.role == 2) *st = launch_strip<2>(h, d_probs, batch, maxM, maxN, f);
   else *st = launch_strip<3>(h, d_probs, batch, maxM, maxN, f);

@@ -593,6 +593,48 @@ def test_separable_envelope_paths_match_autograd(gp_handle, ls, ktype):
         np.testing.assert_allclose(gg.reshape(rg.shape), rg, rtol=0, atol=tol * scale, err_msg=name)
 
 
+@pytest.mark.parametrize("ktype,ls", [("matern32", 1.0), ("matern12", 0.3), ("matern52", 0.05), ("rbf", 0.02)])
+def test_fused_kuf_bar_contraction_matches_autograd(gp_handle, ktype, ls):
+    """Stationary activation kernels with fixed inducing inputs, float64 strips and whole 128-tiles (M = 128, N = 4096: the
+    bench's situation in small) take the form of the Kuf_bar product that contracts its tile with dK/d(variance,
+    lengthscale) in the epilogue and stores nothing (gemm_strip.hip role 5).  Every gradient entry against torch autograd
+    through the oracle, for the four stationary types; the overlap levels (which pick different launch orders around it)
+    must still agree bit for bit."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(4096, 128, 2, num_partials=3, seed=7)
+    for d in prob["kern_act"]:
+        d["type"] = ktype
+        d["lengthscales"] = ls
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    first = None
+    for level in (2, 0, 1):
+        model = pdgp_from_problem(prob, handle=gp_handle)
+        model.za.fixed = True
+        model.zc.fixed = True
+        model._pack()
+        gp_handle.check(gp_handle.lib.gp_pdgp_set_overlap(model._plan, level))
+        f = model._elbo(True)
+        g = model._grad.cpu().numpy().copy()
+        if first is None:
+            first = (f, g)
+            assert abs(f - ref_f) <= ELBO_RTOL * abs(ref_f), (f, ref_f)
+            got_g = model_grad_dict(model)
+            worst = 0.0
+            for name, rg in ref_g.items():
+                if name.startswith("z"):
+                    continue
+                gg = got_g[name]
+                if name.startswith("q_sqrt"):
+                    rg = np.tril(rg[:, :, 0])[:, :, None]
+                scale = max(np.abs(rg).max(), 1e-12)
+                err = np.abs(gg.reshape(rg.shape) - rg).max() / scale
+                worst = max(worst, err)
+                assert err <= 1e-6, (name, err)
+            print("fused Kuf_bar contraction (%s): worst gradient block deviation %.2e" % (ktype, worst))
+        else:
+            assert f == first[0] and np.array_equal(g, first[1]), level
+
+
 @pytest.mark.parametrize("P,world,whiten", [(3, 2, True), (5, 3, True), (4, 8, True), (2, 3, False)])
 def test_gp_sharded_two_stage_matches_unsharded(gp_handle, P, world, whiten):
     """SURVEY section 8e option 2: ONE model with its 2P latent GPs dealt over `world` ranks (gp_pdgp_cond_begin -> all-gather of
