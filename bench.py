@@ -528,8 +528,11 @@ def main():
         else:
             # (whole aligned strips run gemm_strip.hip's lean forms; ragged shapes fall back to gemm_f64_kernel<128,128,...>)
             lean = (M % 128 == 0) and (N % 128 == 0) and os.environ.get("GP_STRIP_LEAN", "1") != "0"
-            sym = ({"cond_A": "gemm_strip_kernel<1>", "cond_LTA": "gemm_strip_kernel<2>", "nt_gemm": "gemm_strip_nt_kernel",
-                    "kuf_bar": "gemm_strip_kernel<3>"} if lean else
+            # (Kuf_bar is one launch per kernel family: the stationary activation family's — inducing inputs fixed —
+            #  contracts its tile with dK/dtheta in the epilogue and stores nothing, gemm_strip_kernel<5, KT = Matern32>)
+            fused = os.environ.get("GP_HYPER_FUSE", "1") != "0" and args.overlap >= 0
+            sym = ({"cond_A": "gemm_strip_kernel<1,-1>", "cond_LTA": "gemm_strip_kernel<2,-1>", "nt_gemm": "gemm_strip_nt_kernel",
+                    "kuf_bar": "gemm_strip_kernel<3,-1> + gemm_strip_kernel<5,1>" if fused else "gemm_strip_kernel<3,-1>"} if lean else
                    {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
                     "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"})
         # roofline (by its definition): the dominant kernel's OWN algorithmic flops per launch / its OWN mean launch
@@ -541,7 +544,9 @@ def main():
             tfile = os.path.join("profiles", "r03", "hbm_traffic.json")
             tj = json.load(open(os.path.join(ROOT, tfile)))
             if (N, M, G, args.partials) == (32768, 512, 24, 20) and tj.get("overlap_level", 2) == args.overlap and not f32:
-                traffic = tj["kernels"][sym[dom].replace(" ", "")]["hbm_bytes"]
+                # (a timer class whose launches are two symbols: the mean over its launches, one launch of each per step)
+                names = [t.strip().replace(" ", "") for t in sym[dom].split(" + ")]
+                traffic = sum(tj["kernels"][t]["hbm_bytes"] for t in names) / len(names)
                 traffic_src = tfile + " (static: rocprofv3 --pmc passes of this command, not measured in this run)"
         except Exception:
             traffic = None

@@ -2,13 +2,13 @@
 # Runs on the GPU box (gpurun): round 3's bench lines, rocprofv3 kernel statistics, the PMC passes the roofline figures are
 # checked against, and the probes behind DESIGN.md 3.0 (float64 MFMA vs vector ALU).  Everything lands under
 # gpurun_out/r03prof/; tools/collect_profiles_r03_copy.sh copies the summaries to profiles/r03/.
-# Part selection: PARTS="bench stats pmc valu probes" (default: all)
+# Part selection: PARTS="bench stats pmc valu probes cfg5" (default: all; probes needs the tools/ab variant libraries)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03prof
 mkdir -p $O
 B="--no-cpu --no-f32-line --no-sgpr-lines"
-PARTS=${PARTS:-"bench stats pmc valu probes"}
+PARTS=${PARTS:-"bench stats pmc valu probes cfg5"}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has bench; then
 echo "== bench default (the driver's command + steps)" && timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err || exit 1
@@ -45,5 +45,13 @@ echo "== strip stamps" && GPITCH_AMD_LIB=tools/ab/lib_stamps.so timeout -k 10 20
 echo "== chol stamps" && GPITCH_AMD_LIB=tools/ab/lib_chstamps.so timeout -k 10 200 python3 tools/chol_stamps.py 512 > $O/chol_stamps.txt 2> $O/chol_stamps.err || exit 1
 echo "== kuf A/B" && : > $O/kuf_ab.txt
 for d in 3 0; do echo "GP_KUF_DIRECT=$d" >> $O/kuf_ab.txt; GP_KUF_DIRECT=$d timeout -k 10 200 python3 tools/bench_kuf.py >> $O/kuf_ab.txt 2>> $O/kuf_ab.err || exit 1; done
+fi
+if has cfg5; then
+# BASELINE configs[4] (sgpr_ss, N = 65536, M = 512, 5 kernels): kernel statistics and one evaluation's launch list (eager
+# launches under the profiler), the per-class timers without it; the hipGraph-replayed figure is bench_default.json's cfg5_sgpr
+echo "== cfg5 stats" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg5 -o s -- python3 tools/time_sgpr.py --only f64 > $O/cfg5_time_profiled.log 2>&1 || exit 1
+python3 tools/sgpr_timeline.py $O/stats_cfg5/s_kernel_trace.csv > $O/cfg5_timeline.txt 2>&1 || true
+echo "== cfg5 timers" && timeout -k 10 300 python3 tools/time_sgpr.py > $O/cfg5_time.log 2> $O/cfg5_time.err || exit 1
+grep float $O/cfg5_time.log > $O/cfg5_time.txt
 fi
 du -sh $O

@@ -19,5 +19,7 @@ for lean in 1 0; do
     python3 tools/pmc_summary.py $O/pmc_mfma_lean$lean/p_counter_collection.csv $O/pmc_inst_lean$lean/p_counter_collection.csv > $P/overlap0_sq_counters_lean$lean.txt
   fi
 done
+[ -f $O/stats_cfg5/s_kernel_stats.csv ] && cp $O/stats_cfg5/s_kernel_stats.csv $P/cfg5_kernel_stats.csv
+for f in cfg5_timeline cfg5_time; do [ -s $O/$f.txt ] && cp $O/$f.txt $P/$f.txt; done
 for f in valu_probe strip_stamps chol_stamps kuf_ab; do [ -s $O/$f.txt ] && cp $O/$f.txt $P/$f.txt; done
 ls -la $P
