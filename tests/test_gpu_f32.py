@@ -170,6 +170,36 @@ def test_mixed_precision_activation_f64_component_f32(gp_handle, N, M, P, m, whi
         assert d <= tol, devs
 
 
+def test_mixed_precision_gp_sharded_matches_unsharded(gp_handle):
+    """per-GP precision under the GP-sharded partition (SURVEY 8e option 2): a rank's subset plan takes the precision of ITS
+    rows (activation rows float64, component rows float32), so every emulated rank reports the unsharded mixed-precision
+    model's ELBO and its own slice of the gradient"""
+    import torch
+    from gpitch_amd.synth import make_problem, pdgp_from_problem
+    P, world = 2, 3
+    prob = make_problem(900, 24, P, num_partials=3, seed=13)
+    ft = (np.float64, np.float32)
+    full = pdgp_from_problem(prob, handle=gp_handle, float_type=ft)
+    full._pack()
+    e_full = full._elbo(True)
+    g_full = full._grad.cpu().numpy().copy()
+    shards = [pdgp_from_problem(prob, handle=gp_handle, shard=("gp", r, world), float_type=ft) for r in range(world)]
+    for s in shards:
+        s._pack()
+    gathered = torch.cat([s._gp_begin(True).clone() for s in shards])
+    for s in shards:
+        e = s._gp_end(True, gathered)
+        assert abs(e - e_full) <= 1e-10 * abs(e_full), (e, e_full)
+        g = s._grad.cpu().numpy()
+        for l, gi in enumerate(s._gp_shard):
+            o_th, o_z, o_mu, o_sq = s._layout[l]
+            f_th, f_z, f_mu, f_sq = full._layout[gi]
+            M = 24
+            for (o, f, n) in ((o_mu, f_mu, M), (o_sq, f_sq, M * M), (o_th, f_th, 2)):
+                ref = g_full[f:f + n]
+                assert np.allclose(g[o:o + n], ref, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref).max())), (gi, o, f)
+
+
 def test_mixed_precision_order_is_checked(gp_handle):
     """float64 latent GPs must precede float32 ones in the engine's order: (float32, float64) is refused, loudly"""
     from gpitch_amd.pdgp import Pdgp
