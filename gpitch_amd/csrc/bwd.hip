@@ -1733,12 +1733,13 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     // (slots of the compacted batch keep the GPs' order: its float64 GPs come first, k64 of them)
     int k64 = 0;
     for (int g : p->kgps) if (!p->gps[g].f32) k64++;
-    auto kuf_bar = [&](int slot0, int count, int fused_ktype = -1) -> gp_status {
+    auto kuf_bar = [&](int slot0, int count, int fused_ktype = -1, int fused_f32 = 0) -> gp_status {
       GemmFlags f;
       f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
       f.uniform_aligned = kuf_uniform;
-      if (fused_ktype >= 0) {      // the family's Kuf-side contraction as the product's epilogue, nothing stored (float64 GPs only)
+      if (fused_ktype >= 0) {      // the family's Kuf-side contraction as the product's epilogue, nothing stored (one precision per family)
         f.role = 5; f.epilogue = 0; f.aux_x = x; f.aux_ktype = fused_ktype;
+        if (fused_f32) return launch_gemm_f32_role(h, D(S_G) + slot0, count, maxM, n, f);
         return launch_gemm_batched(h, D(S_G) + slot0, count, maxM, n, f);
       }
       const int c64 = (slot0 < k64) ? ((slot0 + count <= k64) ? count : k64 - slot0) : 0;
@@ -1779,8 +1780,8 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       for (int fi = 0; fi < nfam; fi++) { fslot[fi] = fam_slot0(p->hy_fams[fi]); if (fslot[fi] < 0) contiguous = false; }
       for (int fi = 0; fi < nfam && contiguous; fi++) {
         const auto& fam = p->hy_fams[fi];
-        bool ok = kuf_uniform && fam.batched && !fam.f32 && !fam.mfma && fam.M == maxM &&
-                  gemm_strip_fused_contraction_ok(maxM, n, fam.type);
+        bool ok = kuf_uniform && fam.batched && !fam.mfma && fam.M == maxM &&
+                  (fam.f32 ? gemm_f32_fused_contraction_ok(maxM, n, fam.type) : gemm_strip_fused_contraction_ok(maxM, n, fam.type));
         for (int g : fam.gps) if (p->gps[g].need_z || !p->gps[g].need_theta) ok = false;
         ffuse[fi] = ok ? 1 : 0;
       }
@@ -1788,7 +1789,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     auto kuf_bar_family = [&](int fi) -> gp_status {          // one family's product (contiguous slots), fused form if chosen
       const auto& fam = p->hy_fams[fi];
       if (!ffuse[fi]) return kuf_bar(fslot[fi], fam.count);
-      GP_CHECK(kuf_bar(fslot[fi], fam.count, fam.type));
+      GP_CHECK(kuf_bar(fslot[fi], fam.count, fam.type, fam.f32));
       for (int g : fam.gps) np_uf[g] = (maxM / 128) * (n / 128);
       return GP_OK;
     };

@@ -247,6 +247,7 @@ struct GemmFlags {
 bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                             gp_status* st);
 bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype);
+bool gemm_f32_fused_contraction_ok(int maxM, int maxN, int ktype);     // gemm_f32.hip: the same for float32 strips
 enum GemmEpi {
   EPI_STORE = 1,     // C = alpha*acc + beta*C
   EPI_COLSUMSQ = 2,  // o0[rowblk*N + n] = sum over the tile's rows of (alpha*acc)^2

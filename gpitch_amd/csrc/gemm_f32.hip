@@ -48,6 +48,7 @@ struct Gemm32Flags {
   int ksplit;       // role 4: K-slices
   int tilesM, tilesN;
   int tm0, tilesM_req;   // row-block range of this launch (see GemmFlags::tile_m0)
+  const double* xcols;   // KT >= 0 (role 3 with the stationary contraction as epilogue): the frames x
 };
 
 // TAG: 1 cond_A (A = W lower, float64 in memory, k-contiguous), 2 cond_LTA (A = Lq^T, upper, float64, row-contiguous),
@@ -55,7 +56,10 @@ struct Gemm32Flags {
 // W8: 8 wavefronts per workgroup (2 x 4: each 64 rows x 32 columns, <= 128 VGPRs, four wavefronts per SIMD) instead of
 // 4 (1 x 4: each 128 x 32).  A float32 MFMA K-tile is half as long as a float64 one against the same staging work, so
 // with two wavefronts per SIMD the matrix pipe idles whenever both are staging (0.68 busy on the dense product).
-template <int TAG, bool W8>
+// KT >= 0 (TAG 3 only): a stationary kernel type — the tile of Kuf_bar is contracted with dK/d(variance, lengthscale) in the
+// epilogue and not stored (gemm_strip.hip's role 5 for float32 strips: the weight is the value the strip would have held,
+// float32(alpha acc), the arithmetic on it float64 as in hyper_contract_kernel).
+template <int TAG, bool W8, int KT = -1>
 __global__ void __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) gemm_f32_kernel(const GemmProblem* __restrict__ probs, Gemm32Flags f) {
   constexpr int NTHREADS = W8 ? 512 : 256;
   constexpr int WAVES_M = W8 ? 2 : 1;
@@ -364,6 +368,67 @@ __global__ void __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) gemm_f32_kernel(co
     return;
   }
   const float alpha = (float)f.alpha;
+  if (TAG == 3 && KT >= 0) {
+    __syncthreads();                                // every wavefront is past its last LDS fragment read
+    double* sm = reinterpret_cast<double*>(smem32);
+    double* etab = sm;                 // GP_EXP_TAB = 64
+    double* row_a = sm + 64;           // 128: z_i / l
+    double* row_al = sm + 192;         // 128: alpha_i
+    double* red = sm + 320;            // [wavefronts][2]
+    const gcptr th = (gcptr)p.kern.theta;
+    const double var = th[0], ls = th[1];
+    gp_exp_tab_init(etab);
+    if (tid < F32_BT) { row_a[tid] = ((gcptr)p.xa)[i0 + tid] / ls; row_al[tid] = gv0[i0 + tid]; }
+    __syncthreads();
+    const double inv_ls = 1.0 / ls;
+    double acc_v = 0.0, acc_l = 0.0;
+    const gcptr gx = (gcptr)f.xcols;
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+      const int j = j0 + ctile[b] * 16 + lc;
+      const double bcol = gx[j] / ls, bb = __dmul_rn(bcol, bcol), gmj = gv2[j];
+#pragma unroll
+      for (int a = 0; a < TM; a++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int ii = wrow0 + a * 16 + kq * 4 + r;
+          const double av = row_a[ii], aa = __dmul_rn(av, av);
+          const double w = fma(row_al[ii], gmj, (double)(alpha * acc[a][b][r]));
+          const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(av, bcol), aa), bb);
+          if (KT == GP_KERN_RBF) {
+            const double e = gp_exp_neg(-0.5 * r2, etab);
+            acc_v = fma(w, e, acc_v);
+            acc_l = fma(w, var * e * r2 * inv_ls, acc_l);
+          } else {
+            double rr, rinv;
+            gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), rr, rinv);
+            double phi, dphi;
+            if (KT == GP_KERN_MATERN12) { phi = gp_exp_neg(-rr, etab); dphi = -phi; }
+            else if (KT == GP_KERN_MATERN32) {
+              const double s3 = 1.7320508075688772, e = gp_exp_neg(-s3 * rr, etab);
+              phi = (1.0 + s3 * rr) * e; dphi = -3.0 * rr * e;
+            } else {
+              const double s5 = 2.23606797749979, e = gp_exp_neg(-s5 * rr, etab);
+              phi = (1.0 + s5 * rr + (5.0 / 3.0) * rr * rr) * e; dphi = -(5.0 / 3.0) * rr * (1.0 + s5 * rr) * e;
+            }
+            acc_v = fma(w, phi, acc_v);
+            acc_l = fma(w * var * dphi, -r2 * rinv * inv_ls, acc_l);
+          }
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { acc_v += __shfl_down(acc_v, o, 64); acc_l += __shfl_down(acc_l, o, 64); }
+    if (lane == 0) { red[wave * 2 + 0] = acc_v; red[wave * 2 + 1] = acc_l; }
+    __syncthreads();
+    if (tid < 2) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < NTHREADS / 64; wv++) sacc += red[wv * 2 + tid];
+      go0[((int64_t)tm * f.tilesN + tn) * 2 + tid] = sacc;
+    }
+    return;
+  }
   if (f.epi & 1) {
 #pragma unroll
     for (int a = 0; a < TM; a++)
@@ -421,7 +486,7 @@ __global__ void __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) gemm_f32_kernel(co
 #ifndef GP_F32_W8_MASK
 #define GP_F32_W8_MASK 15     // bit (role - 1): that role runs with 8 wavefronts per workgroup (same-box A/B, overlap 0: cond_A 3.02 -> 2.53 ms, Lq^T A 2.34 -> 2.24, A D A^T 2.90 -> 2.56, Kuf_bar 4.03 -> 3.60)
 #endif
-template <int TAG>
+template <int TAG, int KT = -1>
 static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, Gemm32Flags f) {
   constexpr bool W8 = ((GP_F32_W8_MASK >> (TAG - 1)) & 1) != 0;
   constexpr int A_ELEMS = (TAG == 2) ? F32_RC_ELEMS : F32_KC_ELEMS;
@@ -439,12 +504,18 @@ static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, 
   static std::atomic<int> attr_dev_mask{0};     // per instantiation; one bit per device (LDS limit is a per-device attribute)
   const int bit = 1 << (h->device & 31);
   if (!(attr_dev_mask.load(std::memory_order_acquire) & bit)) {
-    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f32_kernel<TAG, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES));
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_f32_kernel<TAG, W8, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES));
     attr_dev_mask.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<TAG, W8>), dim3(ntiles, 1, batch), dim3(W8 ? 512 : 256), BYTES, h->stream, d_probs, f);
+  hipLaunchKernelGGL((gemm_f32_kernel<TAG, W8, KT>), dim3(ntiles, 1, batch), dim3(W8 ? 512 : 256), BYTES, h->stream, d_probs, f);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
+}
+
+bool gemm_f32_fused_contraction_ok(int maxM, int maxN, int ktype) {
+  static const bool fuse = !(getenv("GP_HYPER_FUSE") && atoi(getenv("GP_HYPER_FUSE")) == 0);      // A/B switch (as gemm_strip.hip)
+  const bool stat = (ktype == GP_KERN_MATERN12 || ktype == GP_KERN_MATERN32 || ktype == GP_KERN_MATERN52 || ktype == GP_KERN_RBF);
+  return fuse && stat && maxM > 0 && (maxM % F32_BT) == 0 && (maxN % F32_BT) == 0;
 }
 
 // roles 1-3 (see the header of this file); flags as launch_gemm_batched (epilogue bits, alpha); operands: A float64
@@ -452,6 +523,19 @@ static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, 
 gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& gf) {
   if (batch <= 0 || maxM <= 0 || maxN <= 0) return GP_OK;
   GpTimerScope ts(h, gf.timer);
+  if (gf.role == 5) {     // Kuf_bar with the stationary family's contraction as its epilogue (the caller asked gemm_f32_fused_contraction_ok)
+    Gemm32Flags f;
+    f.alpha = gf.alpha; f.epi = 0; f.scale = 1; f.sym = 0; f.ksplit = 1; f.tilesM = f.tilesN = 1; f.tm0 = 0; f.tilesM_req = 0;
+    f.xcols = gf.aux_x;
+    if (!gf.aux_x || (maxM % F32_BT) || (maxN % F32_BT)) return gp_fail(h, GP_ERR_BAD_ARG, "fused float32 Kuf_bar contraction: bad launch");
+    switch (gf.aux_ktype) {
+      case GP_KERN_MATERN12: return launch_f32<3, GP_KERN_MATERN12>(h, d_probs, batch, maxM, maxN, f);
+      case GP_KERN_MATERN32: return launch_f32<3, GP_KERN_MATERN32>(h, d_probs, batch, maxM, maxN, f);
+      case GP_KERN_MATERN52: return launch_f32<3, GP_KERN_MATERN52>(h, d_probs, batch, maxM, maxN, f);
+      case GP_KERN_RBF: return launch_f32<3, GP_KERN_RBF>(h, d_probs, batch, maxM, maxN, f);
+      default: return gp_fail(h, GP_ERR_BAD_ARG, "fused float32 Kuf_bar contraction: not a stationary kernel");
+    }
+  }
   {   // small inducing sets: the M x M operand resident in LDS (gemm_res_f32.hip); whole aligned strips: gemm_strip_f32.hip's lean form
     gp_status st = GP_OK;
     if (launch_gemm_res_f32(h, d_probs, batch, maxM, maxN, gf, &st)) return st;
@@ -459,7 +543,7 @@ gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batc
   }
   Gemm32Flags f;
   f.alpha = gf.alpha; f.epi = gf.epilogue; f.scale = gf.scale_mode; f.sym = 0; f.ksplit = 1; f.tilesM = f.tilesN = 1;
-  f.tm0 = gf.tile_m0; f.tilesM_req = gf.tile_mcount;
+  f.tm0 = gf.tile_m0; f.tilesM_req = gf.tile_mcount; f.xcols = nullptr;
   if (gf.beta != 0.0) return gp_fail(h, GP_ERR_UNSUPPORTED, "float32 strip product: beta != 0");
   switch (gf.role) {
     case 1: return launch_f32<1>(h, d_probs, batch, maxM, maxN, f);
@@ -486,7 +570,7 @@ gp_status launch_gemm_f32_nt_reduce_batched(gp_handle h, const GemmProblem* d_pr
     GpTimerScope ts(h, GP_TIMER_NT_GEMM);
     Gemm32Flags f;
     f.alpha = 1.0; f.epi = 1; f.scale = scale_by_k; f.sym = sym; f.ksplit = nsplit > 1 ? nsplit : 2; f.tilesM = f.tilesN = 1;
-    f.tm0 = 0; f.tilesM_req = 0;
+    f.tm0 = 0; f.tilesM_req = 0; f.xcols = nullptr;
     GP_CHECK(launch_f32<4>(h, d_probs, batch, maxM, maxM, f));
   }
   return launch_slab_reduce(h, d_probs, batch, maxM, nsplit > 1 ? nsplit : 2, sym, alpha);

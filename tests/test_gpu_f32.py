@@ -200,6 +200,39 @@ def test_mixed_precision_gp_sharded_matches_unsharded(gp_handle):
                 assert np.allclose(g[o:o + n], ref, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref).max())), (gi, o, f)
 
 
+@pytest.mark.parametrize("ft", [np.float32, np.float64, (np.float64, np.float32)])
+def test_fused_stationary_contraction_agrees_with_the_separate_kernel(gp_handle, ft):
+    """With the inducing inputs fixed and whole 128-tiles, a stationary family's Kuf-side contraction runs as the epilogue of
+    its Kuf_bar product (gemm_strip.hip role 5 / gemm_f32.hip KT >= 0); with them free the generic contraction kernel reads
+    the stored strip.  Same forward pass, same weights (in float32: the value the strip holds), so the activation kernels'
+    variance / lengthscale gradients of the two models may differ by summation order only."""
+    from gpitch_amd.pdgp import Pdgp
+    from gpitch_amd.synth import make_problem, kernels_from_problem
+    prob = make_problem(4096, 128, 2, num_partials=3, seed=11)
+    grads = []
+    for fixed in (True, False):
+        m = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kernels_from_problem(prob), handle=gp_handle, float_type=ft)
+        for i in range(2):
+            m.q_mu_act[i].value = prob["q_mu_act"][i]; m.q_mu_com[i].value = prob["q_mu_com"][i]
+            m.q_sqrt_act[i].value = prob["q_sqrt_act"][i]; m.q_sqrt_com[i].value = prob["q_sqrt_com"][i]
+        m.likelihood.variance = prob["noise_var"]
+        if fixed:
+            m.za.fixed = True
+            m.zc.fixed = True
+        m._pack()
+        m._elbo(True)
+        g = model_grad_dict(m)
+        grads.append({k: v.copy() for k, v in g.items() if k.startswith("act")})     # (the component family takes two
+        # different routes as well — matrix-core rows kernel / generic — which in float32 read K differently: not compared here)
+    worst = 0.0
+    for k, a in grads[0].items():
+        b = grads[1][k]
+        dev = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+        worst = max(worst, dev)
+        assert dev <= 1e-9, (k, dev)
+    print("fused vs separate stationary contraction: worst relative deviation %.2e" % worst)
+
+
 def test_mixed_precision_order_is_checked(gp_handle):
     """float64 latent GPs must precede float32 ones in the engine's order: (float32, float64) is refused, loudly"""
     from gpitch_amd.pdgp import Pdgp
