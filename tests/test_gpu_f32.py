@@ -200,19 +200,20 @@ def test_mixed_precision_gp_sharded_matches_unsharded(gp_handle):
                 assert np.allclose(g[o:o + n], ref, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref).max())), (gi, o, f)
 
 
-@pytest.mark.parametrize("ft", [np.float32, np.float64, (np.float64, np.float32)])
-def test_fused_stationary_contraction_agrees_with_the_separate_kernel(gp_handle, ft):
+@pytest.mark.parametrize("ft,N,M,P", [(np.float32, 4096, 128, 2), (np.float64, 4096, 128, 2), ((np.float64, np.float32), 4096, 128, 2),
+                                      (np.float64, 8192, 512, 1), (np.float32, 8192, 256, 2)])
+def test_fused_stationary_contraction_agrees_with_the_separate_kernel(gp_handle, ft, N, M, P):
     """With the inducing inputs fixed and whole 128-tiles, a stationary family's Kuf-side contraction runs as the epilogue of
     its Kuf_bar product (gemm_strip.hip role 5 / gemm_f32.hip KT >= 0); with them free the generic contraction kernel reads
     the stored strip.  Same forward pass, same weights (in float32: the value the strip holds), so the activation kernels'
     variance / lengthscale gradients of the two models may differ by summation order only."""
     from gpitch_amd.pdgp import Pdgp
     from gpitch_amd.synth import make_problem, kernels_from_problem
-    prob = make_problem(4096, 128, 2, num_partials=3, seed=11)
+    prob = make_problem(N, M, P, num_partials=3, seed=11)        # (M = 512: the bench's 4 x 4 tile grid; 256: cfg3's)
     grads = []
     for fixed in (True, False):
         m = Pdgp(prob["x"], prob["y"], [prob["za"], prob["zc"]], kernels_from_problem(prob), handle=gp_handle, float_type=ft)
-        for i in range(2):
+        for i in range(P):
             m.q_mu_act[i].value = prob["q_mu_act"][i]; m.q_mu_com[i].value = prob["q_mu_com"][i]
             m.q_sqrt_act[i].value = prob["q_sqrt_act"][i]; m.q_sqrt_com[i].value = prob["q_sqrt_com"][i]
         m.likelihood.variance = prob["noise_var"]
