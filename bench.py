@@ -502,6 +502,10 @@ def main():
             gem = sum(tm[k][0] for k in ("cond_A", "cond_LTA", "nt_gemm", "kuf_bar")) / args.steps
             cfg3[ft] = {"value": args.steps / r3["elapsed"], "unit": "steps/s", "ms_per_step": r3["elapsed"] / args.steps * 1e3,
                         "strip_gemm_ms_per_step": gem, "elbo_final": r3["elbo_final"]}
+            if ft != "mixed":       # whole step against the matrix peak of its strips' type (5 M^2 N per latent GP)
+                pk = PEAK_F32_MFMA_TFLOPS if ft == "f32" else PEAK_F64_MFMA_TFLOPS
+                tf = 5.0 * 256.0 * 256.0 * args.N * 2 * args.P / (r3["elapsed"] / args.steps) / 1e12
+                cfg3[ft]["mfma_frac_step"] = {"achieved": tf, "peak": pk, "unit": "TFLOP/s", "frac": tf / pk}
             r3 = None
             torch.cuda.empty_cache()
         cfg3["dtype"] = "f32"
