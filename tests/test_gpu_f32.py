@@ -363,7 +363,8 @@ def test_f32_adam_trajectory_stays_with_the_f64_one_on_cfg3(gp_handle):
     from gpitch_amd.synth import make_problem
     prob = make_problem(32768, 256, 12, num_partials=5, seed=1)
     out = {}
-    for ft in (np.float32, np.float64):
+    MIXED = (np.float64, np.float32)
+    for ft in (np.float32, np.float64, MIXED):
         m = _model(prob, gp_handle, float_type=ft)
         m.za.fixed = True
         m.zc.fixed = True
@@ -383,6 +384,15 @@ def test_f32_adam_trajectory_stays_with_the_f64_one_on_cfg3(gp_handle):
           % (d_fun, d_ls, moved, d_hyp, d_q))
     assert moved > 0.05                      # the lengthscales did train (50 steps x lr 0.0025 on the free state)
     assert d_fun <= 5e-5 and d_ls <= 2e-4 and d_hyp <= 2e-4 and d_q <= 1e-2
+    # per-GP precision (activation GPs float64, component GPs float32): the same 50 steps.  STATED BOUNDS (measured in brackets):
+    # `fun` 1e-9 (1.3e-11), activation lengthscales 1e-7 (1.0e-9), every hyper-parameter 5e-7 (4.8e-9), q_mu 5e-6 (1.6e-7)
+    c = out[MIXED]
+    m_fun = abs(c["fun"] - b["fun"]) / abs(b["fun"])
+    m_ls = np.max(np.abs(c["ls_act"] - b["ls_act"]) / b["ls_act"])
+    m_hyp = np.max(np.abs(c["hyp"] - b["hyp"]) / np.abs(b["hyp"]))
+    m_q = np.max(np.abs(c["q_mu"] - b["q_mu"])) / np.max(np.abs(b["q_mu"]))
+    print("50 Adam steps mixed vs f64: fun %.2e, activation lengthscales %.2e, hyper-parameters %.2e, q_mu %.2e" % (m_fun, m_ls, m_hyp, m_q))
+    assert m_fun <= 1e-9 and m_ls <= 1e-7 and m_hyp <= 5e-7 and m_q <= 5e-6
 
 
 def test_lds_resident_f32_products_opt_in():
