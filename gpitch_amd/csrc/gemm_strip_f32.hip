@@ -37,7 +37,10 @@ typedef f4 __attribute__((address_space(1))) * gfptr4;
 #define FS_TILE (FS_BT * FS_BK)          // floats per operand tile: fragment (ks = k / 4, t = row or column tile) at (8 ks + t) * 64
 #define FS_STAGE (2 * FS_TILE)
 #define FS_V0_OFF (2 * FS_STAGE)         // (floats) 128 doubles behind the stages: v0[i0 .. i0 + 127]
-#define FS_BYTES ((size_t)(2 * FS_STAGE) * sizeof(float) + FS_BT * sizeof(double))
+#ifndef FS_PAD_BYTES
+#define FS_PAD_BYTES 0                // occupancy probe: extra dynamic LDS per workgroup (one workgroup per CU above 16 KiB)
+#endif
+#define FS_BYTES ((size_t)(2 * FS_STAGE) * sizeof(float) + FS_BT * sizeof(double) + FS_PAD_BYTES)
 
 struct Strip32Flags {
   int tilesM, tilesN, tm0;
@@ -53,12 +56,22 @@ __device__ __forceinline__ gcbytes fs_uniform(gcbytes p) {
 
 // TAG 1: op(A) = W (lower), k-contiguous float64.  TAG 2: op(A) = Lq^T (upper; Lq read row-wise), K walked downwards.
 // TAG 3: op(A) = R dense, B(k, n) *= v1[n].  B, C: float32 strips.
-template <int TAG>
-__global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProblem* __restrict__ probs, Strip32Flags f) {
+// BK: K-tile depth, 32 (two workgroups per CU: 64 KiB of LDS stages each) or 16 (32 KiB and <= 168 VGPRs: three per CU — the
+// short K loops of the triangular products at M = 256 / 512 are latency, and a third resident workgroup hides more of it
+// than the shorter K-tile costs.  Same k-step order for roles 1 and 3 (bit-identical results); role 2 walks its K-tiles
+// downwards, so its sums are taken in another order: float32 rounding, inside the stated tolerance)
+// (The contracting form of the dense product — gemm_f32.hip's — was also built on this kernel and measured: its launch is
+// shorter, 1.51 vs 1.86 ms on cfg3, and the step LONGER, 4.40 vs 4.11 ms: that launch shares the device with the split-K product
+// and the M x M chain on the helper stream, and three resident workgroups of it per CU leave them no room.  Not kept.)
+template <int TAG, int BK>
+__global__ void __launch_bounds__(256, (BK == 16) ? 3 : 2) gemm_strip_f32_kernel(const GemmProblem* __restrict__ probs, Strip32Flags f) {
+  constexpr int NH = BK / 16;                // 16-row halves of a K-tile
+  constexpr int EA = BK / 2;                 // k-contiguous A: elements per thread
+  constexpr int KTILE = FS_BT * BK, KSTAGE = 2 * KTILE, KV0_OFF = 2 * KSTAGE;
   constexpr bool TA = (TAG == 2);
   constexpr bool KDOWN = (TAG == 2);
   constexpr int TRI = (TAG == 1) ? TRI_LOWER : (TAG == 2) ? TRI_UPPER : TRI_NONE;
-  constexpr int TM = 8, TN = 2, NKS = FS_BK / 4;
+  constexpr int TM = 8, TN = 2, NKS = BK / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int bid = blockIdx.x, bz = blockIdx.z;
   {
@@ -77,10 +90,10 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
   int kbeg = 0, kend = p.K;
   if (TRI == TRI_LOWER) kend = min(kend, i0 + FS_BT);
   if (TRI == TRI_UPPER) kbeg = max(kbeg, i0);
-  const int nkt = (kend - kbeg) / FS_BK;
+  const int nkt = (kend - kbeg) / BK;
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
-  double* v0s = reinterpret_cast<double*>(smem + FS_V0_OFF);
+  double* v0s = reinterpret_cast<double*>(smem + KV0_OFF);
   if ((f.epi & EPI_COLDOT) && tid < FS_BT) v0s[tid] = ((gcptr)p.v0)[i0 + tid];
 
   // ---- staging maps ------------------------------------------------------------------------------------------------
@@ -88,19 +101,19 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
   // A, row-wise     (TAG 2)   : thread -> k rows a_k = tid / 16 and a_k + 16, row pairs a_i + 32 q, a_i = 2 (tid & 15)
   // B (float32, row-contiguous): thread -> k rows b_k = tid / 16 and b_k + 16, column quads b_n + 64 q, b_n = 4 (tid & 15)
   const int a_i = TA ? (tid & 15) * 2 : (tid >> 1);
-  const int a_k = TA ? (tid >> 4) : (tid & 1) * 16;
+  const int a_k = TA ? (tid >> 4) : (tid & 1) * EA;
   const int b_k = tid >> 4, b_n = (tid & 15) * 4;
   const uint32_t voffA = TA ? (uint32_t)(((int64_t)a_k * p.lda + i0 + a_i) * 8) : (uint32_t)(((int64_t)(i0 + a_i) * p.lda + a_k) * 8);
   const uint32_t voffB = (uint32_t)(((int64_t)b_k * p.ldb + j0 + b_n) * 4);
-  const int kfirst = KDOWN ? kend - FS_BK : kbeg;
-  const int64_t stepA = (KDOWN ? -1 : 1) * (TA ? (int64_t)FS_BK * p.lda * 8 : (int64_t)FS_BK * 8);
-  const int64_t stepB = (KDOWN ? -1 : 1) * (int64_t)FS_BK * p.ldb * 4;
+  const int kfirst = KDOWN ? kend - BK : kbeg;
+  const int64_t stepA = (KDOWN ? -1 : 1) * (TA ? (int64_t)BK * p.lda * 8 : (int64_t)BK * 8);
+  const int64_t stepB = (KDOWN ? -1 : 1) * (int64_t)BK * p.ldb * 4;
   gcbytes sA = fs_uniform((gcbytes)p.A + (TA ? (int64_t)kfirst * p.lda * 8 : (int64_t)kfirst * 8));
   gcbytes sA2 = fs_uniform((gcbytes)p.A + (TA ? (int64_t)(kfirst + 16) * p.lda * 8 : 0));     // second k row (TAG 2)
   gcbytes sB = fs_uniform((gcbytes)p.B + (int64_t)kfirst * p.ldb * 4);
   gcbytes sB2 = fs_uniform((gcbytes)p.B + (int64_t)(kfirst + 16) * p.ldb * 4);
-  double ra[16];
-  f4 rbX[4], rbY[4];
+  double ra[8 * NH];
+  f4 rbX[2 * NH], rbY[2 * NH];
   float rs[8];
   if (TAG == 3) {
     const gcptr gv1 = (gcptr)p.v1;
@@ -113,34 +126,35 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
     if (TA) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const dbl2 u = *(gcptr2)(sA + voffA + q * 256), v = *(gcptr2)(sA2 + voffA + q * 256);
-        ra[2 * q] = u.x; ra[2 * q + 1] = u.y; ra[8 + 2 * q] = v.x; ra[8 + 2 * q + 1] = v.y;
+        const dbl2 u = *(gcptr2)(sA + voffA + q * 256);
+        ra[2 * q] = u.x; ra[2 * q + 1] = u.y;
+        if (NH == 2) { const dbl2 v = *(gcptr2)(sA2 + voffA + q * 256); ra[8 * (NH - 1) + 2 * q] = v.x; ra[8 * (NH - 1) + 2 * q + 1] = v.y; }
       }
       sA2 = (gcbytes)((int64_t)sA2 + stepA);
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) { const dbl2 v = *(gcptr2)(sA + voffA + e * 8); ra[e] = v.x; ra[e + 1] = v.y; }
+      for (int e = 0; e < EA; e += 2) { const dbl2 v = *(gcptr2)(sA + voffA + e * 8); ra[e] = v.x; ra[e + 1] = v.y; }
     }
     sA = (gcbytes)((int64_t)sA + stepA);
   };
-  auto load_B = [&](f4 (&rb)[4]) {
+  auto load_B = [&](f4 (&rb)[2 * NH]) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) { rb[q] = *(gcfptr4)(sB + voffB + q * 256); rb[2 + q] = *(gcfptr4)(sB2 + voffB + q * 256); }
+    for (int q = 0; q < 2; q++) { rb[q] = *(gcfptr4)(sB + voffB + q * 256); if (NH == 2) rb[2 * (NH - 1) + q] = *(gcfptr4)(sB2 + voffB + q * 256); }
     sB = (gcbytes)((int64_t)sB + stepB);
     sB2 = (gcbytes)((int64_t)sB2 + stepB);
   };
   // LDS write bases (floats) of stage 0
   const int wA = TA ? ((8 * (a_k >> 2) + (a_i >> 4)) * FS_FRAG + 16 * (a_k & 3) + (a_i & 15))
                     : ((8 * (a_k >> 2) + (a_i >> 4)) * FS_FRAG + (a_i & 15));
-  const int wB = FS_TILE + (8 * (b_k >> 2) + (b_n >> 4)) * FS_FRAG + 16 * (b_k & 3) + (b_n & 15);
-  auto store_tiles = [&](const int stage_off, int kt, auto mask_tag, f4 (&rb)[4]) {
+  const int wB = KTILE + (8 * (b_k >> 2) + (b_n >> 4)) * FS_FRAG + 16 * (b_k & 3) + (b_n & 15);
+  auto store_tiles = [&](const int stage_off, int kt, auto mask_tag, f4 (&rb)[2 * NH]) {
     constexpr bool MASK = decltype(mask_tag)::value;
     float* As = smem + stage_off + wA;
     float* Bs = smem + stage_off + wB;
     if (TA) {
       // element (row pair i = a_i + 32 q, k row a_k [+ 16]): non-zero iff k >= i
 #pragma unroll
-      for (int h = 0; h < 2; h++)
+      for (int h = 0; h < NH; h++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           float v0 = (float)ra[8 * h + 2 * q], v1 = (float)ra[8 * h + 2 * q + 1];
@@ -153,14 +167,14 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
         }
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
+      for (int e = 0; e < EA; e++) {
         float v = (float)ra[e];
-        if (MASK && TRI == TRI_LOWER && kt + FS_BK > i0) { if (kt + a_k + e > i0 + a_i) v = 0.f; }
+        if (MASK && TRI == TRI_LOWER && kt + BK > i0) { if (kt + a_k + e > i0 + a_i) v = 0.f; }
         As[(e >> 2) * 8 * FS_FRAG + (e & 3) * 16] = v;
       }
     }
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < NH; h++)
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         f4 v = rb[2 * h + q];
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
   for (int a = 0; a < TM; a++)
 #pragma unroll
     for (int b = 0; b < TN; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-  const int rA = lane, rB = FS_TILE + 2 * wc * FS_FRAG + lane;
+  const int rA = lane, rB = KTILE + 2 * wc * FS_FRAG + lane;
   auto mfma_full = [&](const int stage_off) {
     const float* As = smem + stage_off + rA;
     const float* Bs = smem + stage_off + rB;
@@ -219,10 +233,10 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
   };
   // ---- K loop (gemm_strip.hip's): plain pairs with literal stages and no masks, then the diagonal block ------------------
   {
-    const int kstep = KDOWN ? -FS_BK : FS_BK;
+    const int kstep = KDOWN ? -BK : BK;
     int nplain = nkt;
-    if (TRI == TRI_LOWER) nplain = i0 / FS_BK;
-    if (TRI == TRI_UPPER) nplain = (kend - (i0 + FS_BT)) / FS_BK;
+    if (TRI == TRI_LOWER) nplain = i0 / BK;
+    if (TRI == TRI_UPPER) nplain = (kend - (i0 + FS_BT)) / BK;
     const int npair = (max(0, min(nplain, nkt)) / 2) * 2;
     const std::true_type masked{};
     const std::false_type plain{};
@@ -237,12 +251,12 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
       load_A();
       load_B(rbX);
       mfma_full(0);
-      store_tiles(FS_STAGE, kt + kstep, plain, rbY);
+      store_tiles(KSTAGE, kt + kstep, plain, rbY);
       __syncthreads();
       kt += kstep;
       load_A();
       if (it + 3 < nkt) load_B(rbY);
-      mfma_full(FS_STAGE);
+      mfma_full(KSTAGE);
       store_tiles(0, kt + kstep, plain, rbX);
       __syncthreads();
       kt += kstep;
@@ -251,13 +265,13 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_kernel(const GemmProble
       load_A();
       if (it + 2 < nkt) load_B(rbX);
       mfma_diag(0, kt);
-      store_tiles(FS_STAGE, kt + kstep, masked, rbY);
+      store_tiles(KSTAGE, kt + kstep, masked, rbY);
       __syncthreads();
       kt += kstep;
       const bool more = (it + 2 < nkt);
       if (more) load_A();
       if (it + 3 < nkt) load_B(rbY);
-      mfma_diag(FS_STAGE, kt);
+      mfma_diag(KSTAGE, kt);
       if (more) store_tiles(0, kt + kstep, masked, rbX);
       __syncthreads();
       kt += kstep;
@@ -474,8 +488,9 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_f32_nt_kernel(const GemmPro
   }
 }
 
-template <int TAG>
+template <int TAG, int BK>
 static gp_status launch_strip32(gp_handle h, const GemmProblem* d_probs, int batch, int M, int N, const GemmFlags& f) {
+  constexpr size_t BYTES = (size_t)(4 * FS_BT * BK) * sizeof(float) + FS_BT * sizeof(double) + FS_PAD_BYTES;
   Strip32Flags sf;
   sf.tilesM = M / FS_BT; sf.tilesN = N / FS_BT; sf.tm0 = f.tile_m0; sf.epi = f.epilogue; sf.alpha = (float)f.alpha;
   if (f.tile_m0 > 0 || f.tile_mcount > 0) {
@@ -486,10 +501,10 @@ static gp_status launch_strip32(gp_handle h, const GemmProblem* d_probs, int bat
   static std::atomic<uint32_t> attr_devs{0};
   const uint32_t bit = 1u << (h->device & 31);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_strip_f32_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_BYTES));
+    GP_HIP_CHECK(h, hipFuncSetAttribute((const void*)gemm_strip_f32_kernel<TAG, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES));
     attr_devs.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gemm_strip_f32_kernel<TAG>), dim3(sf.tilesM * sf.tilesN, 1, batch), dim3(256), FS_BYTES, h->stream, d_probs, sf);
+  hipLaunchKernelGGL((gemm_strip_f32_kernel<TAG, BK>), dim3(sf.tilesM * sf.tilesN, 1, batch), dim3(256), BYTES, h->stream, d_probs, sf);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -499,15 +514,19 @@ bool launch_gemm_strip_f32_lean(gp_handle h, const GemmProblem* d_probs, int bat
   static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0);
   // MEASURED (same box, headline shape, overlap 0, against gemm_f32.hip's 8-wavefront kernels): A = W Kuf 2.46 -> 2.41 ms,
   // Lq^T A 2.13 -> 2.00, Kuf_bar 3.59 -> 3.73 (slower), split-K product 2.57 -> 2.58: the float32 products are not bound by
-  // the K loop's vector instructions the way the float64 ones are.  Roles 1 and 2 take the lean form, 3 and 4 stay.
-  static const int roles = getenv("GP_STRIP32_ROLES") ? atoi(getenv("GP_STRIP32_ROLES")) : 3;     // bit (role - 1)
+  // the K loop's vector instructions the way the float64 ones are.  With 16-deep K-tiles and three workgroups per CU (below)
+  // the dense product's lean form passes the 8-wavefront kernel too (cfg3 4.12 -> 4.10 ms, headline shape 12.75 -> 12.63):
+  // roles 1-3 take the lean form, the split-K product stays.
+  static const int roles = getenv("GP_STRIP32_ROLES") ? atoi(getenv("GP_STRIP32_ROLES")) : 7;     // bit (role - 1)
   if (!enabled || !f.uniform_aligned || f.role < 1 || f.role > 3 || !((roles >> (f.role - 1)) & 1)) return false;
   if ((maxM % FS_BT) != 0 || (maxN % FS_BT) != 0 || f.beta != 0.0 || f.triC != TRI_NONE) return false;
   if (f.role == 3 ? !(f.alpha == 1.0 || f.alpha == 2.0 || f.alpha == 0.5 || f.alpha == 4.0) : (f.alpha != 1.0)) return false;
   if (f.role == 3 && f.scale_mode != 1) return false;
-  if (f.role == 1) *st = launch_strip32<1>(h, d_probs, batch, maxM, maxN, f);
-  else if (f.role == 2) *st = launch_strip32<2>(h, d_probs, batch, maxM, maxN, f);
-  else *st = launch_strip32<3>(h, d_probs, batch, maxM, maxN, f);
+  // K-tile depth of the two forward products: 16 (three workgroups per CU) or 32 (two); GP_FS_BK selects (A/B)
+  static const int bk = getenv("GP_FS_BK") ? atoi(getenv("GP_FS_BK")) : 16;
+  if (f.role == 1) *st = (bk == 16) ? launch_strip32<1, 16>(h, d_probs, batch, maxM, maxN, f) : launch_strip32<1, 32>(h, d_probs, batch, maxM, maxN, f);
+  else if (f.role == 2) *st = (bk == 16) ? launch_strip32<2, 16>(h, d_probs, batch, maxM, maxN, f) : launch_strip32<2, 32>(h, d_probs, batch, maxM, maxN, f);
+  else *st = (bk == 16) ? launch_strip32<3, 16>(h, d_probs, batch, maxM, maxN, f) : launch_strip32<3, 32>(h, d_probs, batch, maxM, maxN, f);
   return true;
 }
 
