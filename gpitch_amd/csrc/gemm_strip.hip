@@ -66,6 +66,9 @@ extern "C" int gp_debug_strip_stamps(unsigned long long* host, int max_records) 
 #define GS_STAMP(i) do { } while (0)
 #endif
 
+#ifndef GS_PAD_BYTES
+#define GS_PAD_BYTES 0      // occupancy probe: extra dynamic LDS per workgroup (one workgroup per CU from ~16 KiB on)
+#endif
 struct StripFlags {
   int tilesM, tilesN, tm0;
   int epi;            // EPI_* bitmask
@@ -79,7 +82,7 @@ template <bool TA> struct StripSmem {
   static constexpr int STAGE = A_ELEMS + B_ELEMS;
   static constexpr int V0_OFF = 2 * STAGE;               // 128 doubles behind the stages: v0[i0 .. i0 + 127] (EPI_COLDOT)
   static constexpr int SINK_OFF = V0_OFF + GS_BM;        // 4 x 32 doubles: the L2-warming loads' sink, one per wavefront
-  static constexpr size_t BYTES = (size_t)(2 * STAGE + GS_BM + 4 * 32) * sizeof(double);
+  static constexpr size_t BYTES = (size_t)(2 * STAGE + GS_BM + 4 * 32) * sizeof(double) + GS_PAD_BYTES;
 };
 
 __device__ __forceinline__ gcbytes gs_uniform(gcbytes p) {
