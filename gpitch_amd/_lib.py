@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "gp_pdgp_set_workspace", "gp_pdgp_set_precision", "gp_pdgp_set_gp_precision", "gp_pdgp_set_grad_needs", "gp_pdgp_set_overlap", "gp_pdgp_elbo", "gp_pdgp_elbo_begin", "gp_pdgp_elbo_end", "gp_pdgp_create_subset", "gp_pdgp_cond_begin", "gp_pdgp_cond_end", "gp_pdgp_predict", "gp_pdgp_predict_reuse",
     "gp_overlap_merge", "gp_transform_register_logistic", "gp_transform_forward", "gp_transform_backward", "gp_poll_not_pd", "gp_check_not_pd", "gp_take_not_pd", "gp_adam_step",
     "gp_sgpr_create", "gp_sgpr_destroy", "gp_sgpr_num_params", "gp_sgpr_workspace_bytes", "gp_sgpr_set_workspace", "gp_sgpr_set_precision",
-    "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_exchange_doubles", "gp_sgpr_bound_begin", "gp_sgpr_bound_end", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_f_full", "gp_sgpr_predict_source_full", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
+    "gp_sgpr_bound", "gp_sgpr_bound_grad", "gp_sgpr_residual_grad", "gp_sgpr_exchange_doubles", "gp_sgpr_bound_begin", "gp_sgpr_bound_end", "gp_sgpr_set_graphs", "gp_sgpr_eval_counts", "gp_sgpr_predict_f", "gp_sgpr_predict_f_full", "gp_sgpr_predict_source_full", "gp_sgpr_predict_source_workspace_bytes", "gp_sgpr_predict_source",
     "gp_sgprb_create", "gp_sgprb_destroy", "gp_sgprb_num_params", "gp_sgprb_num_windows", "gp_sgprb_workspace_bytes",
     "gp_sgprb_set_workspace", "gp_sgprb_bound_grad", "gp_sgprb_set_graphs", "gp_sgprb_eval_counts",
     "gp_sgprb_predict_f", "gp_sgprb_predict_source_workspace_bytes", "gp_sgprb_predict_source",
@@ -157,6 +157,7 @@ def load_library():
         "gp_sgpr_set_precision": (i32, [vp, i32]),
         "gp_sgpr_bound": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl)]),
         "gp_sgpr_bound_grad": (i32, [vp, vp, vp, vp, i32, vp, vp, C.POINTER(dbl), vp]),
+        "gp_sgpr_residual_grad": (i32, [vp, vp, vp, i32, vp]),
         "gp_sgpr_exchange_doubles": (i64, [vp]),
         "gp_sgpr_bound_begin": (i32, [vp, vp, vp, vp, i32, vp, vp]),
         "gp_sgpr_bound_end": (i32, [vp, vp, vp, vp, i32, i64, vp, vp, vp, C.POINTER(dbl), vp, i32]),

@@ -49,6 +49,7 @@ struct gp_sgpr_plan_s {
   bool skip_upload = false;                    // set while re-enqueueing with valid device descriptors
   int graphs = 1;                              // gp_sgpr_set_graphs
   int64_t n_eager = 0, n_captured = 0, n_replayed = 0;
+  const double* grad_Y = nullptr; int grad_N = -1;     // data of the last bound + gradient evaluation (gp_sgpr_residual_grad)
   // frame-sharded evaluation: what gp_sgpr_bound_begin staged for gp_sgpr_bound_end
   int staged_N = -1; const double* staged_params = nullptr; const double* staged_X = nullptr;
   ~gp_sgpr_plan_s() { if (gexec) (void)hipGraphExecDestroy(gexec); }
@@ -57,6 +58,7 @@ struct gp_sgpr_plan_s {
 static inline int64_t ldN64(int N) { return (N + 1) & ~1; }
 // any other entry point rewrites the device descriptor blocks the recorded graph reads
 static inline void sg_invalidate(gp_sgpr_plan_s* p) {
+  p->grad_Y = nullptr; p->grad_N = -1;
   p->desc_valid = false;
   if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
 }
@@ -119,6 +121,24 @@ __global__ void __launch_bounds__(256) sgpr_c_kernel(const double* __restrict__ 
   for (int k = l; k <= i; k += 64) acc = fma(WB[(int64_t)i * M + k], u[k], acc);
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if (l == 0) c[i] = acc / params[0];
+}
+
+// r[n] = sum_i A'[i][n] dFdu[i] - y[n] / s2 = d bound / d err_n (err = Y - mean_function(X), sgpr_ss.py:40): what a trainable
+// mean function's parameters are differentiated through.  One thread per frame, the strip read once (coalesced rows).
+__global__ void __launch_bounds__(256) sgpr_resid_grad_kernel(const double* __restrict__ A, int64_t ld, int a_f32,
+                                                              const double* __restrict__ dFdu, const double* __restrict__ y,
+                                                              int M, int N, const double* __restrict__ params,
+                                                              double* __restrict__ r) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  double acc = 0.0;
+  if (a_f32) {
+    const float* Af = reinterpret_cast<const float*>(A);
+    for (int i = 0; i < M; i++) acc = fma((double)Af[(int64_t)i * ld + n], dFdu[i], acc);
+  } else {
+    for (int i = 0; i < M; i++) acc = fma(A[(int64_t)i * ld + n], dFdu[i], acc);
+  }
+  r[n] = acc - y[n] / params[0];
 }
 
 // The bound scalar from c = WB (u / s2) (sgpr_c_kernel), diag(LB) and the scalars.  One block.
@@ -743,6 +763,20 @@ gp_status gp_sgpr_eval_counts(gp_sgpr_plan p, int64_t* eager, int64_t* captured,
   return GP_OK;
 }
 
+// d bound / d err (N doubles on the device) of the evaluation gp_sgpr_bound_grad has just run with the same params / Y / N:
+// A'^T (dF/du) - err / sigma^2, from the strip and the dF/du vector that evaluation left in the workspace.
+gp_status gp_sgpr_residual_grad(gp_sgpr_plan p, const double* params, const double* Y, int32_t N, double* r_dev) {
+  if (!p) return GP_ERR_BAD_ARG;
+  gp_handle h = p->h;
+  if (!p->ws || !params || !Y || !r_dev || N < 1 || N > p->maxN) return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_residual_grad: bad argument");
+  if (p->grad_Y != Y || p->grad_N != N)
+    return gp_fail(h, GP_ERR_BAD_ARG, "gp_sgpr_residual_grad: call it right after gp_sgpr_bound_grad with the same Y and N");
+  hipLaunchKernelGGL(sgpr_resid_grad_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, p->A, gp_strip_ld(N, p->f32 != 0),
+                     p->f32, p->ubar, Y, p->M, N, params, r_dev);
+  GP_HIP_CHECK(h, hipGetLastError());
+  return GP_OK;
+}
+
 gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                              const double* Z, double* bound_dev, double* bound_host, double* grad) {
   if (!p) return GP_ERR_BAD_ARG;
@@ -787,6 +821,7 @@ gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double*
     p->desc_key = key; p->desc_valid = true;
     p->n_eager++;
   }
+  p->grad_Y = Y; p->grad_N = N;
   if (bound_dev) GP_HIP_CHECK(h, hipMemcpyAsync(bound_dev, p->scal, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (bound_host) {
     GP_HIP_CHECK(h, hipMemcpyAsync(bound_host, p->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -28,8 +28,9 @@ class SGPRSS(Parameterized):
         built with the full X, Y; it uploads only its contiguous slice, and each bound / gradient evaluation
         exchanges one all-reduce of M^2 + M + 2 doubles (plus one of the small gradient vector): see
         include/gpitch_abi.h gp_sgpr_bound_begin / _end.  Predictions need the whole window on one GPU."""
-        # mean_function (sgpr_ss.py:14,25): a fixed function of the inputs, subtracted from Y in the bound (:40) and in
-        # the exact posterior (:90), added back to predicted means (:95); see mean_functions.py
+        # mean_function (sgpr_ss.py:14,25): subtracted from Y in the bound (:40) and in the exact posterior (:90), added back
+        # to predicted means (:95); gpitch_amd.mean_functions.Constant / Linear carry trainable Params as GPflow's do
+        # (optimize() trains them unless .fixed), any other callable is a fixed function of the inputs
         if mean_function is not None and not callable(mean_function):
             raise TypeError("mean_function must be callable on an (n, 1) array (gpitch_amd.mean_functions)")
         object.__setattr__(self, "mean_function", mean_function)
@@ -127,13 +128,23 @@ class SGPRSS(Parameterized):
         fr = self._frames()
         self._dev("_params", host)
         self._dev("_Xd", self.X._array[fr])
-        yv = self.Y._array[fr]
-        if self.mean_function is not None:          # err = Y - mean_function(X)
-            yv = yv - np.asarray(self.mean_function(self.X._array[fr]), dtype=np.float64).reshape(yv.shape)
-        self._dev("_Yd", yv)
+        self._dev("_Yd", self._err_host())
         self._dev("_Zd", self.Z._array)
         object.__setattr__(self, "_n_local", fr.stop - fr.start)
         object.__setattr__(self, "_obj_state", None)      # Param values / .fixed flags may have changed
+
+    def _err_host(self):
+        """err = Y - mean_function(X) on this rank's frames (sgpr_ss.py:40)"""
+        fr = self._frames()
+        yv = self.Y._array[fr]
+        if self.mean_function is not None:
+            yv = yv - np.asarray(self.mean_function(self.X._array[fr]), dtype=np.float64).reshape(yv.shape)
+        return yv
+
+    def _mean_params(self):
+        """trainable Params of the mean function (gpflow.mean_functions.Constant.c, Linear.A / .b), [] for a plain callable"""
+        mf = self.mean_function
+        return list(mf.params()) if (mf is not None and hasattr(mf, "params") and hasattr(mf, "grad_from_residual")) else []
 
     def _bound(self, grad=None):
         """one evaluation of the bound (and gradient into the device vector `grad`) on this model's frames; the
@@ -244,7 +255,7 @@ class SGPRSS(Parameterized):
         ps = [self.likelihood.variance]
         for k in self.kern.kern_list:
             ps.extend(k.theta_params())
-        return ps
+        return ps + self._mean_params()     # (after the engine's parameter vector: they live on the host)
 
     def _objective_setup(self):
         """vectorised view of the free state for _objective (rebuilt by optimize(): .fixed flags, transforms and the
@@ -295,13 +306,33 @@ class SGPRSS(Parameterized):
         y, dy = self._free_to_params(st, x_free)
         vals = st["vals0"].copy()
         vals[st["free_idx"]] = y
-        self._dev("_params", vals)
+        nd = self._nparams                        # the engine's parameters; the mean function's follow them
+        mps = self._mean_params()
+        train_mean = bool(mps) and bool(np.any(st["free_idx"] >= nd))
+        if train_mean:                            # a new mean function: new residuals (same device buffer: the recorded
+            for p_, v in zip(mps, vals[nd:]):     # launch sequence stays valid)
+                p_._array = np.array([v], dtype=np.float64)
+            self._dev("_Yd", self._err_host())
+        self._dev("_params", vals[:nd])
         grad = self.__dict__.get("_grad_dev")
-        if grad is None or grad.numel() != self._nparams:
-            grad = h.empty(self._nparams)
+        if grad is None or grad.numel() != nd:
+            grad = h.empty(nd)
             object.__setattr__(self, "_grad_dev", grad)
         value = self._bound(grad)
         g = grad.cpu().numpy()
+        if mps:
+            gm = np.zeros(len(mps))
+            if train_mean:
+                if self._shard:
+                    raise NotImplementedError("trainable mean-function Params of a frame-sharded window")
+                r = self.__dict__.get("_resid_dev")
+                if r is None or r.numel() != self._n_local:
+                    r = h.empty(self._n_local)
+                    object.__setattr__(self, "_resid_dev", r)
+                h.check(h.lib.gp_sgpr_residual_grad(self._plan, self._params.data_ptr(), self._Yd.data_ptr(), self._n_local,
+                                                    r.data_ptr()))
+                gm = np.concatenate(self.mean_function.grad_from_residual(self.X._array[self._frames()], r.cpu().numpy()))
+            g = np.concatenate([g, gm])
         return -value, -(g[st["free_idx"]] * dy)
 
     def optimize(self, method='L-BFGS-B', tol=None, callback=None, maxiter=1000, disp=False, **kw):

@@ -342,6 +342,11 @@ gp_status gp_sgpr_bound(gp_sgpr_plan p, const double* params, const double* X, c
  * transcription.py:283, separation.py:298).  grad has gp_sgpr_num_params entries. */
 gp_status gp_sgpr_bound_grad(gp_sgpr_plan p, const double* params, const double* X, const double* Y, int32_t N,
                              const double* Z, double* bound_dev, double* bound_host, double* grad);
+/* d bound / d err_n, err = Y - mean_function(X) (sgpr_ss.py:40), of the evaluation gp_sgpr_bound_grad has JUST run with the same
+ * params, Y and N: r = A'^T (dF/du) - err / sigma^2, N doubles on the device.  This is what a GPflow mean function's trainable
+ * Params (gpflow.mean_functions.Constant.c, Linear.A / .b; sgpr_ss.py:14,25) are differentiated through — TF autodiff in the
+ * reference: d bound / d theta_m = - sum_n r_n d mean(x_n) / d theta_m.  GP_ERR_BAD_ARG when no such evaluation precedes it. */
+gp_status gp_sgpr_residual_grad(gp_sgpr_plan p, const double* params, const double* Y, int32_t N, double* r_dev);
 
 /* One window sharded over its FRAMES across several GPUs (one process per GPU; SURVEY 8e: "SGPRSS single large
  * window").  Each rank holds a slice (X, Y) of N frames; Z and params are replicated.  The collapsed bound couples

@@ -289,6 +289,66 @@ def test_sgprss_mean_function(gp_handle):
         SGPRSS(X, Y, np.sum(ks), Z, mean_function=3.0, handle=gp_handle)
 
 
+@pytest.mark.parametrize("ft", [np.float64, np.float32])
+def test_sgprss_trainable_mean_function(gp_handle, ft):
+    """GPflow mean functions carry trainable Params (Constant.c, Linear.A / .b; sgpr_ss.py:14,25,40): their gradient comes from
+    d bound / d err on the device (gp_sgpr_residual_grad) and the chain rule on the host.  Residual gradient and the A, b
+    entries against torch autograd through the oracle; then L-BFGS-B moves them (a data offset the zero-mean GP cannot
+    explain cheaply) and improves the bound beyond what the kernel parameters alone reach."""
+    import torch
+    from oracle.backend import TorchBackend
+    from gpitch_amd.mean_functions import Linear, Constant
+    from gpitch_amd.matern12_spectral_mixture import MercerMatern12sm
+    from gpitch_amd.sgpr_ss import SGPRSS
+    X, Y, Z, kl = _problem(1200, 40, 2, 11)
+    Y = Y + 0.8 + 1.5 * X                                  # an offset and a trend in the data
+    mk = lambda: [MercerMatern12sm(1, energy=np.array(d["energy"]), frequency=np.array(d["frequency"]), variance=d["variance"],
+                                   lengthscales=d["lengthscales"]) for d in kl]
+    mf = Linear(0.4, 0.1)
+    m = SGPRSS(X, Y, np.sum(mk()), Z, mean_function=mf, handle=gp_handle, float_type=ft)
+    m.likelihood.variance = 0.3
+    m._compile(); m._pack()
+    ps = m._param_list()
+    assert ps[-2] is mf.A and ps[-1] is mf.b
+    x0 = np.array([p.transform.backward(p.value)[0] for p in ps])
+    f, gfree = m._objective(x0)
+    # reference: autograd through the oracle with A, b (and Y) as leaves
+    tb = TorchBackend()
+    A_t = torch.tensor(0.4, dtype=torch.float64, requires_grad=True)
+    b_t = torch.tensor(0.1, dtype=torch.float64, requires_grad=True)
+    Y_t = torch.tensor(Y, requires_grad=True)
+    X_t = torch.tensor(X)
+    bound = orc.sgpr_bound(X_t, Y_t - (A_t * X_t + b_t), torch.tensor(Z), kl, torch.tensor(0.3, dtype=torch.float64), xp=tb)
+    bound.backward()
+    tol_b, tol_g = (1e-9, 2e-7) if ft is np.float64 else (2e-4, 5e-3)
+    assert abs(-f - float(bound.detach())) <= tol_b * abs(float(bound.detach()))
+    got_A, got_b = -gfree[-2], -gfree[-1]                  # (identity transform: free state = value)
+    scale = max(abs(float(A_t.grad)), abs(float(b_t.grad)))
+    assert abs(got_A - float(A_t.grad)) <= tol_g * scale and abs(got_b - float(b_t.grad)) <= tol_g * scale, (got_A, got_b, A_t.grad, b_t.grad)
+    r = m._resid_dev.cpu().numpy()                         # d bound / d err = d bound / d Y
+    ref_r = Y_t.grad.numpy().reshape(-1)
+    assert np.abs(r - ref_r).max() <= tol_g * np.abs(ref_r).max()
+    if ft is np.float32:
+        return
+    # a fixed mean Param stays put and gets no gradient work; the free one trains
+    m2 = SGPRSS(X, Y, np.sum(mk()), Z, mean_function=Constant(0.0), handle=gp_handle)
+    m2.likelihood.variance = 0.3
+    for k in m2.kern.kern_list:
+        k.lengthscales.fixed = True
+    m2.mean_function.c.fixed = True
+    r_fixed = m2.optimize(maxiter=12)
+    assert m2.mean_function.c.value[0] == 0.0
+    m3 = SGPRSS(X, Y, np.sum(mk()), Z, mean_function=Linear(0.0, 0.0), handle=gp_handle)
+    m3.likelihood.variance = 0.3
+    for k in m3.kern.kern_list:
+        k.lengthscales.fixed = True
+    r_free = m3.optimize(maxiter=12)
+    assert r_free.fun < r_fixed.fun - 1.0, (r_free.fun, r_fixed.fun)
+    assert abs(m3.mean_function.b.value[0]) > 0.05 or abs(m3.mean_function.A.value[0]) > 0.05
+    # the model's own bound at the trained Params is the optimiser's last objective
+    assert abs(m3.build_likelihood() + r_free.fun) <= 1e-9 * abs(r_free.fun)
+
+
 def test_full_cov_predictions_match_oracle(gp_handle):
     """full_cov=True of SGPR.build_predict and SGPRSS.build_predict_source (sgpr_ss.py:95-99): n x n x 1 covariances"""
     X, Y, Z, kl = _problem(600, 40, 2, 11)
