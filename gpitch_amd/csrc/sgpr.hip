@@ -739,7 +739,7 @@ gp_status gp_sgpr_bound_end(gp_sgpr_plan p, const double* params, const double* 
   SgDesc d;
   sg_desc_ptrs(p, 0, &d);
   GP_CHECK(sgpr_global(p, params, (int)N_total, &d));
-  if (grad) GP_CHECK(sgpr_backward(p, params, X, Y, N, (int)N_total, Z, grad, include_replicated, d));
+  if (grad) { GP_CHECK(sgpr_backward(p, params, X, Y, N, (int)N_total, Z, grad, include_replicated, d)); p->grad_Y = Y; p->grad_N = N; }   // (gp_sgpr_residual_grad: this rank's slice)
   if (bound_dev) GP_HIP_CHECK(h, hipMemcpyAsync(bound_dev, p->scal, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (bound_host) {
     GP_HIP_CHECK(h, hipMemcpyAsync(bound_host, p->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -323,8 +323,6 @@ class SGPRSS(Parameterized):
         if mps:
             gm = np.zeros(len(mps))
             if train_mean:
-                if self._shard:
-                    raise NotImplementedError("trainable mean-function Params of a frame-sharded window")
                 r = self.__dict__.get("_resid_dev")
                 if r is None or r.numel() != self._n_local:
                     r = h.empty(self._n_local)
@@ -332,6 +330,9 @@ class SGPRSS(Parameterized):
                 h.check(h.lib.gp_sgpr_residual_grad(self._plan, self._params.data_ptr(), self._Yd.data_ptr(), self._n_local,
                                                     r.data_ptr()))
                 gm = np.concatenate(self.mean_function.grad_from_residual(self.X._array[self._frames()], r.cpu().numpy()))
+                if self._shard:                   # a frame-sharded window: every rank holds its slice's share of the sums
+                    from .dist import allreduce_sum_
+                    gm = allreduce_sum_(h.torch.as_tensor(gm)).numpy()
             g = np.concatenate([g, gm])
         return -value, -(g[st["free_idx"]] * dy)
 

@@ -252,6 +252,17 @@ def test_frame_sharded_window_matches_unsharded(gp_handle, world, reg):
         gsum += g
     gf, gs = g_full.cpu().numpy(), gsum.cpu().numpy()
     np.testing.assert_allclose(gs, gf, rtol=1e-8, atol=1e-9 * np.abs(gf).max())
+    # d bound / d err (gp_sgpr_residual_grad: what trainable mean-function Params are differentiated through): each rank's
+    # slice of it is the unsharded vector's slice
+    r_full = h.empty(1101)
+    h.check(h.lib.gp_sgpr_residual_grad(full._plan, full._params.data_ptr(), full._Yd.data_ptr(), 1101, r_full.data_ptr()))
+    pieces = []
+    for m in shards:
+        rr = h.empty(m._n_local)
+        h.check(h.lib.gp_sgpr_residual_grad(m._plan, m._params.data_ptr(), m._Yd.data_ptr(), m._n_local, rr.data_ptr()))
+        pieces.append(rr.cpu().numpy())
+    rf = r_full.cpu().numpy()
+    np.testing.assert_allclose(np.concatenate(pieces), rf, rtol=0, atol=1e-9 * np.abs(rf).max())
     # end without a matching begin is refused
     with pytest.raises(Exception):
         m = shards[0]
