@@ -174,3 +174,42 @@ def test_headline_launch_against_the_oracle_N32768_M512_P12_m20(gp_handle):
                                    [prob["q_sqrt_com"][p]])
     for got_l, ref_l in zip((ma, va, mc, vc, ms), r):
         np.testing.assert_allclose(got_l[p], ref_l[0], rtol=0, atol=1e-7 * max(np.abs(ref_l[0]).max(), 1e-3))
+
+
+def test_headline_backward_launch_against_autograd_N32768_M512_P12_m20(gp_handle):
+    """The BACKWARD pass of the launch bench.py times (make_problem(32768, 512, 12, num_partials=20, seed=0), inducing
+    inputs fixed as in demo-modgp.py:40-41 = the bench's state): every gradient block — noise, the 24 kernels' variance /
+    lengthscale / energies / frequencies, q_mu and tril(q_sqrt) of the 24 latent GPs — against torch autograd through the
+    oracle (TF reverse mode of pdgp.py:133-170) at the full 4 x 4-tile x 24-GP grid, which is the shape at which the
+    split-K product, the dense Kuf_bar product, the contraction fused into its epilogue (stationary family) and the
+    row-streaming contraction (spectral-mixture family) run in the benchmark.  Bound: 2e-5 of each block's largest entry
+    (cond(Kuu) ~ 1e9 on the activation side: both sides carry cond * eps), as at M = 512, P = 1 in test_gpu_pdgp.py."""
+    from gpitch_amd.synth import make_problem
+    from helpers import oracle_elbo_and_grads, model_grad_dict
+    prob = make_problem(32768, 512, 12, num_partials=20, seed=0)
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model.za.fixed = True
+    model.zc.fixed = True
+    model._pack()
+    f = model._elbo(True)
+    got_g = model_grad_dict(model)
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    print("headline ELBO (gradient pass): HIP %.12e oracle %.12e" % (f, ref_f))
+    assert abs(f - ref_f) <= FULLSIZE_RTOL * abs(ref_f), (f, ref_f)
+    worst = {}
+    for name, rg in ref_g.items():
+        if name.startswith("za") or name.startswith("zc"):
+            continue                                   # fixed: not part of the step
+        gg = got_g[name]
+        if name.startswith("q_sqrt"):
+            rg = np.tril(rg[:, :, 0])[:, :, None]
+            assert np.all(np.triu(gg[:, :, 0], 1) == 0)
+        scale = max(np.abs(rg).max(), 1e-12)
+        worst[name] = np.abs(gg.reshape(rg.shape) - rg).max() / scale
+    by_kind = {}
+    for k, v in worst.items():
+        kind = k.rstrip("0123456789").split(".")[-1] + ("(act)" if "act" in k else "(com)" if "com" in k else "")
+        by_kind[kind] = max(by_kind.get(kind, 0.0), v)
+    print("headline gradient, worst relative deviation per block kind:", {k: "%.1e" % v for k, v in sorted(by_kind.items())})
+    bad = {k: v for k, v in worst.items() if v > 2e-5}
+    assert not bad, bad
