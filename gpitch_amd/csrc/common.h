@@ -243,7 +243,12 @@ struct GemmFlags {
   int aux_ktype = -1;
   int uniform_aligned = 0;            // the caller vouches: every problem has M = maxM (= K structure), N = maxN, 16-byte
                                       // aligned operands with even leading dimensions (gemm_strip.hip's lean form)
+  int rows64_ok = 0;                  // roles 1, 2: the caller has sized o0 / o1 for one partial row per 64-ROW tile and asked
+                                      // gemm_wave_takes() how many rows the launch will write (gemm_wave.hip)
 };
+// gemm_wave.hip: the strip products without LDS or barriers, a 64 x 64 tile per wavefront (true = taken, status in *st)
+bool launch_gemm_wave(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f, gp_status* st);
+bool gemm_wave_takes(int role, int maxM, int maxN, int uniform_aligned);
 bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                             gp_status* st);
 bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype);

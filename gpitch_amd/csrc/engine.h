@@ -97,6 +97,7 @@ struct CondBatch {
   // per-GP precision: tasks [0, n64) keep float64 strips, tasks [n64, G) have float32 ones (CondTask::f32); -1 = uniform
   // (all float64 or, with f32 set, all float32).  cond_batch_upload checks the order and sets it.
   int n64 = -1;
+  bool wave_a = false, wave_lta = false;   // A = W Kuf / Lq^T A of the float64 tasks take gemm_wave.hip's form (64-row partial rows)
   // grouped covariance builds (one launch per kernel family)
   struct Group { int type = 0, m = 0, first = 0, maxM = 0; bool f32 = false; std::vector<int> members; };
   std::vector<Group> groups;

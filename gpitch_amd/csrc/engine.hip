@@ -10,7 +10,7 @@
 
 size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten, bool f32) {
   const size_t strip = gp_strip_doubles((size_t)M, N, f32);
-  const int rb = gemm_rowblocks(M, 1);
+  const int rb = (M + 63) / 64;      // partial-sum rows: one per 64-row tile (gemm_wave.hip; the 128-row forms use half of them)
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   add((size_t)M * M); add((size_t)M * M);          // L, W
@@ -24,7 +24,7 @@ size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten, bool f32) {
 
 bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten, bool f32) {
   const size_t strip = gp_strip_doubles((size_t)t.M, N, f32);
-  const int rb = gemm_rowblocks(t.M, 1);
+  const int rb = (t.M + 63) / 64;
   t.L = ar.take<double>((size_t)t.M * t.M);
   t.W = ar.take<double>((size_t)t.M * t.M);
   t.Tblk = ar.take<double>((size_t)CB_NB * t.M);
@@ -91,10 +91,14 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   GemmProblem* f2 = (GemmProblem*)(cb.h_desc.data() + cb.off_f2);
   char* fin = cb.h_desc.data() + cb.off_finish;
   cb.maxM = 0;
+  for (int g = 0; g < G; g++) if (cb.tasks[g].M > cb.maxM) cb.maxM = cb.tasks[g].M;
+  // which strip products of the float64 tasks take the wave form (one partial row per 64-row tile instead of per 128)
+  const int uni = cond_batch_uniform(cb, N);
+  cb.wave_a = gemm_wave_takes(1, cb.maxM, N, uni);
+  cb.wave_lta = whiten && gemm_wave_takes(2, cb.maxM, N, uni);
   for (int g = 0; g < G; g++) {
     const CondTask& t = cb.tasks[g];
     const int64_t ldN = gp_strip_ld(N, t.f32);
-    if (t.M > cb.maxM) cb.maxM = t.M;
     cp[g] = t.L; wp[g] = t.W; Ms[g] = t.M; lds[g] = t.M;
     GemmProblem p;
     memset(&p, 0, sizeof(p));
@@ -112,9 +116,10 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
     p.M = t.M; p.N = N; p.K = t.M;
     p.o0 = t.s2;
     f2[g] = p;
-    const int rb = gemm_rowblocks(t.M, 1);
-    cond_finish_fill(fin + g * cond_finish_item_bytes(), t.s1, rb, t.s2, t.q_sqrt ? rb : 0, t.dot, rb, t.kern,
-                     t.fmean, t.fvar);
+    const int rb = gemm_rowblocks(t.M, 1), rb64 = t.M / 64;
+    const int rb_a = (cb.wave_a && !t.f32) ? rb64 : rb, rb_lta = (cb.wave_lta && !t.f32) ? rb64 : rb;
+    cond_finish_fill(fin + g * cond_finish_item_bytes(), t.s1, rb_a, t.s2, t.q_sqrt ? rb_lta : 0, t.dot,
+                     whiten ? rb_a : rb, t.kern, t.fmean, t.fvar);
   }
   // Grouped covariance builds: the latent GPs are sorted into kernel families (type, padded partial count); each
   // family's Kuu (and Kuf) matrices are built by ONE launch (48 + 36 launches per step at P = 12 otherwise, which
@@ -382,6 +387,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     f.triA = TRI_LOWER; f.big_tiles = 1; f.timer = GP_TIMER_COND_A; f.role = 1;
     f.epilogue = EPI_STORE | EPI_COLSUMSQ | (whiten ? EPI_COLDOT : 0);
     f.uniform_aligned = cond_batch_uniform(cb, N);
+    f.rows64_ok = cb.wave_a ? 1 : 0;
     static const bool early_ok = !(getenv("GP_COND_A_EARLY") && atoi(getenv("GP_COND_A_EARLY")) == 0);   // A/B switch
     const bool early = early_ok && forked && cb.diag_ready && cb.maxM > 128 &&
                        hipStreamWaitEvent(h->stream, h->ev_diag, 0) == hipSuccess;
@@ -418,6 +424,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     f.transA = 1; f.triA = TRI_UPPER; f.big_tiles = 1; f.timer = GP_TIMER_COND_LTA; f.role = 2;
     f.epilogue = EPI_COLSUMSQ;
     f.uniform_aligned = whiten ? cond_batch_uniform(cb, N) : 0;
+    f.rows64_ok = cb.wave_lta ? 1 : 0;
     GP_CHECK(strips(cb.off_f2, f));
   }
   // 6. fmean / fvar

@@ -607,7 +607,11 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
                               const GemmFlags& f) {
   if (batch <= 0 || maxM <= 0 || maxN <= 0) return GP_OK;
   GpTimerScope ts(h, f.timer);
-  {   // whole aligned strips: the form whose K loop issues no vector-ALU instructions (gemm_strip.hip)
+  {   // whole aligned strips: a 64 x 64 tile per wavefront, no LDS, no barrier (gemm_wave.hip) ...
+    gp_status st = GP_OK;
+    if ((f.role == 3 || f.rows64_ok) && launch_gemm_wave(h, d_probs, batch, maxM, maxN, f, &st)) return st;
+  }
+  {   // ... or the form whose K loop issues no vector-ALU instructions (gemm_strip.hip)
     gp_status st = GP_OK;
     if (launch_gemm_strip_lean(h, d_probs, batch, maxM, maxN, f, &st)) return st;
   }

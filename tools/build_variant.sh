@@ -9,7 +9,7 @@ NAME=$1; FILE=$2; FLAGS=$3
 CS=$ROOT/gpitch_amd/csrc
 mkdir -p $ROOT/tools/ab
 make -s -C $CS >/dev/null
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=on $FLAGS -c $CS/$FILE -o $ROOT/tools/ab/${NAME}_${FILE%.hip}.o 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=on $FLAGS -c $CS/$FILE -o $ROOT/tools/ab/${NAME}_${FILE%.hip}.o
 OBJS=""
 for f in $CS/*.o; do
   if [ "$(basename $f)" == "${FILE%.hip}.o" ]; then OBJS="$OBJS $ROOT/tools/ab/${NAME}_${FILE%.hip}.o"; else OBJS="$OBJS $f"; fi
