@@ -152,11 +152,13 @@ static int hy_rows_for(int n1, int n2) { return ((int64_t)n1 * n2 >= (1 << 20)) 
 size_t hyper_kuf_records(int N, int M) {
   const size_t generic = ((size_t)(N + HY_THREADS - 1) / HY_THREADS + 1) * ((size_t)(M + HY_ROWS - 1) / HY_ROWS + 1);
   const size_t mfma = (size_t)(M + 63) / 64 * 32 + 1;  // hyper_sm_rows_kernel: groups of four row tiles x <= 32 column segments
+  const size_t fused = ((size_t)(M + 63) / 64) * ((size_t)(N + 63) / 64);   // the Kuf_bar product's epilogue: one per 64 x 64 tile
   // small form: only while M * N' < 2^20
   const int64_t nsmall = (M > 0) ? (((int64_t)1 << 20) + M - 1) / M : 0;
   const int64_t ncap = nsmall < N ? nsmall : N;
   const size_t small = ((size_t)(ncap + HY_THREADS - 1) / HY_THREADS + 1) * ((size_t)(M + HY_ROWS_SMALL - 1) / HY_ROWS_SMALL + 1);
   size_t r = generic > mfma ? generic : mfma;
+  if (fused > r) r = fused;
   return r > small ? r : small;
 }
 
@@ -1790,7 +1792,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       const auto& fam = p->hy_fams[fi];
       if (!ffuse[fi]) return kuf_bar(fslot[fi], fam.count);
       GP_CHECK(kuf_bar(fslot[fi], fam.count, fam.type, fam.f32));
-      for (int g : fam.gps) np_uf[g] = (maxM / 128) * (n / 128);
+      for (int g : fam.gps) np_uf[g] = fam.f32 ? (maxM / 128) * (n / 128) : gemm_fused_contraction_records(maxM, n, fam.type);
       return GP_OK;
     };
     bool any_fused = false;

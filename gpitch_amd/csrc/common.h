@@ -249,6 +249,7 @@ struct GemmFlags {
 // gemm_wave.hip: the strip products without LDS or barriers, a 64 x 64 tile per wavefront (true = taken, status in *st)
 bool launch_gemm_wave(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f, gp_status* st);
 bool gemm_wave_takes(int role, int maxM, int maxN, int uniform_aligned);
+int gemm_fused_contraction_records(int maxM, int maxN, int ktype);
 bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                             gp_status* st);
 bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype);

@@ -609,7 +609,7 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
   GpTimerScope ts(h, f.timer);
   {   // whole aligned strips: a 64 x 64 tile per wavefront, no LDS, no barrier (gemm_wave.hip) ...
     gp_status st = GP_OK;
-    if ((f.role == 3 || f.rows64_ok) && launch_gemm_wave(h, d_probs, batch, maxM, maxN, f, &st)) return st;
+    if ((f.role == 3 || f.role == 5 || f.rows64_ok) && launch_gemm_wave(h, d_probs, batch, maxM, maxN, f, &st)) return st;
   }
   {   // ... or the form whose K loop issues no vector-ALU instructions (gemm_strip.hip)
     gp_status st = GP_OK;

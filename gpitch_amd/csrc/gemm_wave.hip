@@ -57,13 +57,18 @@ struct WaveFlags {
   double alpha;       // role 3: a power of two, folded into the column scales
   int N;              // frames (row stride of the partial-sum arrays)
   int pad_;
+  const double* xcols; // role 5: the frames x (the B strip's columns; not part of any descriptor: pdgp.hip pdgp_bind)
 };
 
 // One 64 x 64 tile: rows [i0, i0 + 64) of op(A) x columns [j0, j0 + 64) of B over k in [kbeg, kend) (multiples of 8).
 // TAG 1: op(A) = A lower triangular (k < i0 + 64; zeros above the diagonal are IN the matrix).  TAG 2: op(A) = A^T with A
-// lower triangular (k >= i0), walked downwards.  TAG 3: dense.
-template <int TAG>
-__device__ __forceinline__ void gw_tile(const GemmProblem& p, const WaveFlags& f, const int i0, const int j0, const int lane) {
+// lower triangular (k >= i0), walked downwards.  TAG 3: dense.  TAG 5 (KT = a stationary kernel type): TAG 3's product with the
+// Kuf-side hyper-gradient contraction of that kernel as its epilogue (gemm_strip.hip role 5; bwd.hip hyper_contract_kernel:
+// sum_ij (Kuf_bar_ij + alpha_i gm_j) dK_ij / d(variance, lengthscale)), nothing stored: one partial record per wavefront tile.
+template <int TAG, int KT = -1>
+__device__ __forceinline__ void gw_tile(const GemmProblem& p, const WaveFlags& f, const int i0, const int j0, const int lane,
+                                        double* etab = nullptr) {
+  constexpr bool DENSE = (TAG == 3 || TAG == 5);
   constexpr bool TA = (TAG == 2);
   constexpr bool KDOWN = (TAG == 2);
   const int lc = lane & 15, kq = lane >> 4;
@@ -177,7 +182,7 @@ __device__ __forceinline__ void gw_tile(const GemmProblem& p, const WaveFlags& f
   dbl2 A0[4], A1[4], B0[4], B1[4], B2[4], B3[4];
   load_B(B0); load_B(B1); load_A(A0); load_B(B2);
   GW_WAIT(4);
-  const int nplain = (TAG == 3) ? nch : nch - 8;          // chunks outside the diagonal block: a multiple of 8 (of 4: dense)
+  const int nplain = DENSE ? nch : nch - 8;          // chunks outside the diagonal block: a multiple of 8 (of 4: dense)
   for (int c = 0; c < nplain; c += 4) {
     GW_CHUNK(A0, B0, c0, c4, (load_A(A1), load_B(B3)));
     GW_CHUNK(A1, B1, c0, c4, (load_A(A0), load_B(B0)));
@@ -185,7 +190,7 @@ __device__ __forceinline__ void gw_tile(const GemmProblem& p, const WaveFlags& f
     GW_CHUNK(A1, B3, c0, c4, (load_A(A0), load_B(B2)));
     GW_WAIT(4);
   }
-  if (TAG != 3) {
+  if (!DENSE) {
     GW_DIAG(A0, B0, 0, (load_A(A1), load_B(B3)));
     GW_DIAG(A1, B1, 1, (load_A(A0), load_B(B0)));
     GW_DIAG(A0, B2, 2, (load_A(A1), load_B(B1)));
@@ -202,7 +207,7 @@ __device__ __forceinline__ void gw_tile(const GemmProblem& p, const WaveFlags& f
   // ---- epilogue -------------------------------------------------------------------------------------------------------
   // acc[a][b][r] = C(i0 + ROW(a, r), j0 + 32 (b >> 1) + 2 lc + (b & 1)),  ROW = 16 a + 4 r + kq  (TA: the row permutation
   // is irrelevant — role 2 stores nothing and its column sums run over all 64 rows)
-  if (TAG == 3) {
+  if (DENSE) {
     const gcptr2 gs = (gcptr2)((gcbytes)p.v1 + (int64_t)(j0 + 2 * lc) * 8);
     const dbl2 s0 = gs[0], s1 = gs[16];
     const double sc[4] = {f.alpha * s0.x, f.alpha * s0.y, f.alpha * s1.x, f.alpha * s1.y};
@@ -212,6 +217,63 @@ __device__ __forceinline__ void gw_tile(const GemmProblem& p, const WaveFlags& f
       for (int b = 0; b < 4; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[a][b][r] *= sc[b];
+  }
+  if (TAG == 5) {
+    // per entry the arithmetic of hyper_contract_kernel<1, false, false, KT> (Stationary.euclid_dist expansion included);
+    // the wavefront's own copy of the exp table (LDS operations of one wavefront complete in order: no barrier)
+    etab[lane] = exp2((double)lane * (1.0 / 64.0));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const gcptr th = (gcptr)p.kern.theta;
+    const double var = th[0], ls = th[1], inv_ls = 1.0 / ls;
+    const gcptr gz = (gcptr)p.xa + i0 + kq, gal = (gcptr)p.v0 + i0 + kq;
+    const gcptr2 gx = (gcptr2)((gcptr)f.xcols + j0 + 2 * lc), ggm = (gcptr2)((gcptr)p.v2 + j0 + 2 * lc);
+    const dbl2 x0 = gx[0], x1 = gx[16], g0 = ggm[0], g1 = ggm[16];
+    const double xc[4] = {x0.x, x0.y, x1.x, x1.y}, gmc[4] = {g0.x, g0.y, g1.x, g1.y};
+    double acc_v = 0.0, acc_l = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      double ra[4], ral[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { ra[r] = gz[16 * a + 4 * r] / ls; ral[r] = gal[16 * a + 4 * r]; }
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        __builtin_amdgcn_sched_barrier(0);       // one 16-row tile at a time (the compiler hoists every table read otherwise)
+        const double bcol = xc[b] / ls, bb = __dmul_rn(bcol, bcol), gmj = gmc[b];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const double av = ra[r], aa = __dmul_rn(av, av);
+          const double w = fma(ral[r], gmj, acc[a][b][r]);
+          const double r2 = __dadd_rn(__dadd_rn(-2.0 * __dmul_rn(av, bcol), aa), bb);
+          if (KT == GP_KERN_RBF) {
+            const double e = gp_exp_neg(-0.5 * r2, etab);
+            acc_v = fma(w, e, acc_v);
+            acc_l = fma(w, var * e * r2 * inv_ls, acc_l);
+          } else {
+            double rr, rinv;
+            gp_sqrt_rsqrt_pos(__dadd_rn(r2, 1e-12), rr, rinv);
+            double phi, dphi;
+            if (KT == GP_KERN_MATERN12) { phi = gp_exp_neg(-rr, etab); dphi = -phi; }
+            else if (KT == GP_KERN_MATERN32) {
+              const double s3 = 1.7320508075688772, e = gp_exp_neg(-s3 * rr, etab);
+              phi = (1.0 + s3 * rr) * e; dphi = -3.0 * rr * e;
+            } else {
+              const double s5 = 2.23606797749979, e = gp_exp_neg(-s5 * rr, etab);
+              phi = (1.0 + s5 * rr + (5.0 / 3.0) * rr * rr) * e; dphi = -(5.0 / 3.0) * rr * (1.0 + s5 * rr) * e;
+            }
+            acc_v = fma(w, phi, acc_v);
+            acc_l = fma(w * var * dphi, -r2 * rinv * inv_ls, acc_l);
+          }
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { acc_v += __shfl_down(acc_v, o, 64); acc_l += __shfl_down(acc_l, o, 64); }
+    if (lane == 0) {
+      const gptr out = (gptr)p.o0 + ((int64_t)(i0 / GW_T) * (f.N / GW_T) + j0 / GW_T) * 2;
+      out[0] = acc_v; out[1] = acc_l;
+    }
+    return;
   }
   dbl2 s2[2], sd[2];
   if (f.epi & (EPI_COLSUMSQ | EPI_COLDOT)) {
@@ -298,8 +360,9 @@ __device__ __forceinline__ void gw_tile(const GemmProblem& p, const WaveFlags& f
 #undef GW_SB
 }
 
-template <int TAG>
+template <int TAG, int KT = -1>
 __global__ void __launch_bounds__(256, 2) gemm_wave_kernel(const GemmProblem* __restrict__ probs, WaveFlags f) {
+  __shared__ double etabs[(TAG == 5) ? 4 * 64 : 1];
   // XCD-aware renumbering of the flattened (unit, batch) grid (gemm_strip.hip): blocks b and b + 8 share an XCD and its L2
   int bid = blockIdx.x, bz = blockIdx.z;
   {
@@ -317,8 +380,8 @@ __global__ void __launch_bounds__(256, 2) gemm_wave_kernel(const GemmProblem* __
   const int cg = bid / f.nunits;
   const int u = (bid % f.nunits + cg) % f.nunits;
   const int j0 = cg * 256 + wv * GW_T;
-  if (TAG == 3) {
-    gw_tile<TAG>(p, f, (f.t0 + u) * GW_T, j0, lane);
+  if (TAG == 3 || TAG == 5) {
+    gw_tile<TAG, KT>(p, f, (f.t0 + u) * GW_T, j0, lane, etabs + ((TAG == 5) ? 64 * wv : 0));
   } else {
     // pair (t0 + u, t1 - 1 - u): the longer K range first (every pair starts on the strip's common end: k = 0 for the
     // lower-triangular product, k = K for the upper one), then the shorter one
@@ -337,17 +400,17 @@ static bool gw_enabled() {
 }
 // roles (bitmask 1 << role) the wave form takes; GP_STRIP_WAVE_ROLES is an A/B switch
 static int gw_roles() {
-  static const int r = getenv("GP_STRIP_WAVE_ROLES") ? atoi(getenv("GP_STRIP_WAVE_ROLES")) : ((1 << 1) | (1 << 2) | (1 << 3));
+  static const int r = getenv("GP_STRIP_WAVE_ROLES") ? atoi(getenv("GP_STRIP_WAVE_ROLES")) : ((1 << 1) | (1 << 2) | (1 << 3) | (1 << 5));
   return r;
 }
 
 // would a launch of that role and shape take the wave form?  (engine.hip sizes the partial-sum rows by it: 64-row tiles)
 bool gemm_wave_takes(int role, int maxM, int maxN, int uniform_aligned) {
-  if (!gw_enabled() || !uniform_aligned || role < 1 || role > 3 || !((gw_roles() >> role) & 1)) return false;
+  if (!gw_enabled() || !uniform_aligned || role < 1 || (role > 3 && role != 5) || !((gw_roles() >> role) & 1)) return false;
   return maxM > 0 && (maxM % GW_T) == 0 && (maxN % 256) == 0;
 }
 
-template <int TAG>
+template <int TAG, int KT = -1>
 static gp_status gw_launch(gp_handle h, const GemmProblem* d_probs, int batch, int M, int N, const GemmFlags& f) {
   WaveFlags wf;
   const int tiles = M / GW_T;
@@ -358,10 +421,10 @@ static gp_status gw_launch(gp_handle h, const GemmProblem* d_probs, int batch, i
     if (f.tile_mcount > 0 && 2 * (f.tile_m0 + f.tile_mcount) < tiles) wf.t1 = 2 * (f.tile_m0 + f.tile_mcount);
   }
   const int nt = wf.t1 - wf.t0;
-  wf.nunits = (TAG == 3) ? nt : (nt + 1) / 2;
-  wf.epi = f.epilogue; wf.alpha = f.alpha; wf.N = N; wf.pad_ = 0;
+  wf.nunits = (TAG == 3 || TAG == 5) ? nt : (nt + 1) / 2;
+  wf.epi = f.epilogue; wf.alpha = f.alpha; wf.N = N; wf.pad_ = 0; wf.xcols = f.aux_x;
   dim3 grid(wf.nunits * (N / 256), 1, batch);
-  hipLaunchKernelGGL((gemm_wave_kernel<TAG>), grid, dim3(256), 0, h->stream, d_probs, wf);
+  hipLaunchKernelGGL((gemm_wave_kernel<TAG, KT>), grid, dim3(256), 0, h->stream, d_probs, wf);
   GP_HIP_CHECK(h, hipGetLastError());
   return GP_OK;
 }
@@ -371,9 +434,29 @@ static gp_status gw_launch(gp_handle h, const GemmProblem* d_probs, int batch, i
 bool launch_gemm_wave(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f, gp_status* st) {
   if (!gemm_wave_takes(f.role, maxM, maxN, f.uniform_aligned)) return false;
   if (f.beta != 0.0 || f.triC != TRI_NONE) return false;
-  if (f.role == 3 ? !(f.scale_mode == 1 && (f.alpha == 1.0 || f.alpha == 2.0 || f.alpha == 0.5 || f.alpha == 4.0)) : (f.alpha != 1.0)) return false;
+  if (f.role >= 3 ? !(f.scale_mode == 1 && (f.alpha == 1.0 || f.alpha == 2.0 || f.alpha == 0.5 || f.alpha == 4.0)) : (f.alpha != 1.0)) return false;
+  if (f.role == 5) {       // (the caller has asked gemm_fused_contraction_records first: it cannot fall back from here)
+    if (!f.aux_x || f.tile_m0 || f.tile_mcount) { *st = gp_fail(h, GP_ERR_BAD_ARG, "fused Kuf_bar contraction: bad launch"); return true; }
+    switch (f.aux_ktype) {
+      case GP_KERN_MATERN12: *st = gw_launch<5, GP_KERN_MATERN12>(h, d_probs, batch, maxM, maxN, f); break;
+      case GP_KERN_MATERN32: *st = gw_launch<5, GP_KERN_MATERN32>(h, d_probs, batch, maxM, maxN, f); break;
+      case GP_KERN_MATERN52: *st = gw_launch<5, GP_KERN_MATERN52>(h, d_probs, batch, maxM, maxN, f); break;
+      case GP_KERN_RBF: *st = gw_launch<5, GP_KERN_RBF>(h, d_probs, batch, maxM, maxN, f); break;
+      default: *st = gp_fail(h, GP_ERR_BAD_ARG, "fused Kuf_bar contraction: not a stationary kernel");
+    }
+    return true;
+  }
   if (f.role == 1) *st = gw_launch<1>(h, d_probs, batch, maxM, maxN, f);
   else if (f.role == 2) *st = gw_launch<2>(h, d_probs, batch, maxM, maxN, f);
   else *st = gw_launch<3>(h, d_probs, batch, maxM, maxN, f);
   return true;
+}
+
+// partial records (2 sums each) the fused Kuf_bar contraction of a float64 family leaves per latent GP — 0: no fused form
+// for that shape / kernel type (the separate contraction kernel runs).  One per wavefront tile here, one per 128 x 128 tile
+// in gemm_strip.hip's form.
+int gemm_fused_contraction_records(int maxM, int maxN, int ktype) {
+  if (!gemm_strip_fused_contraction_ok(maxM, maxN, ktype)) return 0;
+  if (gemm_wave_takes(5, maxM, maxN, 1)) return (maxM / GW_T) * (maxN / GW_T);
+  return (maxM / 128) * (maxN / 128);
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of the strip-product forms: kernels alone (tools/valu_probe.py), then the bench step
 mkdir -p gpurun_out
-for cfg in "GP_STRIP_WAVE=0" "GP_STRIP_WAVE=1" "GP_STRIP_WAVE_ROLES=8" "GP_STRIP_WAVE_ROLES=6"; do
+for cfg in "GP_STRIP_WAVE=0" "GP_STRIP_WAVE=1" "GP_STRIP_WAVE_ROLES=14"; do
   echo "== $cfg" >> gpurun_out/ab_wave.txt
   env $cfg python tools/valu_probe.py >> gpurun_out/ab_wave.txt 2>&1 || exit 1
 done
