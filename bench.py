@@ -1,9 +1,12 @@
 """bench.py — ELBO-steps/sec of the Pdgp hot path on MI355X (BASELINE.json metric).
 
 One step = what one iteration of gpflow Model.optimize(method=Adam) does in the reference
-(SURVEY §3.2): fresh (full-size, freshly permuted) batch -> forward ELBO -> gradient w.r.t. every
-non-fixed parameter -> Adam update of the free state.  Workload: N=32768 frames, M=512 inducing
-points per latent GP, P=12 pitches (24 latent GPs), float64, inputs resident in HBM.
+(SURVEY §3.2): batch -> forward ELBO -> gradient w.r.t. every non-fixed parameter -> Adam update of
+the free state.  Workload: N=32768 frames, M=512 inducing points per latent GP, P=12 pitches (24
+latent GPs), float64, inputs resident in HBM.  The batch is the FULL data set (minibatch_size = N):
+the reference's MinibatchData would hand over a permutation of it every step; the ELBO is a sum over
+the batch, so the engine takes the resident x, y in time order — no index draw, sort or gather inside
+the timed step (gpitch_amd/pdgp.py:_batch; equality with the permuted batch: tests/test_gpu_fullsize.py).
 
 Multi-GPU (torchrun, one rank per GPU): the reference scales N by independent windows / segments
 (window_overlap.py:194, transcription.py:265-288), so every rank owns one independent 32768-frame
@@ -24,6 +27,17 @@ sys.path.insert(0, ROOT)
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (vendor sheet); a bare VGPR-accumulator MFMA loop measures 70-76
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X FP32 matrix peak (v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD; guide: 155 measured)
 PEAK_HBM_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def _switch(name, default):
+    """value of one library switch (GPITCH_AMD_SWITCHES="name=value,...": gpitch_amd/csrc/switches.h)"""
+    for item in os.environ.get("GPITCH_AMD_SWITCHES", "").split(","):
+        if item.startswith(name + "="):
+            try:
+                return int(item.split("=", 1)[1])
+            except ValueError:
+                pass
+    return default
 
 
 def build_model(args, rank):
@@ -344,7 +358,7 @@ def main():
     ap.add_argument("--partials", type=int, default=20)
     ap.add_argument("--lr", type=float, default=0.0025)
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline steps (after 2 warm-ups)")
-    ap.add_argument("--cpu-full", type=int, default=0,
+    ap.add_argument("--cpu-full", type=int, default=1,
                     help="also time this many whole P-pitch CPU steps (validates the 1/P scaling; ~1 min each)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--shard", choices=["window", "pitch", "gp"], default="window",
@@ -531,21 +545,27 @@ def main():
                    "kuf_bar": "gemm_f32_kernel<3>"}
         else:
             # (whole aligned strips run gemm_strip.hip's lean forms; ragged shapes fall back to gemm_f64_kernel<128,128,...>)
-            lean = (M % 128 == 0) and (N % 128 == 0) and os.environ.get("GP_STRIP_LEAN", "1") != "0"
+            lean = (M % 128 == 0) and (N % 128 == 0) and _switch("strip_lean", 1) != 0
+            # (... and, M a multiple of 64 and N of 256, gemm_wave.hip's: a 64 x 64 tile per wavefront, no LDS; the split-K
+            #  product stays with gemm_strip_nt_kernel)
+            wave = (M % 64 == 0) and (N % 256 == 0) and _switch("strip_wave", 1) != 0
             # (Kuf_bar is one launch per kernel family: the stationary activation family's — inducing inputs fixed —
             #  contracts its tile with dK/dtheta in the epilogue and stores nothing, gemm_strip_kernel<5, KT = Matern32>)
-            fused = os.environ.get("GP_HYPER_FUSE", "1") != "0" and args.overlap >= 0
+            fused = _switch("hyper_fuse", 1) != 0 and args.overlap >= 0
             sym = ({"cond_A": "gemm_strip_kernel<1,-1>", "cond_LTA": "gemm_strip_kernel<2,-1>", "nt_gemm": "gemm_strip_nt_kernel",
                     "kuf_bar": "gemm_strip_kernel<3,-1> + gemm_strip_kernel<5,1>" if fused else "gemm_strip_kernel<3,-1>"} if lean else
                    {"cond_A": "gemm_f64_kernel<128,128,false,false,1>", "cond_LTA": "gemm_f64_kernel<128,128,true,false,2>",
                     "nt_gemm": "gemm_f64_kernel<128,128,false,true,4>", "kuf_bar": "gemm_f64_kernel<128,128,false,false,3>"})
+            if wave:
+                sym.update({"cond_A": "gemm_wave_kernel<1,-1>", "cond_LTA": "gemm_wave_kernel<2,-1>",
+                            "kuf_bar": "gemm_wave_kernel<3,-1> + gemm_wave_kernel<5,1>" if fused else "gemm_wave_kernel<3,-1>"})
         # roofline (by its definition): the dominant kernel's OWN algorithmic flops per launch / its OWN mean launch
         # duration (HIP events on the stream it is launched on).  At overlap level 2 other kernels share the chip with
         # it (the split-K product on the helper stream), which lengthens its launch: that shows up here, undisguised.
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (tools/make_traffic_json.py)
-            tfile = os.path.join("profiles", "r03", "hbm_traffic.json")
+            tfile = os.path.join("profiles", "r04", "hbm_traffic.json")
             tj = json.load(open(os.path.join(ROOT, tfile)))
             if (N, M, G, args.partials) == (32768, 512, 24, 20) and tj.get("overlap_level", 2) == args.overlap and not f32:
                 # (a timer class whose launches are two symbols: the mean over its launches, one launch of each per step)
@@ -605,14 +625,18 @@ def main():
             "rccl_ranks": (dist.get_world_size() if (dist is not None and args.backend == "nccl") else 0),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if pitch else "weak", "vs_baseline": None, "dtype": args.float_type, "data": "synthetic",
-            "config": {"workload": "pdgp ELBO step (fwd + grad + Adam), N=%d frames x M=%d inducing x P=%d pitches "
-                                   "(2P=%d latent GPs), m=%d partials, %s, full batch; %s"
-                                   % (N, M, args.P, 2 * args.P, args.partials,
-                                      "float32 strips and strip products (float64 Kuu / reductions)" if f32 else "float64",
-                                      ("one model pitch-sharded over the GPUs (all-reduce of 3N+1 doubles per step)"
-                                       if args.shard == "pitch" else
-                                       "one model, its 2P latent GPs dealt over the GPUs (all-gather of (fmean, fvar) per step)")
-                                      if pitch else "one independent window per GPU"),
+            # (kept short: the driver's field cuts at ~100 characters; the long form is "workload_detail")
+            "config": {"workload": "pdgp ELBO step N=%d M=%d P=%d m=%d %s full batch (no index draw), %s"
+                                   % (N, M, args.P, args.partials, "f32 strips" if f32 else "f64",
+                                      ("pitch-sharded" if args.shard == "pitch" else "gp-sharded") if pitch else "window/GPU"),
+                       "workload_detail": "pdgp ELBO step (fwd + grad + Adam), N=%d frames x M=%d inducing x P=%d pitches "
+                                          "(2P=%d latent GPs), m=%d partials, %s, full batch; %s"
+                                          % (N, M, args.P, 2 * args.P, args.partials,
+                                             "float32 strips and strip products (float64 Kuu / reductions)" if f32 else "float64",
+                                             ("one model pitch-sharded over the GPUs (all-reduce of 3N+1 doubles per step)"
+                                              if args.shard == "pitch" else
+                                              "one model, its 2P latent GPs dealt over the GPUs (all-gather of (fmean, fvar) per step)")
+                                             if pitch else "one independent window per GPU"),
                        "N": N, "M": M, "P": args.P, "partials": args.partials, "whiten": True,
                        "parallelism": (("pitch-sharded x%d" if args.shard == "pitch" else "gp-sharded x%d") if pitch
                                        else "window-per-gpu x%d") % world,

@@ -1,5 +1,8 @@
 // abi.hip — extern "C" entry points of libgpitch_hip.so (see include/gpitch_abi.h).
 #include "engine.h"
+#include "switches.h"
+#include <string.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 
@@ -565,3 +568,33 @@ gp_status gp_adam_step(gp_handle h, double* fs, double* params, const double* gr
 }
 
 }  // extern "C"
+
+// ---- run-time switches (switches.h): GPITCH_AMD_SWITCHES="name=value,..." read once --------------------------------------
+const GpSwitches& gp_switches() {
+  static const GpSwitches sw = []() {
+    GpSwitches w;
+    const char* e = getenv("GPITCH_AMD_SWITCHES");
+    if (!e) return w;
+    struct { const char* name; int* slot; } table[] = {
+        {"strip_wave", &w.strip_wave}, {"strip_wave_roles", &w.strip_wave_roles}, {"strip_lean", &w.strip_lean},
+        {"hyper_fuse", &w.hyper_fuse}, {"kufbar_split", &w.kufbar_split}, {"cond_a_early", &w.cond_a_early},
+        {"blocked_256", &w.blocked_256}, {"cov_sum", &w.cov_sum}, {"hyper_sum", &w.hyper_sum}};
+    std::string all(e);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos);
+      if (end == std::string::npos) end = all.size();
+      const std::string item = all.substr(pos, end - pos);
+      pos = end + 1;
+      const size_t eq = item.find('=');
+      if (item.empty()) continue;
+      bool known = false;
+      if (eq != std::string::npos)
+        for (auto& t : table)
+          if (item.compare(0, eq, t.name) == 0 && strlen(t.name) == eq) { *t.slot = atoi(item.c_str() + eq + 1); known = true; }
+      if (!known) fprintf(stderr, "libgpitch_hip: GPITCH_AMD_SWITCHES: unknown switch '%s' ignored (gpitch_amd/csrc/switches.h)\n", item.c_str());
+    }
+    return w;
+  }();
+  return sw;
+}

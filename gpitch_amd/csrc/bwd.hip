@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(HY_THREADS) hyper_contract_sum_kernel(HySumArg
 bool launch_hyper_contract_sum(gp_handle h, const DevKern* kernels, double* const* feats, double* const* partials, int P,
                                const double* x1, int n1, const double* x2, int n2, const double* G, int64_t ldg,
                                const double* alpha, const double* gm, int g32, int* nparts, gp_status* st) {
-  static const bool enabled = !(getenv("GP_HYPER_SUM") && atoi(getenv("GP_HYPER_SUM")) == 0);
+  const bool enabled = gp_switches().hyper_sum != 0;
   if (!enabled || P < 2 || P > 6 || n1 <= 0 || n2 <= 0) return false;
   for (int p = 0; p < P; p++)
     if (kernels[p].type != GP_KERN_MERCER_MATERN12SM || kernels[p].m < 1 || kernels[p].m > 4 || !feats[p] || !partials[p]) return false;
@@ -979,13 +979,17 @@ __global__ void __launch_bounds__(256, 2) hyper_sm_rows_lean_kernel(DevKern k, c
     switch (nt) {                                                                                                  \
       case 1: if (g32) L(1, true); else L(1, false); break;                                                         \
       case 2: if (g32) L(2, true); else L(2, false); break;                                                         \
-      case 3: if (g32) L(3, true); else L(3, false); break;                                                         \
-      default: if (g32) L(4, true); else L(4, false); break;                                                        \
+      default: if (g32) L(3, true); else L(3, false); break;                                                        \
     }                                                                                                              \
   } while (0)
-static bool hyl_enabled() {
-  static const bool on = !(getenv("GP_HYPER_LEAN") && atoi(getenv("GP_HYPER_LEAN")) == 0);
-  return on;
+// Which form contracts a Mercer family's Kuf_bar strip with dK/dtheta: 2 = hyper_sm_rows_lean_kernel (NT = ceil(2 mpad / 16)
+// <= 3 feature tiles, i.e. up to 24 partials, MercerMatern12sm, whole 16-tiles), 1 = hyper_sm_rows_kernel (NT <= 2: up to 16
+// partials; any envelope, ragged shapes), 0 = the generic vector-pipe kernel.  The row-streaming kernels are instantiated
+// only where they compile without register spills: NT = 4 (25-32 partials) spilled 99-135 VGPRs in either form and NT = 3 of
+// the older form 7-26, so those shapes take the generic kernel (profiles/r04/kernel_resource_usage.txt).
+static int hy_rows_form(int nt, bool lean_ok) {
+  if (lean_ok && nt <= 3) return 2;
+  return nt <= 2 ? 1 : 0;
 }
 #define HYR_DISPATCH_ENV(L, NT_, m52, g32)                                             \
   do {                                                                                  \
@@ -996,9 +1000,7 @@ static bool hyl_enabled() {
   do {                                                                                  \
     switch (nt) {                                                                       \
       case 1: HYR_DISPATCH_ENV(L, 1, m52, g32); break;                                  \
-      case 2: HYR_DISPATCH_ENV(L, 2, m52, g32); break;                                  \
-      case 3: HYR_DISPATCH_ENV(L, 3, m52, g32); break;                                  \
-      default: HYR_DISPATCH_ENV(L, 4, m52, g32); break;                                 \
+      default: HYR_DISPATCH_ENV(L, 2, m52, g32); break;                                 \
     }                                                                                   \
   } while (0)
 
@@ -1174,13 +1176,15 @@ gp_status launch_hyper_contract(gp_handle h, DevKern k, const double* x1, int n1
   const int ns = 2 + 2 * k.m;
   const int redw = ns > HY_ROWS ? ns : HY_ROWS;
   size_t sh = ((sm ? (size_t)HY_ROWS * 2 * mp + mp : 0) + 4 * (size_t)redw) * sizeof(double);
-  if (sm && kvals && !gz_partials && !symmetric && alpha && gm) {
+  int col_seg = 0, nseg = 0;
+  if (sm) hyr_geometry(n1, n2, 1, &col_seg, &nseg);
+  const bool lean_ok = sm && k.type == GP_KERN_MERCER_MATERN12SM && (n1 % 16) == 0 && (n2 % 16) == 0 && col_seg <= HYL_CF_MAX &&
+                       (ldg % 2) == 0 && (ldk % 2) == 0 && ((uintptr_t)G % 16) == 0 && ((uintptr_t)kvals % 16) == 0 && ((uintptr_t)f2 % 16) == 0;
+  const int rows_form = sm ? hy_rows_form((2 * mp + 15) / 16, lean_ok) : 0;
+  if (sm && kvals && !gz_partials && !symmetric && alpha && gm && rows_form > 0) {
     // Kuf side with the covariance strip still in memory: the matrix-core form (hyper_sm_rows_kernel)
-    int col_seg = 0, nseg = 0;
-    hyr_geometry(n1, n2, 1, &col_seg, &nseg);
     dim3 gridm((n1 + 63) / 64, 1, nseg);
-    if (hyl_enabled() && (2 * mp + 15) / 16 <= 3 && k.type == GP_KERN_MERCER_MATERN12SM && (n1 % 16) == 0 && (n2 % 16) == 0 && col_seg <= HYL_CF_MAX &&
-        (ldg % 2) == 0 && (ldk % 2) == 0 && ((uintptr_t)G % 16) == 0 && ((uintptr_t)kvals % 16) == 0 && ((uintptr_t)f2 % 16) == 0) {
+    if (rows_form == 2) {
 #define HYL_ONE(NT_, G32_) hipLaunchKernelGGL((hyper_sm_rows_lean_kernel<NT_, G32_>), gridm, dim3(256), 0, h->stream, k, x1, n1, x2, \
                                               n2, G, ldg, alpha, gm, kvals, ldk, f1, f2, partials, col_seg, (const HyperItem*)nullptr)
       HYL_DISPATCH(HYL_ONE, (2 * mp + 15) / 16, g32 != 0);
@@ -1331,12 +1335,14 @@ gp_status launch_hyper_contract_items(gp_handle h, int type, int m, const HyperI
                                       int with_gz, int* nparts, int use_mfma, const double* x2_shared, int g32_items, int lean_items) {
   if (count <= 0) return GP_OK;
   GpTimerScope ts(h, GP_TIMER_HYPER);
-  if (use_mfma && gp_kern_is_mercer(type) && !with_gz) {
-    int col_seg = 0, nseg = 0;
-    hyr_geometry(n1, n2, count, &col_seg, &nseg);
+  int col_seg = 0, nseg = 0;
+  if (gp_kern_is_mercer(type)) hyr_geometry(n1, n2, count, &col_seg, &nseg);
+  const bool lean_ok = lean_items && type == GP_KERN_MERCER_MATERN12SM && (n1 % 16) == 0 && (n2 % 16) == 0 && col_seg <= HYL_CF_MAX;
+  const int rows_form = gp_kern_is_mercer(type) ? hy_rows_form((2 * sm_mpad(m) + 15) / 16, lean_ok) : 0;
+  if (use_mfma && gp_kern_is_mercer(type) && !with_gz && rows_form > 0) {
     dim3 gridm((n1 + 63) / 64, count, nseg);
     DevKern k0{type, m, nullptr};
-    if (lean_items && hyl_enabled() && (2 * sm_mpad(m) + 15) / 16 <= 3 && type == GP_KERN_MERCER_MATERN12SM && (n1 % 16) == 0 && (n2 % 16) == 0 && col_seg <= HYL_CF_MAX) {
+    if (rows_form == 2) {
 #define HYL_ITEMS(NT_, G32_) hipLaunchKernelGGL((hyper_sm_rows_lean_kernel<NT_, G32_>), gridm, dim3(256), 0, h->stream, k0,        \
                                                 (const double*)nullptr, 0, x2_shared, n2, (const double*)nullptr, (int64_t)0,         \
                                                 (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (int64_t)0,   \
@@ -1798,7 +1804,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     bool any_fused = false;
     for (int fi = 0; fi < nfam; fi++) any_fused |= (ffuse[fi] != 0);
     int sm_fam = -1, other_fam = -1, sm_slot = -1, other_slot = -1;
-    static const int split_mode = getenv("GP_KUFBAR_SPLIT") ? atoi(getenv("GP_KUFBAR_SPLIT")) : 2;   // 0 / 1: A/B switches
+    const int split_mode = gp_switches().kufbar_split;   // (switches.h)
     if (split_mode >= 1 && p->hy_fams.size() == 2 && forked && p->overlap >= 2) {
       for (int fi = 0; fi < 2; fi++) {
         if (p->hy_fams[fi].mfma) sm_fam = fi; else other_fam = fi;

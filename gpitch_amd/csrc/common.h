@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "../../include/gpitch_abi.h"
+#include "switches.h"
 
 #define GP_WAVE 64
 
@@ -269,12 +270,8 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
 // uniform_aligned != 0: every problem has M = maxM, K = maxNlong, 16-byte aligned rows (gemm_strip.hip's lean form)
 gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
                                         int nsplit, int sym, int scale_by_k, double alpha, int uniform_aligned = 0);
-// gemm_res_f32.hip: M <= 256, the M x M operand resident in LDS (true = taken)
-bool launch_gemm_res_f32(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f, gp_status* st);
 bool launch_gemm_strip_f32_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                                 gp_status* st);
-bool launch_gemm_strip_f32_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
-                                   int scale_by_k, gp_status* st);
 bool launch_gemm_strip_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
                                int scale_by_k, gp_status* st);
 gp_status launch_tri_inverse_batched(gp_handle h, const double* const* d_L, double* const* d_W, const int* d_M,

@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(COV_THREADS) cov_mercer_sum_kernel(CovSumArgs 
 // workspace (layout of launch_sm_features: x1 block, then x2 block), already current.
 bool launch_kernel_build_sum(gp_handle h, const DevKern* kernels, double* const* feats, int P, const double* x1, int n1,
                              const double* x2, int n2, double* out, int64_t ld, double diag_add, int f32out, gp_status* st) {
-  static const bool enabled = !(getenv("GP_COV_SUM") && atoi(getenv("GP_COV_SUM")) == 0);
+  const bool enabled = gp_switches().cov_sum != 0;
   if (!enabled || P < 2 || P > 8 || n1 <= 0 || n2 <= 0) return false;
   if (x2 == nullptr) { x2 = x1; n2 = n1; }
   const int mp = sm_mpad(kernels[0].m);
@@ -659,216 +659,6 @@ __global__ void __launch_bounds__(1024 / CT, CT == 2 ? 2 : 2) cov_mercer_mfma_ke
   }
 }
 
-// Direct-store form of the kernel above (round 3).  The MFMA operands are SWAPPED: the column (frame) features go in as
-// the first operand — lane lc supplying column pi(lc) of the 16-column tile — and the row (inducing-point) features as the
-// second, so the accumulator holds the TRANSPOSED tile and a lane owns ONE row (lc) and four columns pi(kq + 4 r) of it:
-//     float64 output: pi(c) = 2 (c & 3) + ((c >> 2) & 1) + 8 (c >> 3)   ->  columns 2 kq, 2 kq + 1 | 8 + 2 kq, 9 + 2 kq
-//     float32 output: pi(c) = 4 (c & 3) + (c >> 2)                       ->  columns 4 kq .. 4 kq + 3
-// i.e. 16-byte pieces that leave straight from the accumulator registers, 16 rows x 64 contiguous bytes per instruction:
-// no LDS transposition, no wave barriers, and the separable envelope needs ONE row factor (one exp) per lane and tile
-// instead of four.  The products a * b inside the MFMA commute, so every entry is bit-identical to the other form's.
-// Column factors / scaled inputs of the workgroup's 256 columns live in three small LDS tables (a lane reads the four it
-// needs per tile as two ds_read_b128) so the register count — and four wavefronts per SIMD — stay what they were.
-template <int MPAD, int ENV, int CT, bool PF>
-__global__ void __launch_bounds__(1024 / CT, 8 / CT) cov_mercer_mfma_direct_kernel(const CovItem* __restrict__ items,
-                                                                              const double* __restrict__ x2s, int n2s,
-                                                                              int row_seg) {
-  typedef double d4 __attribute__((ext_vector_type(4)));
-  constexpr int NF = 2 * MPAD, KS = NF / 4, FS = NF + 1;
-  constexpr int WCOLS = 16 * CT, NWV = 256 / WCOLS, NTH = 64 * NWV;
-  const CovItem it = items[blockIdx.y];
-  const cov_gcptr x1 = (cov_gcptr)it.x1;
-  const int n1 = it.n1;
-  const cov_gcptr x2 = (cov_gcptr)((it.n2 >= 0) ? it.x2 : x2s);
-  const int n2 = (it.n2 >= 0) ? it.n2 : n2s;
-  const cov_gptr out = (cov_gptr)it.out;
-  const cov_gcptr gf1 = (cov_gcptr)it.f1, gf2 = (cov_gcptr)it.f2, th = (cov_gcptr)it.k.theta;
-  const int64_t ld = it.ld;
-  const bool F32O = it.f32out != 0;          // (uniform over the workgroup: blockIdx.y = item)
-  __shared__ double zf[2 * CVM_ROWS * FS];             // two chunks of row features (double-buffered)
-  __shared__ double rowa[2 * CVM_ROWS];
-  __shared__ double tile_lo[2 * (CVM_ROWS / 16)], tile_hi[2 * (CVM_ROWS / 16)];
-  __shared__ double etab[GP_EXP_TAB];
-  __shared__ __attribute__((aligned(16))) double cfp_t[256], cfn_t[256], bsc_t[256];
-  gp_exp_tab_init(etab);
-  const double var = th[0], ls = th[1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lc = lane & 15, kq = lane >> 4;
-  const int jw = blockIdx.x * 256 + wave * WCOLS;
-  const int rbeg = blockIdx.z * row_seg, rend = min(n1, rbeg + row_seg);
-  if ((int)(blockIdx.x * 256) >= n2 || rbeg >= n1) return;
-  const int pc = F32O ? (4 * (lc & 3) + (lc >> 2)) : (2 * (lc & 3) + ((lc >> 2) & 1) + 8 * (lc >> 3));   // pi(lc)
-  // column-side operands, loop-invariant: fragment [k = 4 s + kq] of column pi(lc) of each column tile
-  double bfr[CT][KS], bsc_l[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ct++) {
-    const int j = jw + ct * 16 + pc;
-    const bool on = (j < n2);
-    const int jc = on ? j : n2 - 1;
-#pragma unroll
-    for (int s = 0; s < KS; s++) bfr[ct][s] = on ? gf2[(size_t)(4 * s + kq) * n2 + jc] : 0.0;
-    bsc_l[ct] = x2[jc] / ls;
-  }
-  double bmin_w, bmax_w;
-  {
-    double lo = bsc_l[0], hi = bsc_l[0];
-#pragma unroll
-    for (int ct = 1; ct < CT; ct++) { lo = fmin(lo, bsc_l[ct]); hi = fmax(hi, bsc_l[ct]); }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
-    bmin_w = lo; bmax_w = hi;
-  }
-  constexpr double SENV = (ENV == 0) ? 1.0 : 2.23606797749979;
-  const bool sep_ok = (SENV * (bmax_w - bmin_w) < 300.0);
-  __syncthreads();                                                 // etab is ready
-  if (kq == 0) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-      const int c = wave * WCOLS + ct * 16 + pc;
-      bsc_t[c] = bsc_l[ct];
-      cfp_t[c] = var * gp_exp_neg(-SENV * (bmax_w - bsc_l[ct]), etab);
-      cfn_t[c] = var * gp_exp_neg(-SENV * (bsc_l[ct] - bmin_w), etab);
-    }
-  }
-  // this lane's two column pairs inside a 16-column tile, and whether 16-byte stores are legal
-  const int c0 = F32O ? 4 * kq : 2 * kq, c1 = F32O ? 4 * kq + 2 : 8 + 2 * kq;
-  const bool vec = it.vec_ok && (F32O ? ((ld & 3) == 0 && (((uintptr_t)it.out) & 15) == 0) : true);
-  // Row chunks are double-buffered: the next chunk's features travel global -> registers while this chunk's tiles are on
-  // the matrix cores, and go registers -> the other LDS buffer afterwards: one barrier per chunk, no load latency in it.
-  constexpr int ZPT = (CVM_ROWS * NF + NTH - 1) / NTH;          // staged feature values per thread and chunk
-  double zr[ZPT], ar = 0.0, tlo = 0.0, thi = 0.0;
-  auto fetch = [&](int r0) {
-#pragma unroll
-    for (int q = 0; q < ZPT; q++) {
-      const int t = tid + q * NTH, f = t / CVM_ROWS, ii = t % CVM_ROWS;
-      zr[q] = (t < CVM_ROWS * NF && r0 + ii < n1) ? gf1[(size_t)f * n1 + r0 + ii] : 0.0;
-    }
-    if (tid < CVM_ROWS) ar = x1[min(r0 + tid, n1 - 1)] / ls;
-    else if (tid < CVM_ROWS + CVM_ROWS / 16) {
-      const int t16 = (tid - CVM_ROWS) * 16;
-      double lo = x1[min(r0 + t16, n1 - 1)] / ls, hi = lo;
-      for (int q = 1; q < 16; q++) { const double v = x1[min(r0 + t16 + q, n1 - 1)] / ls; lo = fmin(lo, v); hi = fmax(hi, v); }
-      tlo = lo; thi = hi;
-    }
-  };
-  auto stash = [&](int buf) {
-    double* zfb = zf + buf * (CVM_ROWS * FS);
-#pragma unroll
-    for (int q = 0; q < ZPT; q++) {
-      const int t = tid + q * NTH, f = t / CVM_ROWS, ii = t % CVM_ROWS;
-      if (t < CVM_ROWS * NF) zfb[ii * FS + f] = zr[q];
-    }
-    if (tid < CVM_ROWS) rowa[buf * CVM_ROWS + tid] = ar;
-    else if (tid < CVM_ROWS + CVM_ROWS / 16) { tile_lo[buf * (CVM_ROWS / 16) + tid - CVM_ROWS] = tlo; tile_hi[buf * (CVM_ROWS / 16) + tid - CVM_ROWS] = thi; }
-  };
-  fetch(rbeg);
-  stash(0);
-  __syncthreads();                       // (also publishes the column tables)
-  int buf = 0;
-  for (int r0 = rbeg; r0 < rend; r0 += CVM_ROWS, buf ^= 1) {
-    const bool more = (r0 + CVM_ROWS < rend);
-    if (!PF && r0 > rbeg) {              // A/B form without the prefetch: load, store, barrier at the head of every chunk
-      __syncthreads();
-      fetch(r0);
-      stash(buf);
-      __syncthreads();
-    }
-    const double* zfb = zf + buf * (CVM_ROWS * FS);
-    const double* rowab = rowa + buf * CVM_ROWS;
-    const double* tlob = tile_lo + buf * (CVM_ROWS / 16);
-    const double* thib = tile_hi + buf * (CVM_ROWS / 16);
-#pragma unroll
-    for (int rt = 0; rt < CVM_ROWS / 16; rt++) {
-      // the next chunk's loads are issued two tiles before they are needed (short live range: the kernel must stay at 128 VGPRs)
-      if (PF && rt == (CVM_ROWS / 16 >= 2 ? CVM_ROWS / 16 - 2 : 0) && more) fetch(r0 + CVM_ROWS);
-      if (r0 + rt * 16 >= n1) continue;
-      d4 acc[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++) acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < KS; s++) {
-        const double af = zfb[(rt * 16 + lc) * FS + 4 * s + kq];           // row lc of the tile, k = 4 s + kq
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[ct][s], af, acc[ct], 0, 0, 0);
-      }
-      // element r of acc[ct]: row 16 rt + lc, column 16 ct + pi(kq + 4 r) = 16 ct + (r < 2 ? c0 : c1) + (r & 1)   [float64]
-      //                                                                    = 16 ct + c0 + r                          [float32]
-      const double a = rowab[rt * 16 + lc];
-      const int i = r0 + rt * 16 + lc;
-      const bool above = sep_ok && (tlob[rt] - bmax_w >= CVM_SEP), below = sep_ok && (bmin_w - thib[rt] >= CVM_SEP);
-      double res[CT][4];
-      if (above || below) {                 // (wavefront-uniform)
-        const double rf = gp_exp_neg(-SENV * (above ? a - bmax_w : bmin_w - a), etab);
-        const double* cft = (above ? cfp_t : cfn_t) + wave * WCOLS;
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-          const cov_d2 f01 = *reinterpret_cast<const cov_d2*>(cft + ct * 16 + c0), f23 = *reinterpret_cast<const cov_d2*>(cft + ct * 16 + c1);
-          const double cf[4] = {f01.x, f01.y, f23.x, f23.y};
-          cov_d2 b01, b23;
-          if (ENV != 0) {
-            b01 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c0);
-            b23 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c1);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            double e = rf * cf[r];
-            if (ENV != 0) {
-              const double b = (r == 0) ? b01.x : (r == 1) ? b01.y : (r == 2) ? b23.x : b23.y;
-              const double rr = fabs(a - b);
-              e *= 1.0 + SENV * rr + (5.0 / 3.0) * (rr * rr);
-            }
-            res[ct][r] = e * acc[ct][r];
-          }
-        }
-      } else {
-        const double aa = __dmul_rn(a, a), m2a = -2.0 * a;
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-          const cov_d2 b01 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c0);
-          const cov_d2 b23 = *reinterpret_cast<const cov_d2*>(bsc_t + wave * WCOLS + ct * 16 + c1);
-          const double bv[4] = {b01.x, b01.y, b23.x, b23.y};
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            // (-2 (a b) + a a) + b b, every operation rounded on its own (scaling by -2 is exact)
-            const double rr = gp_sqrt_pos(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m2a, bv[r]), aa), __dmul_rn(bv[r], bv[r])), 1e-12));
-            double env;
-            if (ENV == 0) env = gp_exp_neg(-rr, etab);
-            else { const double s5 = 2.23606797749979; env = (1.0 + s5 * rr + (5.0 / 3.0) * (rr * rr)) * gp_exp_neg(-s5 * rr, etab); }
-            res[ct][r] = var * env * acc[ct][r];
-          }
-        }
-      }
-      if (i < n1) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-          const int jb = jw + ct * 16;
-          if (F32O) {
-            const cov_gfptr o = (cov_gfptr)out + (size_t)i * ld + jb + c0;
-            if (vec && jb + c0 + 3 < n2) {
-              typedef float cov_f4 __attribute__((ext_vector_type(4)));
-              __builtin_nontemporal_store(cov_f4{(float)res[ct][0], (float)res[ct][1], (float)res[ct][2], (float)res[ct][3]},
-                                          (cov_f4 __attribute__((address_space(1)))*)o);
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; r++) if (jb + c0 + r < n2) o[r] = (float)res[ct][r];
-            }
-          } else {
-            const cov_gptr o0 = out + (size_t)i * ld + jb + c0, o1 = out + (size_t)i * ld + jb + c1;
-            if (vec && jb + c0 + 1 < n2) __builtin_nontemporal_store(cov_d2{res[ct][0], res[ct][1]}, (cov_gptr2)o0);
-            else { if (jb + c0 < n2) o0[0] = res[ct][0]; if (jb + c0 + 1 < n2) o0[1] = res[ct][1]; }
-            if (vec && jb + c1 + 1 < n2) __builtin_nontemporal_store(cov_d2{res[ct][2], res[ct][3]}, (cov_gptr2)o1);
-            else { if (jb + c1 < n2) o1[0] = res[ct][2]; if (jb + c1 + 1 < n2) o1[1] = res[ct][3]; }
-          }
-        }
-      }
-    }
-    if (PF) {
-      if (more) stash(buf ^ 1);
-      __syncthreads();
-    }
-  }
-}
-
 // Lean free-running form (round 3).  Measured on MI355X (same box, tools/bench_kuf.py): whatever the staged forms above
 // do to the vector work, the m = 20 build takes 0.45 ms; with its stores removed 0.38 ms; the 20 MFMAs of a tile alone
 // are 0.21 ms.  A float64 MFMA occupies the SIMD's vector ALU for its whole 64 cycles — it runs on the float64 vector
@@ -1119,34 +909,23 @@ gp_status launch_kernel_build_items(gp_handle h, int type, int m, const CovItem*
       const int colblk = (max_n2 + 255) / 256;
       int nseg = 1;
       while (nseg < 8 && (int64_t)colblk * count * nseg < 512 && (max_n1 + nseg * 2 - 1) / (nseg * 2) >= 2 * CVM_ROWS) nseg *= 2;
-      static const int direct = getenv("GP_KUF_DIRECT") ? atoi(getenv("GP_KUF_DIRECT")) : 3;   // A/B switch: 0 LDS-transposed stores (round 2), 1 direct stores, 2 direct + prefetched row chunks, 3 lean free-running wavefronts
       constexpr int FREE_NWV = 4;
       // the lean form takes whole tiles of the engine's strips only, rows in segments its LDS tables hold
       // (m <= 8 partials: the build is store-bound either way and the staged form's four wavefronts per SIMD are 6 % ahead)
       // (float32 strips, engine_strips == 2: half the store bytes, so from 5 partials on the lean form wins there too — cfg3
       // 0.18 -> 0.12 ms per launch, same-box)
-      static const int lean_min_mpad = getenv("GP_KUF_LEAN_MINMPAD") ? atoi(getenv("GP_KUF_LEAN_MINMPAD")) : 0;
-      const int min_mpad = lean_min_mpad > 0 ? lean_min_mpad : (engine_strips == 2 ? 8 : 12);
-      const bool lean_ok = (direct == 3) && lean_items && (n2_shared % (16 * CVM_CT * FREE_NWV) == 0) && sm_mpad(m) >= min_mpad;
+      const int min_mpad = (engine_strips == 2 ? 8 : 12);
+      const bool lean_ok = lean_items && (n2_shared % (16 * CVM_CT * FREE_NWV) == 0) && sm_mpad(m) >= min_mpad;
       if (lean_ok) while ((max_n1 + nseg - 1) / nseg > CVL_MAXR) nseg *= 2;
       const int row_seg = ((max_n1 + nseg - 1) / nseg + CVM_ROWS - 1) / CVM_ROWS * CVM_ROWS;
       dim3 gm(colblk, count, (max_n1 + row_seg - 1) / row_seg);
       const dim3 gfree((max_n2 + 16 * CVM_CT * FREE_NWV - 1) / (16 * CVM_CT * FREE_NWV), count, gm.z);
-      const int mode = lean_ok ? 3 : (direct == 3 ? 0 : direct);     // (the lean form's fall-back is the staged round-2 kernel)
 #define COV_MFMA(MP)                                                                                                   \
       do {                                                                                                             \
         if (lean_ok && type == GP_KERN_MERCER_MATERN12SM)                                                              \
           hipLaunchKernelGGL((cov_mercer_mfma_lean_kernel<MP, 0, CVM_CT, FREE_NWV>), gfree, dim3(64 * FREE_NWV), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else if (lean_ok)                                                                                              \
           hipLaunchKernelGGL((cov_mercer_mfma_lean_kernel<MP, 2, CVM_CT, FREE_NWV>), gfree, dim3(64 * FREE_NWV), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (mode == 2 && type == GP_KERN_MERCER_MATERN12SM)                                                       \
-          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 0, CVM_CT, true>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (mode == 2)                                                                                            \
-          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 2, CVM_CT, true>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (mode == 1 && type == GP_KERN_MERCER_MATERN12SM)                                                       \
-          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 0, CVM_CT, false>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
-        else if (mode == 1)                                                                                            \
-          hipLaunchKernelGGL((cov_mercer_mfma_direct_kernel<MP, 2, CVM_CT, false>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else if (type == GP_KERN_MERCER_MATERN12SM)                                                                         \
           hipLaunchKernelGGL((cov_mercer_mfma_kernel<MP, 0, CVM_CT>), gm, dim3(1024 / CVM_CT), 0, h->stream, d_items, x2_shared, n2_shared, row_seg); \
         else                                                                                                           \

@@ -169,7 +169,7 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   // (two panels already pay off for long batches: the factor comes from one resident launch, the first row-block of
   // A = W Kuf starts from W's diagonal blocks — cond_batch_run — and the fused factor + inverse kernel was the head's
   // critical path: 0.46 ms at M = 256)
-  static const bool blk256 = !(getenv("GP_BLOCKED_256") && atoi(getenv("GP_BLOCKED_256")) == 0);     // A/B switch
+  const bool blk256 = gp_switches().blocked_256 != 0;
   cb.blocked = (cb.maxM > 256 || (blk256 && cb.maxM > 128 && cb.N >= 4096)) && cb.nblk <= CB_MAX_PANELS;
   if (cb.blocked) {
     for (int k = 0; k < cb.nblk; k++) {
@@ -388,7 +388,7 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     f.epilogue = EPI_STORE | EPI_COLSUMSQ | (whiten ? EPI_COLDOT : 0);
     f.uniform_aligned = cond_batch_uniform(cb, N);
     f.rows64_ok = cb.wave_a ? 1 : 0;
-    static const bool early_ok = !(getenv("GP_COND_A_EARLY") && atoi(getenv("GP_COND_A_EARLY")) == 0);   // A/B switch
+    const bool early_ok = gp_switches().cond_a_early != 0;
     const bool early = early_ok && forked && cb.diag_ready && cb.maxM > 128 &&
                        hipStreamWaitEvent(h->stream, h->ev_diag, 0) == hipSuccess;
     auto cond_a = [&](int m0, int mcount) -> gp_status {

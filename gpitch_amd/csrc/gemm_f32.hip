@@ -513,7 +513,7 @@ static gp_status launch_f32(gp_handle h, const GemmProblem* d_probs, int batch, 
 }
 
 bool gemm_f32_fused_contraction_ok(int maxM, int maxN, int ktype) {
-  static const bool fuse = !(getenv("GP_HYPER_FUSE") && atoi(getenv("GP_HYPER_FUSE")) == 0);      // A/B switch (as gemm_strip.hip)
+  const bool fuse = gp_switches().hyper_fuse != 0;
   const bool stat = (ktype == GP_KERN_MATERN12 || ktype == GP_KERN_MATERN32 || ktype == GP_KERN_MATERN52 || ktype == GP_KERN_RBF);
   return fuse && stat && maxM > 0 && (maxM % F32_BT) == 0 && (maxN % F32_BT) == 0;
 }
@@ -536,9 +536,8 @@ gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batc
       default: return gp_fail(h, GP_ERR_BAD_ARG, "fused float32 Kuf_bar contraction: not a stationary kernel");
     }
   }
-  {   // small inducing sets: the M x M operand resident in LDS (gemm_res_f32.hip); whole aligned strips: gemm_strip_f32.hip's lean form
+  {   // whole aligned strips: gemm_strip_f32.hip's lean form
     gp_status st = GP_OK;
-    if (launch_gemm_res_f32(h, d_probs, batch, maxM, maxN, gf, &st)) return st;
     if (launch_gemm_strip_f32_lean(h, d_probs, batch, maxM, maxN, gf, &st)) return st;
   }
   Gemm32Flags f;
@@ -559,14 +558,8 @@ gp_status launch_slab_reduce(gp_handle h, const GemmProblem* d_probs, int batch,
 gp_status launch_gemm_f32_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxNlong,
                                             int nsplit, int sym, int scale_by_k, double alpha, int uniform_aligned) {
   if (batch <= 0 || maxM <= 0) return GP_OK;
-  bool lean = false;
-  if (uniform_aligned) {
-    GpTimerScope ts(h, GP_TIMER_NT_GEMM);
-    gp_status st = GP_OK;
-    lean = launch_gemm_strip_f32_nt_lean(h, d_probs, batch, maxM, maxNlong, nsplit > 1 ? nsplit : 2, sym, scale_by_k, &st);
-    if (lean) GP_CHECK(st);
-  }
-  if (!lean) {
+  (void)uniform_aligned;    // (a lean form of this product measured slower than the 8-wavefront kernel: DESIGN.md section 3b)
+  {
     GpTimerScope ts(h, GP_TIMER_NT_GEMM);
     Gemm32Flags f;
     f.alpha = 1.0; f.epi = 1; f.scale = scale_by_k; f.sym = sym; f.ksplit = nsplit > 1 ? nsplit : 2; f.tilesM = f.tilesN = 1;

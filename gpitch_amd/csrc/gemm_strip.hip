@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(256, 2) gemm_strip_nt_kernel(const GemmProblem
 
 bool launch_gemm_strip_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
                                int scale_by_k, gp_status* st) {
-  static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0);    // A/B switch
+  const bool enabled = gp_switches().strip_lean != 0;
   if (!enabled || (M % GS_BM) != 0 || (Nlong % GS_BK) != 0 || nsplit < 2) return false;
   using S = StripSmem<false>;
   StripNtFlags nf;
@@ -745,8 +745,7 @@ static gp_status launch_strip(gp_handle h, const GemmProblem* d_probs, int batch
 // role 5 (Kuf_bar with the stationary hyper-gradient contraction as its epilogue) exists in the lean form only: whether a
 // launch of that shape would take it (pdgp_backward asks before it decides to skip the separate contraction)
 bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype) {
-  static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0);
-  static const bool fuse = !(getenv("GP_HYPER_FUSE") && atoi(getenv("GP_HYPER_FUSE")) == 0);      // A/B switch
+  const bool enabled = gp_switches().strip_lean != 0, fuse = gp_switches().hyper_fuse != 0;
   const bool stat = (ktype == GP_KERN_MATERN12 || ktype == GP_KERN_MATERN32 || ktype == GP_KERN_MATERN52 || ktype == GP_KERN_RBF);
   return enabled && fuse && stat && maxM > 0 && (maxM % GS_BM) == 0 && (maxN % GS_BN) == 0;
 }
@@ -755,7 +754,7 @@ bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype) {
 // vouches that every problem of the batch has M = K-structure maxM, N = maxN, 16-byte aligned operands, even leading dimensions.
 bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                             gp_status* st) {
-  static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0);    // A/B switch
+  const bool enabled = gp_switches().strip_lean != 0;
   if (!enabled || !f.uniform_aligned || f.role < 1 || (f.role > 3 && f.role != 5)) return false;
   if ((maxM % GS_BM) != 0 || (maxN % GS_BN) != 0 || f.beta != 0.0 || f.triC != TRI_NONE) return false;
   if (f.role >= 3 ? !(f.alpha == 1.0 || f.alpha == 2.0 || f.alpha == 0.5 || f.alpha == 4.0) : (f.alpha != 1.0)) return false;

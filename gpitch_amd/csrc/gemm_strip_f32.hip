@@ -330,164 +330,6 @@ __global__ void __launch_bounds__(256, (BK == 16) ? 3 : 2) gemm_strip_f32_kernel
   }
 }
 
-// role 4: H = X diag(d) X^T over the frames, X a float32 strip; float64 slabs, u = X v2 fused (float64 accumulation)
-struct Strip32NtFlags { int tilesM, ksplit, sym, scale; };
-
-__global__ void __launch_bounds__(256, 2) gemm_strip_f32_nt_kernel(const GemmProblem* __restrict__ probs, Strip32NtFlags f) {
-  constexpr int TM = 8, TN = 2, NKS = FS_BK / 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int bid = blockIdx.x, bz = blockIdx.z;
-  {
-    const int nx = gridDim.x, total = nx * (int)gridDim.z;
-    if ((total & 7) == 0) {
-      const int lin = bz * nx + bid;
-      const int log = (lin & 7) * (total >> 3) + (lin >> 3);
-      bz = log / nx; bid = log - bz * nx;
-    }
-  }
-  const GemmProblem p = probs[bz];
-  const int ntl = f.sym ? f.tilesM * (f.tilesM + 1) / 2 : f.tilesM * f.tilesM;
-  const int ksl = bid / ntl, t = bid % ntl;
-  int tm, tn;
-  if (f.sym) {
-    tm = (int)((__dsqrt_rn(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
-    while (tm * (tm + 1) / 2 > t) tm--;
-    tn = t - tm * (tm + 1) / 2;
-  } else { tm = t % f.tilesM; tn = t / f.tilesM; }
-  const int i0 = tm * FS_BT, j0 = tn * FS_BT;
-  if (i0 >= p.M || j0 >= p.N) return;
-  int kbeg, kend;
-  {
-    const int nk = p.K / FS_BK, per = (nk + f.ksplit - 1) / f.ksplit;
-    kbeg = ksl * per * FS_BK;
-    kend = min(p.K, kbeg + per * FS_BK);
-  }
-  const int nkt = (kend > kbeg) ? (kend - kbeg) / FS_BK : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
-  const int lc = lane & 15, kq = lane >> 4;
-  const bool diag_sym = f.sym && (tm == tn);
-  const int ct0 = wc, ct1 = 7 - wc;
-  const int cmin0 = diag_sym ? ct0 : 0, cmin1 = diag_sym ? ct1 : 0;
-  const bool rowdot = (p.v2 != nullptr) && (tn == 0);
-  const bool scale = f.scale && (p.v1 != nullptr);
-  const int s_r = tid >> 1, s_k = (tid & 1) * 16;
-  const uint32_t voffA = (uint32_t)(((int64_t)(i0 + s_r) * p.lda + s_k) * 4);
-  const uint32_t voffB = (uint32_t)(((int64_t)(j0 + s_r) * p.ldb + s_k) * 4);
-  const uint32_t voffK = (uint32_t)(s_k * 8);
-  gcbytes sA = fs_uniform((gcbytes)p.A + (int64_t)kbeg * 4);
-  gcbytes sB = fs_uniform((gcbytes)p.B + (int64_t)kbeg * 4);
-  gcbytes sV1 = fs_uniform((gcbytes)p.v1 + (int64_t)kbeg * 8);
-  gcbytes sV2 = fs_uniform((gcbytes)p.v2 + (int64_t)kbeg * 8);
-  f4 ra[4], rb[4];
-  double rs[16], rg[16], udot = 0.0;
-  auto load_tiles = [&]() {
-#pragma unroll
-    for (int q = 0; q < 4; q++) { ra[q] = *(gcfptr4)(sA + voffA + q * 16); rb[q] = *(gcfptr4)(sB + voffB + q * 16); }
-    if (scale) {
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) { const dbl2 v = *(gcptr2)(sV1 + voffK + e * 8); rs[e] = v.x; rs[e + 1] = v.y; }
-    }
-    if (rowdot) {
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) { const dbl2 v = *(gcptr2)(sV2 + voffK + e * 8); rg[e] = v.x; rg[e + 1] = v.y; }
-    }
-    sA += FS_BK * 4; sB += FS_BK * 4; sV1 += FS_BK * 8; sV2 += FS_BK * 8;
-  };
-  const int wA = (8 * (s_k >> 2) + (s_r >> 4)) * FS_FRAG + (s_r & 15);
-  const int wB = FS_TILE + wA;
-  auto store_tiles = [&](const int stage_off) {
-    float* As = smem + stage_off + wA;
-    float* Bs = smem + stage_off + wB;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const float va = ra[e >> 2][e & 3];
-      float vb = rb[e >> 2][e & 3];
-      if (scale) vb *= (float)rs[e];
-      if (rowdot) udot = fma((double)va, rg[e], udot);
-      As[(e >> 2) * 8 * FS_FRAG + (e & 3) * 16] = va;
-      Bs[(e >> 2) * 8 * FS_FRAG + (e & 3) * 16] = vb;
-    }
-  };
-  f4 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; a++)
-#pragma unroll
-    for (int b = 0; b < TN; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-  const int rA = lane, rB0 = FS_TILE + ct0 * FS_FRAG + lane, rB1 = FS_TILE + ct1 * FS_FRAG + lane;
-  auto mfma_tile = [&](const int stage_off) {
-    const float* As = smem + stage_off + rA;
-    const float* B0 = smem + stage_off + rB0;
-    const float* B1 = smem + stage_off + rB1;
-    __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ks++) {
-      float af[TM];
-      const float bf0 = B0[8 * ks * FS_FRAG], bf1 = B1[8 * ks * FS_FRAG];
-#pragma unroll
-      for (int a = 0; a < TM; a++) af[a] = As[(8 * ks + a) * FS_FRAG];
-#pragma unroll
-      for (int a = 0; a < TM; a++) {
-        if (a >= cmin0) acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf0, acc[a][0], 0, 0, 0);
-        if (a >= cmin1) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf1, acc[a][1], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  if (nkt > 0) {
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
-    int it = 0;
-    for (; it + 2 <= nkt; it += 2) {
-      load_tiles();
-      mfma_tile(0);
-      store_tiles(FS_STAGE);
-      __syncthreads();
-      const bool more = (it + 2 < nkt);
-      if (more) load_tiles();
-      mfma_tile(FS_STAGE);
-      if (more) store_tiles(0);
-      __syncthreads();
-    }
-    if (it < nkt) { mfma_tile(0); __syncthreads(); }
-  }
-  {
-    constexpr int TS = 34;
-    double* tw = reinterpret_cast<double*>(smem) + wc * (32 * TS);       // 4 x 8704 bytes <= 2 stages
-    const int srow = lane >> 4, sc = lane & 15;
-    const int gcol = ((sc < 8) ? ct0 : ct1) * 16 + (sc & 7) * 2;
-    const int lcol = ((sc < 8) ? 0 : 16) + (sc & 7) * 2;
-    const uint32_t voffC = (uint32_t)(((int64_t)(i0 + srow) * p.N + j0 + gcol) * 8);
-    const gcbytes slab = (gcbytes)p.o2 + (int64_t)ksl * p.M * p.N * 8;
-    const int64_t rowstride = (int64_t)p.N * 8;
-#pragma unroll
-    for (int part = 0; part < 4; part++) {
-#pragma unroll
-      for (int a2 = 0; a2 < 2; a2++)
-#pragma unroll
-        for (int b = 0; b < TN; b++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) tw[(a2 * 16 + 4 * kq + r) * TS + b * 16 + lc] = (double)acc[part * 2 + a2][b][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const dbl2 v = *reinterpret_cast<const dbl2*>(tw + (4 * q + srow) * TS + lcol);
-        const gbytes cb = (gbytes)fs_uniform(slab + (int64_t)(part * 32 + 4 * q) * rowstride);
-        *(gptr2)(cb + voffC) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (rowdot) {
-      udot += __shfl_xor(udot, 1, 64);
-      if ((tid & 1) == 0) ((gptr)p.o1)[(int64_t)ksl * p.M + i0 + s_r] = udot;
-    }
-  }
-}
-
 template <int TAG, int BK>
 static gp_status launch_strip32(gp_handle h, const GemmProblem* d_probs, int batch, int M, int N, const GemmFlags& f) {
   constexpr size_t BYTES = (size_t)(4 * FS_BT * BK) * sizeof(float) + FS_BT * sizeof(double) + FS_PAD_BYTES;
@@ -511,41 +353,19 @@ static gp_status launch_strip32(gp_handle h, const GemmProblem* d_probs, int bat
 
 bool launch_gemm_strip_f32_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                                 gp_status* st) {
-  static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0);
+  const bool enabled = gp_switches().strip_lean != 0;
   // MEASURED (same box, headline shape, overlap 0, against gemm_f32.hip's 8-wavefront kernels): A = W Kuf 2.46 -> 2.41 ms,
   // Lq^T A 2.13 -> 2.00, Kuf_bar 3.59 -> 3.73 (slower), split-K product 2.57 -> 2.58: the float32 products are not bound by
   // the K loop's vector instructions the way the float64 ones are.  With 16-deep K-tiles and three workgroups per CU (below)
   // the dense product's lean form passes the 8-wavefront kernel too (cfg3 4.12 -> 4.10 ms, headline shape 12.75 -> 12.63):
   // roles 1-3 take the lean form, the split-K product stays.
-  static const int roles = getenv("GP_STRIP32_ROLES") ? atoi(getenv("GP_STRIP32_ROLES")) : 7;     // bit (role - 1)
-  if (!enabled || !f.uniform_aligned || f.role < 1 || f.role > 3 || !((roles >> (f.role - 1)) & 1)) return false;
+  if (!enabled || !f.uniform_aligned || f.role < 1 || f.role > 3) return false;
   if ((maxM % FS_BT) != 0 || (maxN % FS_BT) != 0 || f.beta != 0.0 || f.triC != TRI_NONE) return false;
   if (f.role == 3 ? !(f.alpha == 1.0 || f.alpha == 2.0 || f.alpha == 0.5 || f.alpha == 4.0) : (f.alpha != 1.0)) return false;
   if (f.role == 3 && f.scale_mode != 1) return false;
-  // K-tile depth of the two forward products: 16 (three workgroups per CU) or 32 (two); GP_FS_BK selects (A/B)
-  static const int bk = getenv("GP_FS_BK") ? atoi(getenv("GP_FS_BK")) : 16;
-  if (f.role == 1) *st = (bk == 16) ? launch_strip32<1, 16>(h, d_probs, batch, maxM, maxN, f) : launch_strip32<1, 32>(h, d_probs, batch, maxM, maxN, f);
-  else if (f.role == 2) *st = (bk == 16) ? launch_strip32<2, 16>(h, d_probs, batch, maxM, maxN, f) : launch_strip32<2, 32>(h, d_probs, batch, maxM, maxN, f);
-  else *st = (bk == 16) ? launch_strip32<3, 16>(h, d_probs, batch, maxM, maxN, f) : launch_strip32<3, 32>(h, d_probs, batch, maxM, maxN, f);
-  return true;
-}
-
-bool launch_gemm_strip_f32_nt_lean(gp_handle h, const GemmProblem* d_probs, int batch, int M, int Nlong, int nsplit, int sym,
-                                   int scale_by_k, gp_status* st) {
-  static const bool enabled = !(getenv("GP_STRIP_LEAN") && atoi(getenv("GP_STRIP_LEAN")) == 0) &&
-                              (getenv("GP_STRIP32_ROLES") && ((atoi(getenv("GP_STRIP32_ROLES")) >> 3) & 1));   // off by default (see above)
-  if (!enabled || (M % FS_BT) != 0 || (Nlong % FS_BK) != 0 || nsplit < 2) return false;
-  Strip32NtFlags nf;
-  nf.tilesM = M / FS_BT; nf.ksplit = nsplit; nf.sym = sym; nf.scale = scale_by_k;
-  const int ntl = sym ? nf.tilesM * (nf.tilesM + 1) / 2 : nf.tilesM * nf.tilesM;
-  static std::atomic<uint32_t> attr_devs{0};
-  const uint32_t bit = 1u << (h->device & 31);
-  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_strip_f32_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_BYTES);
-    if (e != hipSuccess) { *st = gp_fail(h, GP_ERR_HIP, "hipFuncSetAttribute failed"); return true; }
-    attr_devs.fetch_or(bit, std::memory_order_release);
-  }
-  hipLaunchKernelGGL(gemm_strip_f32_nt_kernel, dim3(ntl * nsplit, 1, batch), dim3(256), FS_BYTES, h->stream, d_probs, nf);
-  *st = (hipGetLastError() == hipSuccess) ? GP_OK : gp_fail(h, GP_ERR_HIP, "gemm_strip_f32_nt_kernel launch failed");
+  // K-tile depth 16: three workgroups per CU (32-deep tiles, two per CU, measured 5 % behind on cfg3: DESIGN.md section 3b)
+  if (f.role == 1) *st = launch_strip32<1, 16>(h, d_probs, batch, maxM, maxN, f);
+  else if (f.role == 2) *st = launch_strip32<2, 16>(h, d_probs, batch, maxM, maxN, f);
+  else *st = launch_strip32<3, 16>(h, d_probs, batch, maxM, maxN, f);
   return true;
 }

@@ -394,15 +394,8 @@ __global__ void __launch_bounds__(256, 2) gemm_wave_kernel(const GemmProblem* __
   }
 }
 
-static bool gw_enabled() {
-  static const bool on = !(getenv("GP_STRIP_WAVE") && atoi(getenv("GP_STRIP_WAVE")) == 0);
-  return on;
-}
-// roles (bitmask 1 << role) the wave form takes; GP_STRIP_WAVE_ROLES is an A/B switch
-static int gw_roles() {
-  static const int r = getenv("GP_STRIP_WAVE_ROLES") ? atoi(getenv("GP_STRIP_WAVE_ROLES")) : ((1 << 1) | (1 << 2) | (1 << 3) | (1 << 5));
-  return r;
-}
+static bool gw_enabled() { return gp_switches().strip_wave != 0; }
+static int gw_roles() { return gp_switches().strip_wave_roles; }      // bitmask 1 << role (switches.h)
 
 // would a launch of that role and shape take the wave form?  (engine.hip sizes the partial-sum rows by it: 64-row tiles)
 bool gemm_wave_takes(int role, int maxM, int maxN, int uniform_aligned) {

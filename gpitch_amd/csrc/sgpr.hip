@@ -219,7 +219,7 @@ static size_t sgpr_ws_doubles(const gp_sgpr_plan_s* p) {
   size_t d = 0;
   auto add = [&](size_t c) { d += gp_align_up(c * sizeof(double), 256) / sizeof(double); };
   const size_t M = p->M, strip = gp_strip_doubles(M, p->maxN, p->f32 != 0);
-  const int rb = gemm_rowblocks(p->M, 1);
+  const int rb = (p->M + 63) / 64;                   // column-partial rows: one per 64-row tile (gemm_wave.hip; the 128-row forms use half)
   for (int i = 0; i < 5; i++) add(M * M);           // L, W, H, LB, WB
   add(strip); add(strip);                            // Kuf, A
   add(sgpr_feat_stride(p) * p->P);                   // one feature table per kernel of the sum
@@ -281,7 +281,7 @@ gp_status gp_sgpr_set_workspace(gp_sgpr_plan p, void* workspace, size_t bytes) {
     return gp_fail(p->h, GP_ERR_WORKSPACE, "gp_sgpr_set_workspace: workspace too small or not 256-byte aligned");
   GpArena ar(workspace, bytes);
   const size_t M = p->M, strip = gp_strip_doubles(M, p->maxN, p->f32 != 0);
-  const int rb = gemm_rowblocks(p->M, 1);
+  const int rb = (p->M + 63) / 64;
   p->d_desc = ar.take<char>(2 * SG_DESC_BYTES);
   p->L = ar.take<double>(M * M); p->W = ar.take<double>(M * M); p->H = ar.take<double>(M * M);
   p->LB = ar.take<double>(M * M); p->WB = ar.take<double>(M * M);
@@ -366,7 +366,8 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   const int M = p->M;
   const int f32 = p->f32;
   const int64_t ld = gp_strip_ld(N, f32 != 0);
-  const int rb = gemm_rowblocks(M, 1);
+  const bool wave_a = !f32 && M > 64 && gemm_wave_takes(1, M, N, 1);      // A' = W Kuf in gemm_wave.hip's form: a partial row per 64 rows
+  const int rb = wave_a ? M / 64 : gemm_rowblocks(M, 1);
   std::vector<GemmProblem> probs(3);
   memset(probs.data(), 0, probs.size() * sizeof(GemmProblem));
   { GemmProblem& r = probs[0]; r.A = p->W; r.lda = M; r.B = p->Kuf; r.ldb = ld; r.C = p->A; r.ldc = ld; r.M = M; r.N = N; r.K = M; r.o0 = p->s1; }
@@ -408,7 +409,7 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
         GP_CHECK(launch_kernel_build(h, kerns[i], Z, M, X, N, p->Kuf, ld, i > 0, 0.0, feats[i], 1, f32));
   }
   GP_CHECK(gp_aux_join(h));
-  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ; f.uniform_aligned = 1;   /* one problem, arena buffers, ld = gp_strip_ld */
+  { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ; f.uniform_aligned = 1;   /* one problem, arena buffers, ld = gp_strip_ld */ f.rows64_ok = wave_a ? 1 : 0;
     if (f32) { f.role = 1; GP_CHECK(launch_gemm_f32_role(h, desc->probs + 0, 1, M, N, f)); }
     else GP_CHECK(launch_gemm_batched(h, desc->probs + 0, 1, M, N, f)); }
   hipLaunchKernelGGL(sgpr_sums_partial_kernel, dim3(SG_RED_BLOCKS, 2), dim3(256), 0, h->stream, p->s1, (int64_t)rb * N, Y,

@@ -395,13 +395,16 @@ def test_f32_adam_trajectory_stays_with_the_f64_one_on_cfg3(gp_handle):
     assert m_fun <= 1e-9 and m_ls <= 1e-7 and m_hyp <= 5e-7 and m_q <= 5e-6
 
 
-def test_lds_resident_f32_products_opt_in():
-    """gemm_res_f32.hip is off by default (it ties the tiled kernels alone and loses in the overlapped step); its parity is
-    kept by running the M = 128 / 256 cases of this file in a child process with GP_RES32=1 (the switch is read once per
-    process)."""
+@pytest.mark.parametrize("switches", ["strip_wave=0", "strip_wave=0,strip_lean=0"])
+def test_fallback_strip_forms_keep_parity(switches):
+    """The default float64 strip products are gemm_wave.hip's (a 64 x 64 tile per wavefront); shapes it does not take run
+    gemm_strip.hip's lean 128 x 128 tiles and, ragged, gemm.hip's.  Their parity is kept by running the ELBO / gradient /
+    fused-contraction tests of test_gpu_pdgp.py in a child process with the forms switched by GPITCH_AMD_SWITCHES (read once
+    per process: gpitch_amd/csrc/switches.h)."""
     import subprocess
     import sys
-    env = dict(os.environ, GP_RES32="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
-                        "-k", "2048-128 or 4096-256"], capture_output=True, text=True, timeout=900, env=env)
+    env = dict(os.environ, GPITCH_AMD_SWITCHES=switches)
+    target = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_pdgp.py")
+    r = subprocess.run([sys.executable, "-m", "pytest", target, "-q", "-m", "gpu", "-x",
+                        "-k", "elbo or gradient or fused or overlap_levels"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])

@@ -1,5 +1,5 @@
 """Kuf strip build alone on the device (forward passes, helper stream off): average launch time of the spectral-mixture
-and the stationary family for m partials.  Same-box A/B of build variants: GP_KUF_DIRECT=0/1/2 python tools/bench_kuf.py"""
+and the stationary family for m partials.  Same-box A/B of build variants: GPITCH_AMD_LIB=tools/ab/lib_X.so python tools/bench_kuf.py"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +33,7 @@ def main():
                                                                         byts / (ms / n * 1e-3) / 8e12))
         del model
         torch.cuda.empty_cache()
-    print("GP_KUF_DIRECT=%s | " % os.environ.get("GP_KUF_DIRECT", "default") + " | ".join(out))
+    print("lib=%s | " % os.environ.get("GPITCH_AMD_LIB", "product") + " | ".join(out))
 
 
 if __name__ == "__main__":

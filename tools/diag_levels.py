@@ -24,6 +24,6 @@ def main():
             f = model._elbo(True)
             g = model._grad.cpu().numpy().copy()
             out.append((f, float(np.abs(g).sum())))
-        print("roles=%s level %d:" % (os.environ.get("GP_STRIP_WAVE_ROLES", "all"), level), " ".join("%.15e/%.15e" % o for o in out))
+        print("roles=%s level %d:" % (os.environ.get("GPITCH_AMD_SWITCHES", "default"), level), " ".join("%.15e/%.15e" % o for o in out))
 
 main()
