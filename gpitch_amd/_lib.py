@@ -37,6 +37,8 @@ ABI_SYMBOLS = [
     "gp_sgprb_set_workspace", "gp_sgprb_bound_grad", "gp_sgprb_set_graphs", "gp_sgprb_eval_counts",
     "gp_sgprb_predict_f", "gp_sgprb_predict_source_workspace_bytes", "gp_sgprb_predict_source",
     "gp_timers_enable", "gp_timers_reset", "gp_timers_read",
+    "gp_comm_unique_id", "gp_comm_create", "gp_comm_destroy", "gp_comm_world", "gp_comm_rank", "gp_comm_allreduce_sum",
+    "gp_pdgp_elbo_pitch_sharded", "gp_pdgp_elbo_gp_sharded", "gp_sgpr_bound_grad_sharded",
 ]
 
 
@@ -60,6 +62,13 @@ class PdgpConfig(C.Structure):
                 ("kern_type_act", C.POINTER(C.c_int32)), ("kern_type_com", C.POINTER(C.c_int32)),
                 ("partials_act", C.POINTER(C.c_int32)), ("partials_com", C.POINTER(C.c_int32)),
                 ("jitter", C.c_double)]
+
+
+class AdamArgs(C.Structure):
+    """gp_adam_args: gp_adam_step's arguments for the sharded one-call steps"""
+    _fields_ = [("free_state", C.c_void_p), ("tcode", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("nparams", C.c_int64), ("t", C.c_int64), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double)]
 
 
 class SgprConfig(C.Structure):
@@ -183,6 +192,16 @@ def load_library():
         "gp_timers_enable": (i32, [vp, i32]),
         "gp_timers_reset": (i32, [vp]),
         "gp_timers_read": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(i64)]),
+        "gp_comm_unique_id": (i32, [vp]),
+        "gp_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "gp_comm_destroy": (i32, [vp]),
+        "gp_comm_world": (i32, [vp]),
+        "gp_comm_rank": (i32, [vp]),
+        "gp_comm_allreduce_sum": (i32, [vp, vp, i64]),
+        "gp_pdgp_elbo_pitch_sharded": (i32, [vp, vp, vp, vp, vp, i32, dbl, vp, vp, C.POINTER(dbl), vp, C.POINTER(AdamArgs)]),
+        "gp_pdgp_elbo_gp_sharded": (i32, [vp, vp, vp, vp, vp, i32, dbl, i32, i32, vp, vp, vp, vp, C.POINTER(dbl), vp,
+                                        C.POINTER(AdamArgs)]),
+        "gp_sgpr_bound_grad_sharded": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, C.POINTER(dbl), vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
@@ -250,6 +269,45 @@ class Handle(object):
         # torch allocations are >= 512-byte aligned
         return self.torch.empty(int(nbytes) + 256, dtype=self.torch.uint8, device=self.device)
 
+    def comm(self, world=None, rank=None):
+        """The RCCL communicator of this handle over the ranks of the initialised torch.distributed group (or a one-rank
+        communicator without one): rank 0 draws the 128-byte unique id (gp_comm_unique_id) and the group broadcasts it;
+        every rank then calls gp_comm_create.  None when the group's backend is not nccl (the gloo rehearsals keep the
+        torch.distributed exchange) or the library finds no RCCL.  Cached per handle."""
+        if getattr(self, "_comm_done", False):
+            return self._comm
+        self._comm_done, self._comm = True, None
+        import torch.distributed as dist
+        grouped = dist.is_available() and dist.is_initialized()
+        if grouped and dist.get_backend() != "nccl":
+            return None
+        w = dist.get_world_size() if grouped else 1
+        r = dist.get_rank() if grouped else 0
+        if (world is not None and world != w) or (rank is not None and rank != r):
+            return None
+        ident = (C.c_uint8 * 128)()
+        if r == 0 and self.lib.gp_comm_unique_id(ident) != GP_OK:
+            ident = None
+        if grouped:
+            t = self.torch.zeros(129, dtype=self.torch.uint8, device=self.device)
+            if r == 0 and ident is not None:
+                t[:128] = self.torch.frombuffer(bytearray(bytes(ident)), dtype=self.torch.uint8).to(self.device)
+                t[128] = 1
+            dist.broadcast(t, 0)
+            host = t.cpu().numpy()
+            if host[128] != 1:
+                return None
+            ident = (C.c_uint8 * 128)(*[int(v) for v in host[:128]])
+        elif ident is None:
+            return None
+        c = C.c_void_p()
+        st = self.lib.gp_comm_create(self.h, ident, r, w, C.byref(c))
+        if st == GP_ERR_UNSUPPORTED:
+            return None
+        self.check(st)
+        self._comm = c
+        return c
+
     def timers(self):
         out = {}
         for i, name in enumerate(TIMER_NAMES):
@@ -260,6 +318,9 @@ class Handle(object):
         return out
 
     def close(self):
+        if getattr(self, "_comm", None):
+            self.lib.gp_comm_destroy(self._comm)
+            self._comm = None
         if getattr(self, "h", None):
             self.lib.gp_destroy(self.h)
             self.h = None

@@ -38,14 +38,34 @@ def allreduce_sum_(t):
     through the backend: that is how a one-GPU box exercises the RCCL path, stream ordering included.)"""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        if t.is_cuda and dist.get_backend() == "gloo":
+        backend = dist.get_backend()
+        if t.is_cuda and backend == "gloo":
             # CPU rehearsal backend: stage through the host (RCCL reduces device memory directly)
             host = t.cpu()
             dist.all_reduce(host)
             t.copy_(host)
+        elif (not t.is_cuda) and backend == "nccl":
+            # a host tensor on the production group (nccl only: "No backend type associated with device type cpu"):
+            # reduce a device copy
+            import torch
+            dev = t.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(dev)
+            t.copy_(dev.cpu())
         else:
             dist.all_reduce(t)
     return t
+
+
+def require_group(world, what):
+    """a sharded model's cross-rank step needs an initialised process group of exactly `world` ranks: without one the
+    sum over ranks would silently be the local rows alone"""
+    import torch.distributed as dist
+    if world <= 1:
+        return
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("%s: the model is sharded over %d ranks but torch.distributed is not initialised" % (what, world))
+    if dist.get_world_size() != world:
+        raise RuntimeError("%s: the model is sharded over %d ranks, the process group has %d" % (what, world, dist.get_world_size()))
 
 
 def allreduce_max_(t):

@@ -25,6 +25,10 @@ except Exception:      # pragma: no cover
 _SELF_CHECK = [None]
 
 
+# why available() returned False (None while it has not, or has returned True): for bench / test reports
+unavailable_reason = [None]
+
+
 def _self_check():
     """`setulb` is private: a scipy that keeps the name but changes the argument list or the task codes would fail or,
     worse, iterate differently.  Minimise a 2-D Rosenbrock function through LbfgsbRC and through scipy.optimize.minimize:
@@ -43,8 +47,13 @@ def _self_check():
         while run.step() and guard < 1000:
             run.give(*fg(run.x))
             guard += 1
-        return bool(np.array_equal(run.x, ref.x) and run.fun == ref.fun and run.nit == ref.nit and run.nfev == ref.nfev)
-    except Exception:
+        same = bool(np.array_equal(run.x, ref.x) and run.fun == ref.fun and run.nit == ref.nit and run.nfev == ref.nfev)
+        if not same:
+            unavailable_reason[0] = ("self-check: iterates differ from scipy.optimize.minimize (x %s, fun %r vs %r, nit %d vs %d, "
+                                     "nfev %d vs %d)" % (np.array_equal(run.x, ref.x), run.fun, ref.fun, run.nit, ref.nit, run.nfev, ref.nfev))
+        return same
+    except Exception as e:
+        unavailable_reason[0] = "self-check raised %s: %s" % (type(e).__name__, e)
         return False
 
 
@@ -52,9 +61,16 @@ def available():
     """True when the installed scipy exposes the reverse-communication routine this module drives AND a small
     self-check reproduces scipy.optimize.minimize's iterates exactly (verified on scipy 1.15.x)"""
     if not _SCIPY_OK:
+        if unavailable_reason[0] is None:
+            unavailable_reason[0] = "scipy.optimize._lbfgsb.setulb is not importable in this scipy"
         return False
     if _SELF_CHECK[0] is None:
         _SELF_CHECK[0] = _self_check()
+        if not _SELF_CHECK[0]:
+            import warnings
+            import scipy
+            warnings.warn("gpitch_amd.lbfgsb_batch is unavailable with scipy %s (%s): window fits fall back to the per-window "
+                          "fit_windows path, which is several times slower" % (scipy.__version__, unavailable_reason[0]))
     return _SELF_CHECK[0]
 
 

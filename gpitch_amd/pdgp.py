@@ -316,9 +316,53 @@ class Pdgp(Parameterized):
         ev.record()
         return dev[:n]
 
-    def _elbo(self, want_grad, sync=True):
+    def _sharded_comm(self):
+        """the handle's RCCL communicator when this sharded model can use the one-call forms (gp_pdgp_elbo_pitch_sharded /
+        gp_pdgp_elbo_gp_sharded: begin -> exchange -> end [-> Adam] inside the library): an nccl process group of the
+        model's world size (or no group at all for a one-rank model).  None: the torch.distributed exchange between the two
+        stages (gloo rehearsals, emulated ranks)."""
+        if "_comm_cache" not in self.__dict__:
+            import torch.distributed as dist
+            world = self._shard[1]
+            grouped = dist.is_available() and dist.is_initialized()
+            ok = (grouped and dist.get_backend() == "nccl" and dist.get_world_size() == world) or (not grouped and world == 1)
+            object.__setattr__(self, "_comm_cache", self._handle.comm() if ok else None)
+        return self._comm_cache
+
+    def _elbo_one_call(self, comm, want_grad, sync, adam):
+        """a sharded evaluation (and, with `adam`, the optimiser step behind it) as ONE library call"""
+        h = self._handle
+        xb, yb, n = self._batch()
+        self._last_batch = (xb, yb)
+        out = C.c_double()
+        grad = self._grad.data_ptr() if want_grad else None
+        aa = C.byref(adam) if adam is not None else None
+        if self._gp_shard is not None:
+            from .dist import gp_exchange_layout
+            G, world = 2 * self.num_sources, self._shard[1]
+            per, blk = gp_exchange_layout(G, world, n)
+            full = self.__dict__.get("_gp_full")
+            if full is None or full.numel() < 2 * G * n + 8:
+                full = h.empty(2 * G * self._max_batch + 8)
+                object.__setattr__(self, "_gp_full", full)
+            h.check(h.lib.gp_pdgp_elbo_gp_sharded(self._plan, comm, self._params.data_ptr(), xb.data_ptr(), yb.data_ptr(), n,
+                                                  float(self.num_data), G, len(self._gp_shard), self._gp_send.data_ptr(),
+                                                  self._gp_recv.data_ptr(), full.data_ptr(), self._elbo_dev.data_ptr(),
+                                                  C.byref(out) if sync else None, grad, aa))
+        else:
+            h.check(h.lib.gp_pdgp_elbo_pitch_sharded(self._plan, comm, self._params.data_ptr(), xb.data_ptr(), yb.data_ptr(), n,
+                                                     float(self.num_data), self._xchg.data_ptr(), self._elbo_dev.data_ptr(),
+                                                     C.byref(out) if sync else None, grad, aa))
+        return out.value if sync else None
+
+    def _elbo(self, want_grad, sync=True, adam=None):
         h = self._handle
         self._pred_state = None      # the engine drops its prediction factorisation on every ELBO evaluation
+        if self._shard:
+            comm = self._sharded_comm()
+            if comm is not None:
+                return self._elbo_one_call(comm, want_grad, sync, adam)
+        assert adam is None
         if self._gp_shard is not None:
             from .dist import allgather_
             send = self._gp_begin(want_grad)
@@ -449,13 +493,21 @@ class Pdgp(Parameterized):
         h = self._handle
         if isinstance(method, AdamOptimizer):
             flag = C.c_int32(0)
+            one_call = bool(self._shard) and self._sharded_comm() is not None
             for it in range(maxiter):
-                self._elbo(True, sync=False)
                 self._adam_t += 1
-                h.check(h.lib.gp_adam_step(h.h, self._free.data_ptr(), self._params.data_ptr(), self._grad.data_ptr(),
-                                           self._tcode.data_ptr(), self._adam_m.data_ptr(), self._adam_v.data_ptr(),
-                                           self._nparams, self._adam_t, method.learning_rate, method.beta1,
-                                           method.beta2, method.epsilon))
+                if one_call:
+                    # a sharded model on an RCCL group: conditionals -> exchange -> likelihood + backward -> Adam, one call
+                    aa = _lib.AdamArgs(self._free.data_ptr(), self._tcode.data_ptr(), self._adam_m.data_ptr(),
+                                       self._adam_v.data_ptr(), self._nparams, self._adam_t, method.learning_rate,
+                                       method.beta1, method.beta2, method.epsilon)
+                    self._elbo(True, sync=False, adam=aa)
+                else:
+                    self._elbo(True, sync=False)
+                    h.check(h.lib.gp_adam_step(h.h, self._free.data_ptr(), self._params.data_ptr(), self._grad.data_ptr(),
+                                               self._tcode.data_ptr(), self._adam_m.data_ptr(), self._adam_v.data_ptr(),
+                                               self._nparams, self._adam_t, method.learning_rate, method.beta1,
+                                               method.beta2, method.epsilon))
                 # a failed Cholesky freezes the optimiser state on the device (gp_adam_step); the loop itself stops at
                 # the next poll that has seen the flag — no host synchronisation per step
                 h.check(h.lib.gp_poll_not_pd(h.h, C.byref(flag)))
@@ -525,8 +577,11 @@ class Pdgp(Parameterized):
                 src[loc, s:s + c] = ms.cpu().numpy()
         self._pred_state = state
         if self._shard:
-            # rows of other ranks are zero here: a sum over ranks assembles the full prediction
-            from .dist import allreduce_sum_
+            # rows of other ranks are zero here: a sum over ranks assembles the full prediction (emulated ranks — a test
+            # driving several shards in one process — pass allow_local=True through _pred_allow_local and get their rows only)
+            from .dist import allreduce_sum_, require_group
+            if not self.__dict__.get("_pred_allow_local", False):
+                require_group(self._shard[1], "Pdgp.predict")
             t = h.torch
             for a in ((fmean, fvar) if gp_mode else (fmean, fvar, src)):
                 a[...] = allreduce_sum_(t.as_tensor(a)).numpy()

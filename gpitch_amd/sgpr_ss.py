@@ -166,6 +166,20 @@ class SGPRSS(Parameterized):
         if xchg is None or xchg.numel() != need:
             xchg = h.empty(need)
             object.__setattr__(self, "_xchg", xchg)
+        comm = self.__dict__.get("_comm_cache", False)
+        if comm is False:
+            import torch.distributed as dist
+            world = self._shard[1]
+            grouped = dist.is_available() and dist.is_initialized()
+            ok = (grouped and dist.get_backend() == "nccl" and dist.get_world_size() == world) or (not grouped and world == 1)
+            comm = h.comm() if ok else None
+            object.__setattr__(self, "_comm_cache", comm)
+        if comm is not None:
+            # an RCCL group: begin -> all-reduce -> end -> all-reduce(grad) inside ONE library call (gp_sgpr_bound_grad_sharded)
+            h.check(h.lib.gp_sgpr_bound_grad_sharded(args[0], comm, *args[1:], self.X.shape[0], self._Zd.data_ptr(), xchg.data_ptr(),
+                                                     self._bound_dev.data_ptr(), C.byref(out),
+                                                     None if grad is None else grad.data_ptr()))
+            return out.value
         h.check(h.lib.gp_sgpr_bound_begin(*args, self._Zd.data_ptr(), xchg.data_ptr()))
         allreduce_sum_(xchg)
         h.check(h.lib.gp_sgpr_bound_end(*args, self.X.shape[0], self._Zd.data_ptr(), xchg.data_ptr(),

@@ -260,8 +260,10 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
     default reset and AMT.reset_model set the same values for every window); per-window starting values go in `params0`.
     The template model must have no mean function and float64 strips (NotImplementedError otherwise).
     A window whose Kuu or B loses positive definiteness during its fit (the reference: tf.cholesky raises out of that
-    window's optimize()) is retired with results[i]["error"] set, bound = nan and its starting parameters; the other
-    windows of the batch are unaffected (their evaluation is repeated without it).
+    window's optimize()) — or has them not positive definite at its STARTING parameters already — is retired with
+    results[i]["error"] set, bound = nan and its starting parameters; the other windows of the batch are unaffected (their
+    evaluation is repeated; the retired slot rides along on a healthy window's parameters, so it cannot fail again).  One
+    repeat per failing window: the device's status word names the first failure of an evaluation only.
     Returns a list over windows of dicts: bound, nfev, nit, variances, noise, params [, error]."""
     from . import _lib, lbfgsb_batch
     from .dist import window_assignment
@@ -340,8 +342,11 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
         y, r.dy = SGPRSS._free_to_params(st, r.Xf)
         pv = r.base.copy()
         pv[:, free_idx] = y
-        for q in r.failed:                  # retired windows ride along at their (valid) starting parameters
-            pv[q] = r.base[q]
+        # retired windows ride along on the parameters of a healthy window (their own starting parameters may be what failed:
+        # Kuu depends on the kernel parameters and Z alone, so a healthy window's parameters factorise in any slot)
+        donor = r.active[0] if r.active else None
+        for q in r.failed:
+            pv[q] = pv[donor] if donor is not None else r.base[q]
         r.dev.submit(pv)
 
     def advance(r):
@@ -354,8 +359,9 @@ def fit_windows_batched(make_model, windows, maxiter=10, batch=64, reset=default
             # is repeated for the others (the device word names the first failure only: another window may have failed in
             # the same evaluation — it is found by the repeat)
             if slot in r.failed or not (0 <= slot < r.n):
-                raise _lib.NotPositiveDefiniteError(_lib.GP_ERR_NOT_PD, "Cholesky failed in window slot %d (pivot %d) at "
-                                                    "its starting parameters" % (slot, pivot))
+                # (a retired slot runs on a healthy window's parameters: it cannot be what failed unless the status word is wrong)
+                raise _lib.NotPositiveDefiniteError(_lib.GP_ERR_NOT_PD, "Cholesky failed in window slot %d (pivot %d), which is %s"
+                                                    % (slot, pivot, "already retired" if slot in r.failed else "outside the batch"))
             r.failed[slot] = "Cholesky failed: not positive definite (pivot %d) at evaluation %d" % (pivot, r.runs[slot].nfev + 1)
             r.active = [q for q in r.active if q != slot]
             if r.active:

@@ -268,6 +268,46 @@ gp_status gp_pdgp_cond_end(gp_pdgp_plan p, const double* params, const double* x
                            double num_data, const double* fmean_full, const double* fvar_full, const double* kl_total,
                            double* elbo_dev, double* elbo_host, double* grad);
 
+/* ---- the sharded forms with their exchange step INSIDE the call (the handle owns "workspace, stream,
+ * RCCL comm"; section 8e).  The reference has no distributed code: nothing of it is replaced here beyond what
+ * gp_pdgp_elbo_begin/_end, gp_pdgp_cond_begin/_end and gp_sgpr_bound_begin/_end replace (pdgp.py:133-170, sgpr_ss.py:29-71);
+ * these entry points issue the collective the "-- caller: --" lines above ask for themselves — ncclAllReduce / ncclAllGather
+ * of RCCL on the handle's stream, between the two stages — so that one evaluation, and with `adam` one whole optimiser step,
+ * is ONE enqueue with no host code in between.  RCCL is bound at run time (the copy already in the process, else
+ * /opt/rocm/lib/librccl.so); without it gp_comm_create returns GP_ERR_UNSUPPORTED and nothing else is affected.
+ *   gp_comm_unique_id : rank 0 fills 128 bytes (ncclGetUniqueId) and hands them to every rank by any channel
+ *                       (torch.distributed broadcast, a file, MPI ...)
+ *   gp_comm_create    : every rank, same id: ncclCommInitRank on the handle's device; the communicator's collectives run on
+ *                       the handle's stream.  Plans used with a communicator must live on the same handle.
+ * gp_adam_args (may be NULL): gp_adam_step's arguments, applied right behind the evaluation (params is updated in place). */
+typedef struct gp_comm_s* gp_comm;
+typedef struct {
+  double* free_state; const uint8_t* tcode; double* m; double* v;
+  int64_t nparams; int64_t t; double lr, beta1, beta2, eps;
+} gp_adam_args;
+gp_status gp_comm_unique_id(uint8_t* id128);
+gp_status gp_comm_create(gp_handle h, const uint8_t* id128, int32_t rank, int32_t world, gp_comm* out);
+gp_status gp_comm_destroy(gp_comm c);
+int32_t gp_comm_world(gp_comm c);
+int32_t gp_comm_rank(gp_comm c);
+gp_status gp_comm_allreduce_sum(gp_comm c, double* buf, int64_t count);      /* in place, float64, on the handle's stream */
+/* pitch-sharded: gp_pdgp_elbo_begin -> all-reduce of exchange[0 .. 3n] -> gp_pdgp_elbo_end [-> gp_adam_step] */
+gp_status gp_pdgp_elbo_pitch_sharded(gp_pdgp_plan p, gp_comm c, double* params, const double* x, const double* y, int32_t n,
+                                     double num_data, double* exchange, double* elbo_dev, double* elbo_host, double* grad,
+                                     const gp_adam_args* adam);
+/* GP-sharded: gp_pdgp_cond_begin -> all-gather of one block per rank -> rows assembled in the model's order ->
+ * gp_pdgp_cond_end [-> gp_adam_step].  num_gps = 2 P; local_gps = this plan's count; latent GP g lives on rank g mod world
+ * as its (g div world)-th row.  With per = ceil(num_gps / world): send holds 2 per n + 8 doubles
+ * [fmean rows | fvar rows | KL sum + pad], recv world times that, full 2 num_gps n + 8 ([fmean | fvar | KL total]). */
+gp_status gp_pdgp_elbo_gp_sharded(gp_pdgp_plan p, gp_comm c, double* params, const double* x, const double* y, int32_t n,
+                                  double num_data, int32_t num_gps, int32_t local_gps, double* send, double* recv, double* full,
+                                  double* elbo_dev, double* elbo_host, double* grad, const gp_adam_args* adam);
+/* frame-sharded SGPRSS: gp_sgpr_bound_begin -> all-reduce(exchange) -> gp_sgpr_bound_end (the frame-independent terms on
+ * rank 0) [-> all-reduce(grad)]: bound and, when grad != NULL, the full gradient on every rank. */
+gp_status gp_sgpr_bound_grad_sharded(gp_sgpr_plan p, gp_comm c, const double* params, const double* X, const double* Y, int32_t N,
+                                     int64_t N_total, const double* Z, double* exchange, double* bound_dev, double* bound_host,
+                                     double* grad);
+
 /* Pdgp.predict_act / predict_com / predict_act_n_com (pdgp.py:172-208): conditionals at xnew for all 2P
  * GPs.  fmean/fvar: 2P x n row-major (row g as in gp_pdgp_layout).  mean_source (P x n, may be NULL)
  * = nlinfun(mean_act_i) * mean_com_i (pdgp.py:207). */

@@ -72,3 +72,14 @@ def test_bench_one_rank_through_rccl(shard):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["backend"] == "nccl" and d["rccl_ranks"] == 1 and d["value"] > 0
+
+
+def test_one_call_sharded_steps_match_the_two_stage_path():
+    """with an RCCL communicator (here: one rank, no torch.distributed group needed — rank 0 draws the
+    unique id itself) a sharded evaluation is ONE library call that issues the collective between its two stages on the
+    handle's stream (gp_pdgp_elbo_pitch_sharded / gp_pdgp_elbo_gp_sharded / gp_sgpr_bound_grad_sharded), with the Adam step
+    behind it when asked.  Against the two-stage path with the exchange done by the caller, on the same one-rank models:
+    ELBO / gradient / three Adam steps bit for bit (the same kernels in the same order; a one-rank sum changes nothing)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_one_call_child.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-2500:])
+    assert "ONE-CALL OK" in r.stdout, r.stdout[-2500:]

@@ -380,6 +380,8 @@ def test_pitch_sharded_two_stage_matches_unsharded(gp_handle, P, world, whiten):
     # predictions: each rank fills its own rows (the sum over ranks assembles the list)
     xs = prob["x"][::7]
     ref = full.predict_act_n_com(xs)
+    for s in shards:
+        object.__setattr__(s, "_pred_allow_local", True)      # emulated ranks in one process: no process group to sum over
     got = [s._predict(xs, True) for s in shards]
     fm = sum(g[0] for g in got)
     src = sum(g[2] for g in got)
@@ -390,6 +392,16 @@ def test_pitch_sharded_two_stage_matches_unsharded(gp_handle, P, world, whiten):
 
 
 @pytest.mark.gpu
+def test_sharded_predict_needs_its_process_group(gp_handle):
+    """A sharded model's predictions are a sum over ranks; without an initialised group of that size the result would be the
+    local rows with zeros elsewhere — refused instead of returned."""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(512, 16, 2, num_partials=2, seed=3)
+    m = pdgp_from_problem(prob, handle=gp_handle, shard=(0, 2))
+    with pytest.raises(RuntimeError, match="sharded over 2 ranks"):
+        m._predict(prob["x"][::5], True)
+
+
 def test_pitch_sharded_end_requires_matching_begin(gp_handle):
     from gpitch_amd.synth import make_problem
     prob = make_problem(200, 8, 2, num_partials=2, seed=3)
@@ -685,6 +697,8 @@ def test_gp_sharded_two_stage_matches_unsharded(gp_handle, P, world, whiten):
     # predictions: each rank fills its own rows; the sum over ranks (the all-reduce of _predict) assembles them
     xs = prob["x"][::7]
     ref = full.predict_act_n_com(xs)
+    for s in shards:
+        object.__setattr__(s, "_pred_allow_local", True)      # emulated ranks in one process: no process group to sum over
     fm = sum(s._predict(xs, True)[0] for s in shards)
     for i in range(P):
         assert np.allclose(fm[i].reshape(-1, 1), ref[0][i], rtol=1e-10, atol=1e-12)

@@ -385,3 +385,25 @@ def test_full_cov_predictions_match_oracle(gp_handle):
         np.testing.assert_allclose(sm[i], rsm[i], rtol=0, atol=1e-8 * max(np.abs(rsm[i]).max(), 1e-3))
         np.testing.assert_allclose(sc[i], rsc[i], rtol=0, atol=1e-8 * np.abs(rsc[i]).max())
         np.testing.assert_allclose(np.diag(sc[i][:, :, 0]), sv[i][:, 0], rtol=0, atol=3e-6 * kd)
+
+
+@pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2)])
+def test_frame_sharded_optimize_with_a_trainable_mean_function_under_a_process_group(backend, world):
+    """SGPRSS(shard=...).optimize() with trainable mean-function Params all-reduces their gradient entries — a
+    host array — every evaluation; on the production group (nccl only) a host tensor has no backend.  One rank through RCCL
+    and two ranks through gloo (both on this box's one GPU) must run and land on the unsharded window's optimum."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29810 + (os.getpid() % 100) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "_sharded_sgpr_child.py"), backend]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert len(line) == 1, r.stdout[-1500:]
+    d = json.loads(line[0][7:])
+    assert d["world"] == world
+    assert abs(d["fun"] - d["ref_fun"]) <= 1e-8 * abs(d["ref_fun"]), d
+    np.testing.assert_allclose(d["x"], d["ref_x"], rtol=1e-6, atol=1e-8)

@@ -227,6 +227,35 @@ def test_a_window_that_turns_not_positive_definite_mid_fit_is_retired_alone(gp_h
     gp_handle.check(gp_handle.lib.gp_check_not_pd(gp_handle.h))
 
 
+def test_a_window_not_positive_definite_at_its_starting_parameters_is_retired_alone(gp_handle, monkeypatch):
+    """a window whose Kuu is not positive definite at its STARTING parameters fails in every evaluation it takes
+    part in with its own parameters; retired, it rides along on a healthy window's parameters, so the repeat (and every later
+    evaluation) goes through and the other windows finish exactly as in a clean run."""
+    from gpitch_amd import windows as W
+    wins = _windows(5, 801, 32, 2, seed0=33)
+    data = [(w[0], w[1], w[2]) for w in wins]
+
+    def make(h):
+        return _model(*wins[0][:3], wins[0][3], 1.0, h)
+    clean = W.fit_windows_batched(make, data, maxiter=5, batch=5, handle=None, inflight=1)
+    real_submit = W.SgprWindowBatch.submit
+
+    def bad_submit(self, params_host, with_grad=True):
+        p = np.array(params_host, dtype=np.float64, copy=True)
+        if not any(np.array_equal(p[2], p[q]) for q in (0, 1, 3, 4)):      # slot 2 still on parameters of its own
+            p[2, 1] = -3.0                                                   # -> negative kernel variance: Kuu not PD
+        return real_submit(self, p, with_grad)
+    monkeypatch.setattr(W.SgprWindowBatch, "submit", bad_submit)
+    res = W.fit_windows_batched(make, data, maxiter=5, batch=5, handle=None, inflight=1)
+    monkeypatch.setattr(W.SgprWindowBatch, "submit", real_submit)
+    assert "error" in res[2] and np.isnan(res[2]["bound"])
+    for i in (0, 1, 3, 4):
+        assert "error" not in res[i]
+        assert res[i]["bound"] == clean[i]["bound"] and res[i]["nfev"] == clean[i]["nfev"]
+        np.testing.assert_array_equal(res[i]["params"], clean[i]["params"])
+    gp_handle.check(gp_handle.lib.gp_check_not_pd(gp_handle.h))
+
+
 def test_evaluate_raises_for_a_bad_window_and_a_new_bound_buffer_is_not_served_from_the_old_graph(gp_handle):
     """(i) SgprWindowBatch.evaluate reports a failed Cholesky instead of returning numbers; (ii) ADVICE r2: predict_f runs
     the forward pass with its own bound buffer — a following evaluate() with the same window count must write self.bound,
