@@ -8,6 +8,8 @@
 #include <cstring>
 #include <cmath>
 gp_status launch_gemm_batched(gp_handle, const GemmProblem*, int, int, int, const GemmFlags&) { return GP_OK; }
+const GpSwitches& gp_switches() { static const GpSwitches s; return s; }
+bool gemm_strip_fused_contraction_ok(int, int, int) { return false; }
 GpTimerScope::GpTimerScope(gp_handle h_, int w) : h(h_), which(w) {}
 GpTimerScope::~GpTimerScope() {}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
