@@ -1486,7 +1486,7 @@ gp_status pdgp_upload_bwd(gp_pdgp_plan p, const double* params, const double* x,
     { GemmProblem& r = P(S_RANK1); r.C = b.Wbar; r.v0 = q_mu; r.v1 = b.Lu; }
     { GemmProblem& r = P(S_R); r.A = t.W; r.B = b.E; r.C = b.R; }
     { GemmProblem& r = P(S_ALPHA); r.A = t.W; r.v0 = q_mu; r.o0 = b.alpha; }
-    { GemmProblem& r = P(S_G); r.A = b.R; r.B = t.A; r.ldb = ldN; r.N = n; r.v1 = gv; r.C = b.G; r.ldc = ldN;
+    { GemmProblem& r = P(S_G); r.A = b.R; r.B = t.A; r.ldb = ldN; r.N = n; r.v1 = gv; r.C = b.G; r.ldc = ldN; r.xb = b.R32;
       // (read only by the form that contracts Kuf_bar with dK/dtheta in its epilogue — gemm_strip.hip role 5)
       r.kern = t.kern; r.xa = params + q.off_z; r.v0 = b.alpha; r.v2 = gm; r.o0 = b.hyp_part; }
     { GemmProblem& r = P(S_T2); r.A = t.W; r.B = b.Wbar; r.C = b.T2; }
@@ -1745,6 +1745,7 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       GemmFlags f;
       f.big_tiles = 1; f.scale_mode = 1; f.alpha = 2.0; f.timer = GP_TIMER_KUF_BAR; f.role = 3;
       f.uniform_aligned = kuf_uniform;
+      f.a32_ok = 1;          // (float32 GPs: b.R32 is in every problem's xb)
       if (fused_ktype >= 0) {      // the family's Kuf-side contraction as the product's epilogue, nothing stored (one precision per family)
         f.role = 5; f.epilogue = 0; f.aux_x = x; f.aux_ktype = fused_ktype;
         if (fused_f32) return launch_gemm_f32_role(h, D(S_G) + slot0, count, maxM, n, f);
@@ -1798,7 +1799,8 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
       const auto& fam = p->hy_fams[fi];
       if (!ffuse[fi]) return kuf_bar(fslot[fi], fam.count);
       GP_CHECK(kuf_bar(fslot[fi], fam.count, fam.type, fam.f32));
-      for (int g : fam.gps) np_uf[g] = fam.f32 ? (maxM / 128) * (n / 128) : gemm_fused_contraction_records(maxM, n, fam.type);
+      for (int g : fam.gps) np_uf[g] = fam.f32 ? (gemm_wave_f32_takes(5, maxM, n, kuf_uniform) ? (maxM / 64) * (n / 64) : (maxM / 128) * (n / 128))
+                                                : gemm_fused_contraction_records(maxM, n, fam.type);
       return GP_OK;
     };
     bool any_fused = false;

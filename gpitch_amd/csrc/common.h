@@ -244,6 +244,7 @@ struct GemmFlags {
   int aux_ktype = -1;
   int uniform_aligned = 0;            // the caller vouches: every problem has M = maxM (= K structure), N = maxN, 16-byte
                                       // aligned operands with even leading dimensions (gemm_strip.hip's lean form)
+  int a32_ok = 0;                     // float32 strips (gemm_wave_f32.hip): every problem's xb = M * M floats of scratch for the M x M operand
   int rows64_ok = 0;                  // roles 1, 2: the caller has sized o0 / o1 for one partial row per 64-ROW tile and asked
                                       // gemm_wave_takes() how many rows the launch will write (gemm_wave.hip)
 };
@@ -251,6 +252,9 @@ struct GemmFlags {
 bool launch_gemm_wave(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f, gp_status* st);
 bool gemm_wave_takes(int role, int maxM, int maxN, int uniform_aligned);
 int gemm_fused_contraction_records(int maxM, int maxN, int ktype);
+// gemm_wave_f32.hip: the same for float32 strips
+bool launch_gemm_wave_f32(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f, gp_status* st);
+bool gemm_wave_f32_takes(int role, int maxM, int maxN, int uniform_aligned);
 bool launch_gemm_strip_lean(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& f,
                             gp_status* st);
 bool gemm_strip_fused_contraction_ok(int maxM, int maxN, int ktype);

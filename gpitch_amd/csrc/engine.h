@@ -75,6 +75,8 @@ struct CondTask {
   double* Kuf = nullptr;  // M x N
   double* A = nullptr;    // M x N  W Kuf
   double* A2 = nullptr;   // M x N  W^T A (unwhitened only)
+  double* W32 = nullptr;  // float32 strips only: M * M floats each, the float32 copies of W and tril(Lq)^T (gemm_wave_f32.hip)
+  double* Lq32 = nullptr;
   double* feat = nullptr; // spectral-mixture features (2m x (M + N))
   double* feat_uu = nullptr; // the same for the Kuu build (2m x M), separate because the two builds overlap
   double* s1 = nullptr; double* s2 = nullptr; double* dot = nullptr;  // [rowblocks][N] partials
@@ -97,7 +99,8 @@ struct CondBatch {
   // per-GP precision: tasks [0, n64) keep float64 strips, tasks [n64, G) have float32 ones (CondTask::f32); -1 = uniform
   // (all float64 or, with f32 set, all float32).  cond_batch_upload checks the order and sets it.
   int n64 = -1;
-  bool wave_a = false, wave_lta = false;   // A = W Kuf / Lq^T A of the float64 tasks take gemm_wave.hip's form (64-row partial rows)
+  bool wave_a = false, wave_lta = false;
+  bool wave_a32 = false, wave_lta32 = false;   // the same for the float32 tasks (gemm_wave_f32.hip)   // A = W Kuf / Lq^T A of the float64 tasks take gemm_wave.hip's form (64-row partial rows)
   // grouped covariance builds (one launch per kernel family)
   struct Group { int type = 0, m = 0, first = 0, maxM = 0; bool f32 = false; std::vector<int> members; };
   std::vector<Group> groups;

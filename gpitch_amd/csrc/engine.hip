@@ -19,6 +19,7 @@ size_t cond_task_workspace_doubles(int M, int N, int m, bool whiten, bool f32) {
   if (!whiten) add(strip);                         // A2
   if (m > 0) { add(kernel_build_feat_ws_doubles(m, M, N)); add(kernel_build_feat_ws_doubles(m, M, M)); }
   add((size_t)rb * N); add((size_t)rb * N); add((size_t)rb * N);  // s1, s2, dot
+  if (f32) { add(((size_t)M * M + 1) / 2); add(((size_t)M * M + 1) / 2); }   // float32 copies of W, tril(Lq)^T
   return d;
 }
 
@@ -38,6 +39,8 @@ bool cond_task_carve(GpArena& ar, CondTask& t, int N, bool whiten, bool f32) {
   t.s1 = ar.take<double>((size_t)rb * N);
   t.s2 = ar.take<double>((size_t)rb * N);
   t.dot = ar.take<double>((size_t)rb * N);
+  t.W32 = f32 ? ar.take<double>(((size_t)t.M * t.M + 1) / 2) : nullptr;
+  t.Lq32 = f32 ? ar.take<double>(((size_t)t.M * t.M + 1) / 2) : nullptr;
   return ar.ok;
 }
 
@@ -96,6 +99,8 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
   const int uni = cond_batch_uniform(cb, N);
   cb.wave_a = gemm_wave_takes(1, cb.maxM, N, uni);
   cb.wave_lta = whiten && gemm_wave_takes(2, cb.maxM, N, uni);
+  cb.wave_a32 = gemm_wave_f32_takes(1, cb.maxM, N, uni);
+  cb.wave_lta32 = whiten && gemm_wave_f32_takes(2, cb.maxM, N, uni);
   for (int g = 0; g < G; g++) {
     const CondTask& t = cb.tasks[g];
     const int64_t ldN = gp_strip_ld(N, t.f32);
@@ -104,7 +109,7 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
     memset(&p, 0, sizeof(p));
     p.A = t.W; p.lda = t.M; p.B = t.Kuf; p.ldb = ldN; p.C = t.A; p.ldc = ldN;
     p.M = t.M; p.N = N; p.K = t.M;
-    p.v0 = t.q_mu; p.o0 = t.s1; p.o1 = t.dot;
+    p.v0 = t.q_mu; p.o0 = t.s1; p.o1 = t.dot; p.xb = t.W32;
     f1[g] = p;
     memset(&p, 0, sizeof(p));
     p.A = t.W; p.lda = t.M; p.B = t.A; p.ldb = ldN; p.C = t.A2; p.ldc = ldN;
@@ -114,10 +119,10 @@ gp_status cond_batch_upload(gp_handle h, CondBatch& cb, bool whiten, double jitt
     memset(&p, 0, sizeof(p));
     p.A = t.q_sqrt; p.lda = t.M; p.B = whiten ? t.A : t.A2; p.ldb = ldN; p.C = nullptr; p.ldc = ldN;
     p.M = t.M; p.N = N; p.K = t.M;
-    p.o0 = t.s2;
+    p.o0 = t.s2; p.xb = t.Lq32;
     f2[g] = p;
     const int rb = gemm_rowblocks(t.M, 1), rb64 = t.M / 64;
-    const int rb_a = (cb.wave_a && !t.f32) ? rb64 : rb, rb_lta = (cb.wave_lta && !t.f32) ? rb64 : rb;
+    const int rb_a = (t.f32 ? cb.wave_a32 : cb.wave_a) ? rb64 : rb, rb_lta = (t.f32 ? cb.wave_lta32 : cb.wave_lta) ? rb64 : rb;
     cond_finish_fill(fin + g * cond_finish_item_bytes(), t.s1, rb_a, t.s2, t.q_sqrt ? rb_lta : 0, t.dot,
                      whiten ? rb_a : rb, t.kern, t.fmean, t.fvar);
   }
@@ -360,7 +365,13 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     const GemmProblem* d = (const GemmProblem*)(cb.d_desc + off);
     const int n64 = (cb.n64 < 0) ? (cb.f32 ? 0 : G) : cb.n64;
     if (n64 > 0) GP_CHECK(launch_gemm_batched(h, d, n64, cb.maxM, N, f));
-    if (n64 < G) GP_CHECK(launch_gemm_f32_role(h, d + n64, G - n64, cb.maxM, N, f32flags ? *f32flags : f));
+    if (n64 < G) {
+      GemmFlags g32 = f32flags ? *f32flags : f;
+      // (float32 tasks: their own wave form — scratch for the float32 copy of the M x M operand is in xb; partial rows per 64-row tile)
+      g32.a32_ok = 1;
+      g32.rows64_ok = (g32.role == 1) ? (cb.wave_a32 ? 1 : 0) : (g32.role == 2 && !f32flags) ? (cb.wave_lta32 ? 1 : 0) : 0;
+      GP_CHECK(launch_gemm_f32_role(h, d + n64, G - n64, cb.maxM, N, g32));
+    }
     return GP_OK;
   };
   gp_status st = GP_OK;

@@ -523,6 +523,10 @@ bool gemm_f32_fused_contraction_ok(int maxM, int maxN, int ktype) {
 gp_status launch_gemm_f32_role(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int maxN, const GemmFlags& gf) {
   if (batch <= 0 || maxM <= 0 || maxN <= 0) return GP_OK;
   GpTimerScope ts(h, gf.timer);
+  {   // whole aligned strips with float32 scratch for the M x M operand: a 64 x 64 tile per wavefront (gemm_wave_f32.hip)
+    gp_status st = GP_OK;
+    if (launch_gemm_wave_f32(h, d_probs, batch, maxM, maxN, gf, &st)) return st;
+  }
   if (gf.role == 5) {     // Kuf_bar with the stationary family's contraction as its epilogue (the caller asked gemm_f32_fused_contraction_ok)
     Gemm32Flags f;
     f.alpha = gf.alpha; f.epi = 0; f.scale = 1; f.sym = 0; f.ksplit = 1; f.tilesM = f.tilesN = 1; f.tm0 = 0; f.tilesM_req = 0;

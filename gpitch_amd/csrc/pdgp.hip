@@ -12,6 +12,7 @@ static size_t pdgp_bwd_doubles(const gp_pdgp_plan_s* p) {
     const size_t M = p->gps[g].M;
     for (int i = 0; i < 6; i++) add(M * M);
     add(gp_strip_doubles(M, p->maxN, p->gps[g].f32 != 0));
+    if (p->gps[g].f32) add((M * M + 1) / 2);
     add(M); add(M); add(M); add((size_t)65 * M);
     const size_t ns = hyper_num_sums(p->gps[g].m);
     const size_t colblocks = (p->maxN + 255) / 256 + 1;
@@ -215,6 +216,7 @@ gp_status gp_pdgp_set_workspace(gp_pdgp_plan p, void* workspace, size_t bytes) {
       b.H = ar.take<double>(M * M); b.E = ar.take<double>(M * M); b.T1 = ar.take<double>(M * M);
       b.T2 = ar.take<double>(M * M); b.Wbar = ar.take<double>(M * M); b.R = ar.take<double>(M * M);
       b.G = ar.take<double>(gp_strip_doubles(M, p->maxN, p->gps[g].f32 != 0));
+      b.R32 = p->gps[g].f32 ? ar.take<double>((M * M + 1) / 2) : nullptr;
       b.u = ar.take<double>(M); b.Lu = ar.take<double>(M); b.alpha = ar.take<double>(M);
       b.upart = ar.take<double>((size_t)p->nsplit * M);
       const size_t ns = hyper_num_sums(p->gps[g].m);

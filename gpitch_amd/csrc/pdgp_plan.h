@@ -26,6 +26,7 @@ struct BwdBufs {  // per-GP backward workspace (device)
   double* T2 = nullptr;     // M x M   scratch
   double* Wbar = nullptr;   // M x M
   double* R = nullptr;      // M x M   W^T E
+  double* R32 = nullptr;    // float32 strips only: M * M floats, the float32 copy of R (gemm_wave_f32.hip)
   double* G = nullptr;      // M x N   K̄uf (dense part R (A D))
   double* u = nullptr;      // M       A gm
   double* upart = nullptr;  // nsplit x M   fused row-dot partials

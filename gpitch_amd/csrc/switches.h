@@ -8,6 +8,7 @@
 //   name            default  meaning
 //   strip_wave        1      gemm_wave.hip: float64 strip products with a 64 x 64 tile per wavefront, no LDS (0: gemm_strip.hip)
 //   strip_wave_roles  46     bit (1 << role) — which roles (1 A = W Kuf, 2 Lq^T A, 3 Kuf_bar, 5 Kuf_bar + contraction) take it
+//   strip_wave_f32    46     gemm_wave_f32.hip: the same form for float32 strips, a bitmask 1 << role (0: gemm_strip_f32.hip / gemm_f32.hip)
 //   strip_lean        1      gemm_strip.hip / gemm_strip_f32.hip: the lean 128 x 128 LDS tiles (0: gemm.hip / gemm_f32.hip's)
 //   hyper_fuse        1      a stationary family's Kuf-side contraction as the epilogue of its Kuf_bar product
 //   kufbar_split      2      Kuf_bar per kernel family: 2 stationary family first, 1 spectral-mixture family first, 0 one launch
@@ -19,7 +20,7 @@
 // Unknown names are reported once on stderr and ignored.
 #pragma once
 struct GpSwitches {
-  int strip_wave = 1, strip_wave_roles = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_lean = 1, hyper_fuse = 1, kufbar_split = 2,
+  int strip_wave = 1, strip_wave_f32 = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_wave_roles = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_lean = 1, hyper_fuse = 1, kufbar_split = 2,
       cond_a_early = 1, blocked_256 = 1, cov_sum = 1, hyper_sum = 1;
 };
 const GpSwitches& gp_switches();     // abi.hip

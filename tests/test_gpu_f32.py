@@ -11,7 +11,9 @@ STATED TOLERANCES (relative; measured on MI355X, each bound has >= 3x headroom o
   posterior variance, activation GPs         2e-3    cond(Kuu) ~ 1e9, cond(L) ~ 3e4, times float32 eps = 2e-3 per entry of A)
   mean_source = nlin(mean_act) * mean_com    2e-2
   gradients (relative to the largest entry of each parameter block): 5e-3, except the activation kernels'
-  lengthscale and inducing inputs (the ill-conditioned direction): 2e-1
+  lengthscale and inducing inputs (the ill-conditioned direction): 2e-1, and the spectral-mixture frequencies: 2.5e-2
+  (d/d f of cos(2 pi f r) carries the factor 2 pi r: the block is a difference of large sums and moves with the
+  summation order of the strip kernels; seen 4e-4 .. 7.5e-3 over seeds 1-4 and both kernel forms, tools/f32_grad_err.py)
 """
 import os
 import numpy as np
@@ -24,7 +26,7 @@ from helpers import oracle_elbo, oracle_elbo_and_grads, model_grad_dict  # noqa:
 ELBO_RTOL = 2e-4
 # unwhitened model in float32 (two applications of Lm^-1 to float32 strips): stated bounds
 UNW_ELBO_RTOL, UNW_MEAN_RTOL, UNW_VAR_RTOL = 2e-4, 6e-2, 6e-2     # measured: ELBO 1.1e-8, conditional moments 3.7e-6 (cond(Kuu) 1e3), activation-GP mean 4.6e-3 / 2.3e-2 (Matern32, l = 0.05 s, M = 48 / 256), gradient blocks 2.5e-4
-GRAD_RTOL, GRAD_RTOL_ILL = 5e-3, 2e-1
+GRAD_RTOL, GRAD_RTOL_ILL, GRAD_RTOL_FREQ = 5e-3, 2e-1, 2.5e-2
 PRED_RTOL = (5e-2, 2e-3, 1e-5, 1e-5, 2e-2)       # mean_act, var_act, mean_com, var_com, mean_source
 
 
@@ -60,7 +62,7 @@ def test_kernel_build_f32_is_the_f64_build_rounded_once(gp_handle):
 def test_f32_elbo_gradient_and_predictions_against_the_f64_oracle(gp_handle, N, M, P, m):
     """ragged sizes on purpose: M = 48 / 300 leave partial 128-row tiles, N = 1000 / 4200 partial column strips (the
     guarded staging path of gemm_f32.hip); M = 512 is the bench's tile grid; M = 128 / 256 with whole column tiles take
-    the LDS-resident form (gemm_res_f32.hip: one and two row-blocks, triangular and dense operands)"""
+    the wave form (gemm_wave_f32.hip: one and two tile pairs, triangular and dense operands)"""
     from gpitch_amd.synth import make_problem
     from oracle import gpflow05 as orc
     prob = make_problem(N, M, P, num_partials=m, seed=3)
@@ -77,7 +79,7 @@ def test_f32_elbo_gradient_and_predictions_against_the_f64_oracle(gp_handle, N, 
             rg = np.tril(rg[:, :, 0])[:, :, None]
         err = np.abs(gg.reshape(rg.shape) - rg).max() / max(np.abs(rg).max(), 1e-12)
         ill = name.startswith("za") or (name.startswith("act") and name.endswith("lengthscales"))
-        if err > (GRAD_RTOL_ILL if ill else GRAD_RTOL):
+        if err > (GRAD_RTOL_ILL if ill else GRAD_RTOL_FREQ if ".frequency" in name else GRAD_RTOL):
             bad[name] = err
     assert not bad, bad
     xs = prob["x"][::7]
@@ -153,7 +155,7 @@ def test_mixed_precision_activation_f64_component_f32(gp_handle, N, M, P, m, whi
         err = np.abs(gg.reshape(rg.shape) - rg).max() / max(np.abs(rg).max(), 1e-12)
         act = name.startswith(("za", "act")) or "_act" in name
         worst["act" if act else "other"] = max(worst["act" if act else "other"], err)
-        if err > (MIXED_GRAD_RTOL_ACT if act else MIXED_GRAD_RTOL):
+        if err > (MIXED_GRAD_RTOL_ACT if act else GRAD_RTOL_FREQ if ".frequency" in name else MIXED_GRAD_RTOL):
             bad[name] = err
     print("mixed precision gradient blocks: activation side %.2e, component side / noise %.2e" % (worst["act"], worst["other"]))
     assert not bad, bad
@@ -279,7 +281,7 @@ def test_f32_unwhitened_model_against_the_f64_oracle(gp_handle, N, M, P, m):
         r = g_ref[k]
         scale = max(np.abs(r).max(), 1e-12)
         worst = max(worst, np.abs(v - r).max() / scale)
-        tol = GRAD_RTOL_ILL if (k.startswith("act") or k.startswith("za") or "q_" in k) else GRAD_RTOL
+        tol = GRAD_RTOL_ILL if (k.startswith("act") or k.startswith("za") or "q_" in k) else GRAD_RTOL_FREQ if ".frequency" in k else GRAD_RTOL
         assert np.abs(v - r).max() <= tol * scale, (k, np.abs(v - r).max() / scale)
     print("unwhitened f32 gradient: worst block deviation %.2e" % worst)
     xt = prob["x"][::5]
