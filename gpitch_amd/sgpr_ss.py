@@ -39,15 +39,19 @@ class SGPRSS(Parameterized):
         if reg:
             kern.var_vector = ParamList([k.variance for k in kern.kern_list])   # sgpr_ss.py:17-22
         Y = np.asarray(Y, dtype=np.float64)
-        if Y.ndim != 2 or Y.shape[1] != 1:
-            raise ValueError("Y must be N x 1")
+        if Y.ndim != 2 or Y.shape[1] < 1:
+            raise ValueError("Y must be N x D")
         self.X = DataHolder(np.asarray(X, dtype=np.float64).reshape(-1, 1))
         self.Y = DataHolder(Y)
         self.Z = DataHolder(np.asarray(Z, dtype=np.float64).reshape(-1, 1), on_shape_change='pass')   # :26
         self.kern = kern
         self.reg = reg
         self.likelihood = _Gaussian()
-        self.num_latent = 1
+        # D = Y.shape[1] outputs share X, Z, the kernel and the noise (sgpr_ss.py:38 output_dim): the bound is the sum of
+        # the D one-column bounds (every term of :55-62 is linear in the columns or carries the factor output_dim), so
+        # D > 1 is D evaluations of the one-column launch sequence, summed on the device (_bound).  The reference's
+        # callers only ever pass one column.
+        self.num_latent = Y.shape[1]
         self._handle = handle
         self._plan = None
         self._plan_key = None
@@ -76,7 +80,11 @@ class SGPRSS(Parameterized):
         cur = self.__dict__.get(name)
         if isinstance(cur, DataHolder) and not isinstance(value, DataHolder):
             value = np.asarray(value, dtype=np.float64)
-            object.__setattr__(self, name, DataHolder(value.reshape(-1, 1)))
+            if name == "Y" and value.ndim == 2:
+                object.__setattr__(self, name, DataHolder(value))
+                object.__setattr__(self, "num_latent", value.shape[1])
+            else:
+                object.__setattr__(self, name, DataHolder(value.reshape(-1, 1)))
         else:
             Parameterized.__setattr__(self, name, value)
 
@@ -128,27 +136,83 @@ class SGPRSS(Parameterized):
         fr = self._frames()
         self._dev("_params", host)
         self._dev("_Xd", self.X._array[fr])
-        self._dev("_Yd", self._err_host())
+        self._upload_err()
         self._dev("_Zd", self.Z._array)
         object.__setattr__(self, "_n_local", fr.stop - fr.start)
         object.__setattr__(self, "_obj_state", None)      # Param values / .fixed flags may have changed
 
     def _err_host(self):
-        """err = Y - mean_function(X) on this rank's frames (sgpr_ss.py:40)"""
+        """err = Y - mean_function(X) on this rank's frames (sgpr_ss.py:40); a mean function of one column is
+        subtracted from every column"""
         fr = self._frames()
         yv = self.Y._array[fr]
         if self.mean_function is not None:
-            yv = yv - np.asarray(self.mean_function(self.X._array[fr]), dtype=np.float64).reshape(yv.shape)
+            mv = np.asarray(self.mean_function(self.X._array[fr]), dtype=np.float64).reshape(yv.shape[0], -1)
+            yv = yv - mv
         return yv
+
+    def _upload_err(self):
+        """the residual columns on the device: `_Yd` is the column the library reads (a stable pointer: the recorded
+        launch sequence stays valid); with D > 1 `_Yall` holds all of them, column-major, and _bound copies each in turn"""
+        err = self._err_host()
+        if self.num_latent == 1:
+            self._dev("_Yd", err)
+            object.__setattr__(self, "_Yall", None)
+            return
+        self._dev("_Yall", np.ascontiguousarray(err.T))
+        self._dev("_Yd", err[:, 0])
+
+    def _columns(self):
+        """iterate over the output columns with `_Yd` holding the current one"""
+        D = self.num_latent
+        if D == 1:
+            yield 0
+            return
+        n = self._Yd.numel()
+        for d in range(D):
+            self._Yd.copy_(self._Yall[d * n:(d + 1) * n])
+            yield d
 
     def _mean_params(self):
         """trainable Params of the mean function (gpflow.mean_functions.Constant.c, Linear.A / .b), [] for a plain callable"""
         mf = self.mean_function
         return list(mf.params()) if (mf is not None and hasattr(mf, "params") and hasattr(mf, "grad_from_residual")) else []
 
-    def _bound(self, grad=None):
-        """one evaluation of the bound (and gradient into the device vector `grad`) on this model's frames; the
-        frame-sharded form runs begin -> all-reduce -> end -> all-reduce(grad)"""
+    def _bound(self, grad=None, per_column=None):
+        """the bound (and its gradient into the device vector `grad`): the sum over the D output columns of the
+        one-column evaluation (per_column(d) is called after each, while the plan still holds that column's state)"""
+        D = self.num_latent
+        if D == 1:
+            v = self._bound_column(grad)
+            if per_column is not None:
+                per_column(0)
+            return v
+        h = self._handle
+        total, gsum = 0.0, (None if grad is None else h.zeros(grad.numel()))
+        for d in self._columns():
+            total += self._bound_column(grad)
+            if grad is not None:
+                gsum += grad
+            if per_column is not None:
+                per_column(d)
+        if self.reg:
+            # every column's bound carries the whole L1 term -beta sum |variance_k| (sgpr_ss.py:64-68): keep one
+            beta, off = 1000., 1
+            corr = np.zeros(self._nparams)
+            for k in self.kern.kern_list:
+                th = k.theta()                    # th[0]: the kernel's variance in the library's layout
+                total += (D - 1) * beta * abs(th[0])
+                corr[off] = (D - 1) * beta * np.sign(th[0])
+                off += th.size
+            if grad is not None:
+                gsum += h.to_device(corr)
+        if grad is not None:
+            grad.copy_(gsum)
+        return total
+
+    def _bound_column(self, grad=None):
+        """one evaluation of the one-column bound (and gradient into the device vector `grad`) on this model's frames, for
+        the residual column in `_Yd`; the frame-sharded form runs begin -> all-reduce -> end -> all-reduce(grad)"""
         h = self._handle
         out = C.c_double()
         n = self._n_local
@@ -211,20 +275,23 @@ class SGPRSS(Parameterized):
         xs = h.to_device(Xnew)
         mean, var = h.empty(n), h.empty(n)
         cov = h.empty(n, n) if full_cov else None
-        if full_cov:
-            h.check(h.lib.gp_sgpr_predict_f_full(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
-                                                 self._Yd.data_ptr(), self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(),
-                                                 n, mean.data_ptr(), var.data_ptr(), cov.data_ptr()))
-        else:
-            h.check(h.lib.gp_sgpr_predict_f(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
-                                            self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(), n, mean.data_ptr(),
-                                            var.data_ptr()))
-        mu = mean.cpu().numpy().reshape(-1, 1)
+        D = self.num_latent
+        mu = np.empty((n, D))
+        for d in self._columns():                   # the mean is linear in the column, the variance does not see it
+            if full_cov:
+                h.check(h.lib.gp_sgpr_predict_f_full(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
+                                                     self._Yd.data_ptr(), self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(),
+                                                     n, mean.data_ptr(), var.data_ptr(), cov.data_ptr()))
+            else:
+                h.check(h.lib.gp_sgpr_predict_f(self._plan, self._params.data_ptr(), self._Xd.data_ptr(), self._Yd.data_ptr(),
+                                                self.X.shape[0], self._Zd.data_ptr(), xs.data_ptr(), n, mean.data_ptr(),
+                                                var.data_ptr()))
+            mu[:, d] = mean.cpu().numpy()
         if self.mean_function is not None:          # SGPR.build_predict: + mean_function(Xnew)
-            mu = mu + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(-1, 1)
-        if full_cov:
-            return mu, cov.cpu().numpy().reshape(n, n, 1)
-        return mu, var.cpu().numpy().reshape(-1, 1)
+            mu = mu + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(n, -1)
+        if full_cov:                                # GPflow tiles the covariance over the D outputs
+            return mu, np.tile(cov.cpu().numpy().reshape(n, n, 1), (1, 1, D))
+        return mu, np.tile(var.cpu().numpy().reshape(-1, 1), (1, D))
 
     def predict_f_full_cov(self, Xnew):
         """GPflow's AutoFlow'd name for predict_f(full_cov=True)"""
@@ -244,21 +311,25 @@ class SGPRSS(Parameterized):
         mean, var = h.empty(P, n), h.empty(P, n)
         ws = h.workspace(h.lib.gp_sgpr_predict_source_workspace_bytes(N, n))
         cov = h.empty(P, n, n) if full_cov else None
-        if full_cov:
-            h.check(h.lib.gp_sgpr_predict_source_full(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
-                                                      self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(),
-                                                      var.data_ptr(), cov.data_ptr(), ws.data_ptr(), ws.numel()))
-        else:
-            h.check(h.lib.gp_sgpr_predict_source(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
-                                                 self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(), var.data_ptr(),
-                                                 ws.data_ptr(), ws.numel()))
-        m, v = mean.cpu().numpy(), var.cpu().numpy()
+        D = self.num_latent
+        m = np.empty((P, n, D))
+        for d in self._columns():                   # one exact posterior per column (the reference's callers have one)
+            if full_cov:
+                h.check(h.lib.gp_sgpr_predict_source_full(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
+                                                          self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(),
+                                                          var.data_ptr(), cov.data_ptr(), ws.data_ptr(), ws.numel()))
+            else:
+                h.check(h.lib.gp_sgpr_predict_source(self._plan, self._params.data_ptr(), self._Xd.data_ptr(),
+                                                     self._Yd.data_ptr(), N, xs.data_ptr(), n, mean.data_ptr(), var.data_ptr(),
+                                                     ws.data_ptr(), ws.numel()))
+            m[:, :, d] = mean.cpu().numpy()
+        v = var.cpu().numpy()
         if self.mean_function is not None:          # sgpr_ss.py:95 adds it to EVERY source's mean
-            m = m + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(1, -1)
-        if full_cov:                                # sgpr_ss.py:95-99: n x n x D with D = 1
+            m = m + np.asarray(self.mean_function(Xnew.reshape(-1, 1)), dtype=np.float64).reshape(1, n, -1)
+        if full_cov:                                # sgpr_ss.py:95-99: tiled to n x n x D
             c = cov.cpu().numpy()
-            return [m[i].reshape(-1, 1) for i in range(P)], [c[i].reshape(n, n, 1) for i in range(P)]
-        return [m[i].reshape(-1, 1) for i in range(P)], [v[i].reshape(-1, 1) for i in range(P)]
+            return [m[i] for i in range(P)], [np.tile(c[i].reshape(n, n, 1), (1, 1, D)) for i in range(P)]
+        return [m[i] for i in range(P)], [np.tile(v[i].reshape(-1, 1), (1, D)) for i in range(P)]   # :101-102
 
     def predict_s(self, Xnew):
         """sgpr_ss.py:108-114"""
@@ -326,24 +397,28 @@ class SGPRSS(Parameterized):
         if train_mean:                            # a new mean function: new residuals (same device buffer: the recorded
             for p_, v in zip(mps, vals[nd:]):     # launch sequence stays valid)
                 p_._array = np.array([v], dtype=np.float64)
-            self._dev("_Yd", self._err_host())
+            self._upload_err()
         self._dev("_params", vals[:nd])
         grad = self.__dict__.get("_grad_dev")
         if grad is None or grad.numel() != nd:
             grad = h.empty(nd)
             object.__setattr__(self, "_grad_dev", grad)
-        value = self._bound(grad)
+        gm = np.zeros(len(mps))
+
+        def mean_grad(d):
+            # d bound / d err of the column just evaluated, chained through the mean function (shared by the columns)
+            r = self.__dict__.get("_resid_dev")
+            if r is None or r.numel() != self._n_local:
+                r = h.empty(self._n_local)
+                object.__setattr__(self, "_resid_dev", r)
+            h.check(h.lib.gp_sgpr_residual_grad(self._plan, self._params.data_ptr(), self._Yd.data_ptr(), self._n_local,
+                                                r.data_ptr()))
+            gm[:] += np.concatenate(self.mean_function.grad_from_residual(self.X._array[self._frames()], r.cpu().numpy()))
+
+        value = self._bound(grad, per_column=mean_grad if train_mean else None)
         g = grad.cpu().numpy()
         if mps:
-            gm = np.zeros(len(mps))
             if train_mean:
-                r = self.__dict__.get("_resid_dev")
-                if r is None or r.numel() != self._n_local:
-                    r = h.empty(self._n_local)
-                    object.__setattr__(self, "_resid_dev", r)
-                h.check(h.lib.gp_sgpr_residual_grad(self._plan, self._params.data_ptr(), self._Yd.data_ptr(), self._n_local,
-                                                    r.data_ptr()))
-                gm = np.concatenate(self.mean_function.grad_from_residual(self.X._array[self._frames()], r.cpu().numpy()))
                 if self._shard:                   # a frame-sharded window: every rank holds its slice's share of the sums
                     from .dist import allreduce_sum_
                     gm = allreduce_sum_(h.torch.as_tensor(gm)).numpy()

@@ -386,11 +386,17 @@ def sgpr_predict_f(Xnew, X, Y, Z, kern_list, noise_var, xp=NP, full_cov=False):
     tmp1 = xp.trsm(L, Kus, lower=True)
     tmp2 = xp.trsm(LB, tmp1, lower=True)
     mean = xp.matmul(xp.t(tmp2), c)
+    D = Y.shape[1]
     if full_cov:
         var = K_sum(kern_list, Xnew, None, xp) + xp.matmul(xp.t(tmp2), tmp2) - xp.matmul(xp.t(tmp1), tmp1)
-        return mean, xp.reshape(var, (var.shape[0], var.shape[1], 1))
+        return mean, _tile_last(xp.reshape(var, (var.shape[0], var.shape[1], 1)), D, xp)
     var = Kdiag_sum(kern_list, Xnew, xp) + xp.sum(xp.square(tmp2), 0) - xp.sum(xp.square(tmp1), 0)
-    return mean, xp.reshape(var, (-1, 1))
+    return mean, _tile_last(xp.reshape(var, (-1, 1)), D, xp)
+
+
+def _tile_last(a, D, xp=NP):
+    """tf.tile over the trailing output axis (GPflow 0.5 SGPR.build_predict; sgpr_ss.py:97-98,102)"""
+    return a if D == 1 else xp.concat([a] * D, axis=a.ndim - 1)
 
 
 def sgpr_predict_source(Xnew, X, Y, kern_list, noise_var, xp=NP, full_cov=False):
@@ -401,16 +407,17 @@ def sgpr_predict_source(Xnew, X, Y, kern_list, noise_var, xp=NP, full_cov=False)
     L = xp.cholesky(Kxx)
     V = xp.trsm(L, Y, lower=True)
     means, variances = [], []
+    D = Y.shape[1]
     for kp in kern_list:
         Kx = K(kp, X, Xnew, xp)
         A = xp.trsm(L, Kx, lower=True)
         means.append(xp.matmul(xp.t(A), V))
         if full_cov:     # sgpr_ss.py:95-99: the SUM kernel's K(Xnew), as the diagonal form uses its Kdiag
             svar = K_sum(kern_list, Xnew, None, xp) - xp.matmul(xp.t(A), A)
-            variances.append(xp.reshape(svar, (svar.shape[0], svar.shape[1], 1)))
+            variances.append(_tile_last(xp.reshape(svar, (svar.shape[0], svar.shape[1], 1)), D, xp))
             continue
         svar = Kdiag_sum(kern_list, Xnew, xp) - xp.sum(xp.square(A), 0)
-        variances.append(xp.reshape(svar, (-1, 1)))
+        variances.append(_tile_last(xp.reshape(svar, (-1, 1)), D, xp))
     return means, variances
 
 

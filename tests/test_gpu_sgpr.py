@@ -407,3 +407,61 @@ def test_frame_sharded_optimize_with_a_trainable_mean_function_under_a_process_g
     assert d["world"] == world
     assert abs(d["fun"] - d["ref_fun"]) <= 1e-8 * abs(d["ref_fun"]), d
     np.testing.assert_allclose(d["x"], d["ref_x"], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("reg", [False, True])
+def test_several_output_columns(gp_handle, reg):
+    """Y of D = 3 columns (sgpr_ss.py:38 output_dim; :57-62 carry the factor D): bound, gradient (autograd through the
+    oracle), predict_f / predict_s (means per column, variances tiled over the columns: :97-102), the window swap to
+    another D, and a frame-sharded evaluation (emulated ranks are not needed: one rank holds every frame)"""
+    X, Y1, Z, kl = _problem(1300, 48, 3, 21)
+    rng = np.random.RandomState(5)
+    Y = np.concatenate([Y1, 0.7 * Y1[::-1] + 0.05 * rng.randn(*Y1.shape), np.roll(Y1, 100, axis=0)], axis=1)
+    m = _model(X, Y, Z, kl, 0.3, gp_handle, reg=reg)
+    assert m.num_latent == 3
+    got = m.build_likelihood()
+    ref = orc.sgpr_bound(X, Y, Z, kl, 0.3, reg=reg)
+    assert abs(got - ref) <= 1e-9 * abs(ref), (got, ref)
+    ps = m._param_list()
+    x0 = np.array([p.transform.backward(p.value)[0] for p in ps])
+    f, gfree = m._objective(x0)
+    ref_b, ref_g = _torch_bound_and_grads(X, Y, Z, kl, 0.3, reg=reg)
+    assert abs(-f - ref_b) <= 1e-9 * abs(ref_b)
+    np.testing.assert_allclose(-gfree * (1. + np.exp(-x0)), ref_g, rtol=0, atol=2e-7 * np.abs(ref_g).max())
+    Xs = X[::11] + 1e-5
+    n = Xs.shape[0]
+    mean, var = m.predict_f(Xs)
+    rm, rv = orc.sgpr_predict_f(Xs, X, Y, Z, kl, 0.3)
+    assert mean.shape == (n, 3) and var.shape == (n, 3) and rv.shape == (n, 3)
+    np.testing.assert_allclose(mean, rm, rtol=0, atol=1e-8 * np.abs(rm).max())
+    np.testing.assert_allclose(var, rv, rtol=0, atol=1e-8 * np.abs(rv).max())
+    _, cov = m.predict_f(Xs, full_cov=True)
+    _, rc = orc.sgpr_predict_f(Xs, X, Y, Z, kl, 0.3, full_cov=True)
+    assert cov.shape == (n, n, 3)
+    np.testing.assert_allclose(cov, rc, rtol=0, atol=1e-8 * np.abs(rc).max())
+    sm, sv = m.predict_s(Xs)
+    rsm, rsv = orc.sgpr_predict_source(Xs, X, Y, kl, 0.3)
+    for i in range(3):
+        assert sm[i].shape == (n, 3) and sv[i].shape == (n, 3)
+        np.testing.assert_allclose(sm[i], rsm[i], rtol=0, atol=1e-8 * max(np.abs(rsm[i]).max(), 1e-3))
+        np.testing.assert_allclose(sv[i], rsv[i], rtol=0, atol=1e-8 * np.abs(rsv[i]).max())
+    # the same model object fed a window of two columns, then one (transcription.py:253-263 swaps the DataHolders)
+    m.Y = Y[:, :2]
+    ref2 = orc.sgpr_bound(X, Y[:, :2], Z, kl, 0.3, reg=reg)
+    assert abs(m.build_likelihood() - ref2) <= 1e-9 * abs(ref2)
+    m.Y = Y[:, 2:]
+    ref1 = orc.sgpr_bound(X, Y[:, 2:], Z, kl, 0.3, reg=reg)
+    assert abs(m.build_likelihood() - ref1) <= 1e-9 * abs(ref1)
+    # trainable mean function shared by the columns: d bound / d c against a central difference of the oracle bound
+    from gpitch_amd.mean_functions import Constant
+    mc = _model(X, Y, Z, kl, 0.3, gp_handle, reg=reg)
+    object.__setattr__(mc, "mean_function", Constant(0.2))
+    mc._compile(); mc._pack()
+    psc = mc._param_list()
+    xc = np.array([p.transform.backward(p.value)[0] for p in psc])
+    fc, gc = mc._objective(xc)
+    eps = 1e-5
+    bp = orc.sgpr_bound(X, Y - (0.2 + eps), Z, kl, 0.3, reg=reg)
+    bm = orc.sgpr_bound(X, Y - (0.2 - eps), Z, kl, 0.3, reg=reg)
+    assert abs(-fc - orc.sgpr_bound(X, Y - 0.2, Z, kl, 0.3, reg=reg)) <= 1e-9 * abs(fc)
+    assert abs(-gc[-1] - (bp - bm) / (2 * eps)) <= 1e-5 * abs(gc[-1]) + 1e-6
