@@ -161,6 +161,7 @@ gp_status gp_destroy(gp_handle h) {
   if (h->ev_diag) (void)hipEventDestroy(h->ev_diag);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  cholesky_cluster_release(h);
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -578,7 +579,7 @@ const GpSwitches& gp_switches() {
     struct { const char* name; int* slot; } table[] = {
         {"strip_wave", &w.strip_wave}, {"strip_wave_f32", &w.strip_wave_f32}, {"strip_wave_roles", &w.strip_wave_roles}, {"strip_lean", &w.strip_lean},
         {"hyper_fuse", &w.hyper_fuse}, {"kufbar_split", &w.kufbar_split}, {"cond_a_early", &w.cond_a_early},
-        {"blocked_256", &w.blocked_256}, {"cov_sum", &w.cov_sum}, {"hyper_sum", &w.hyper_sum}};
+        {"blocked_256", &w.blocked_256}, {"cov_sum", &w.cov_sum}, {"hyper_sum", &w.hyper_sum}, {"chol_cluster", &w.chol_cluster}};
     std::string all(e);
     size_t pos = 0;
     while (pos < all.size()) {

@@ -213,6 +213,11 @@ gp_status launch_cholesky_inverse_single(gp_handle h, double* A, double* W, int 
 gp_status launch_zero_upper_blocks_batched(gp_handle h, double* const* d_mats, const int* d_M, const int* d_ld, int batch,
                                            int maxM, int nb);
 gp_status check_not_pd(gp_handle h);  // syncs; turns the device flag into GP_ERR_NOT_PD
+// chol_cluster.hip: one matrix by a cluster of workgroups (factor in place, W = L^-1 when W is given), one launch; false =
+// not a launch the cluster takes (shape, switch, exchange area not allocatable inside a stream capture)
+bool cholesky_cluster_takes(int M, int count);
+bool launch_cholesky_cluster_single(gp_handle h, double* A, double* W, int M, int64_t ld, int pivot_base, gp_status* st);
+void cholesky_cluster_release(gp_handle h);
 
 // gemm.hip
 struct GemmProblem {

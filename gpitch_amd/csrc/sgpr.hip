@@ -395,19 +395,35 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   // handle's helper stream and the Kuf strip build (device-filling, 0.3 ms at N = 65536) runs beside it, as in the Pdgp
   // engine (engine.hip: cond_batch_run); they meet before A' = W Kuf.  Event fork / join only: it records into a hipGraph.
   const bool forked = (N >= 4096) && gp_aux_fork(h);
+  auto build_kuf = [&]() -> gp_status {
+    gp_status st = GP_OK;
+    if (launch_kernel_build_sum(h, kerns.data(), feats.data(), p->P, Z, M, X, N, p->Kuf, ld, 0.0, f32, &st)) return st;
+    for (int i = 0; i < p->P; i++)
+      GP_CHECK(launch_kernel_build(h, kerns[i], Z, M, X, N, p->Kuf, ld, i > 0, 0.0, feats[i], 1, f32));
+    return GP_OK;
+  };
+  bool kuf_built = false;
   {
-    gp_status st = p->chol_blocked ? chol_inverse_blocked_run(h, M, M, p->chol_ws_kuu, p->chol_ws_bytes)
-                                   : launch_cholesky_inverse_single(h, p->L, p->W, M, M);
+    // A workgroup cluster where it takes the shape (chol_cluster.hip): all its 16 workgroups have to be resident to make
+    // progress, so it is enqueued FIRST and on the main stream, and the device-filling strip build takes the helper
+    // stream behind it (launched the other way round the cluster's workgroups waited for the build to drain: 0.62 ms
+    // instead of 0.36).  Otherwise one workgroup + blocked inverse, or one fused launch, on the helper stream.
+    gp_status st = GP_OK;
+    hipStream_t helper = h->stream;
+    if (forked) h->stream = h->main_stream_saved;
+    const bool cluster = launch_cholesky_cluster_single(h, p->L, p->W, M, M, 0, &st);
+    if (forked) h->stream = helper;
+    if (cluster) {
+      if (st == GP_OK) st = build_kuf();
+      kuf_built = true;
+    } else {
+      st = p->chol_blocked ? chol_inverse_blocked_run(h, M, M, p->chol_ws_kuu, p->chol_ws_bytes)
+                           : launch_cholesky_inverse_single(h, p->L, p->W, M, M);
+    }
     if (forked) { gp_status s2 = gp_aux_end(h); if (st == GP_OK) st = s2; }
     GP_CHECK(st);
   }
-  {
-    gp_status st = GP_OK;
-    if (launch_kernel_build_sum(h, kerns.data(), feats.data(), p->P, Z, M, X, N, p->Kuf, ld, 0.0, f32, &st)) GP_CHECK(st);
-    else
-      for (int i = 0; i < p->P; i++)
-        GP_CHECK(launch_kernel_build(h, kerns[i], Z, M, X, N, p->Kuf, ld, i > 0, 0.0, feats[i], 1, f32));
-  }
+  if (!kuf_built) GP_CHECK(build_kuf());
   GP_CHECK(gp_aux_join(h));
   { GemmFlags f; f.triA = TRI_LOWER; f.big_tiles = (M > 64); f.role = (M > 64) ? 1 : 0;   /* one row-block either way: the 64-tiles double the workgroups of a window-sized product */ f.timer = GP_TIMER_COND_A; f.epilogue = EPI_STORE | EPI_COLSUMSQ; f.uniform_aligned = 1;   /* one problem, arena buffers, ld = gp_strip_ld */ f.rows64_ok = wave_a ? 1 : 0;
     if (f32) { f.role = 1; GP_CHECK(launch_gemm_f32_role(h, desc->probs + 0, 1, M, N, f)); }
@@ -426,8 +442,12 @@ static gp_status sgpr_global(gp_sgpr_plan p, const double* params, int Ntotal, c
   gp_handle h = p->h;
   const int M = p->M;
   hipLaunchKernelGGL(sgpr_B_kernel, dim3(64), dim3(256), 0, h->stream, p->H, p->LB, M, params);
-  if (p->chol_blocked) GP_CHECK(chol_inverse_blocked_run(h, M, M, p->chol_ws_b, p->chol_ws_bytes));
-  else GP_CHECK(launch_cholesky_inverse_single(h, p->LB, p->WB, M, M));
+  {
+    gp_status st = GP_OK;
+    if (launch_cholesky_cluster_single(h, p->LB, p->WB, M, M, 0, &st)) GP_CHECK(st);
+    else if (p->chol_blocked) GP_CHECK(chol_inverse_blocked_run(h, M, M, p->chol_ws_b, p->chol_ws_bytes));
+    else GP_CHECK(launch_cholesky_inverse_single(h, p->LB, p->WB, M, M));
+  }
   hipLaunchKernelGGL(sgpr_c_kernel, dim3((M + 3) / 4), dim3(256), 0, h->stream, p->WB, p->u, p->c, M, params);
   hipLaunchKernelGGL(sgpr_finish_kernel, dim3(1), dim3(256), 0, h->stream, p->LB, p->c, M, Ntotal, params,
                      p->P, desc->toff, desc->ktype, desc->km, p->reg, p->scal);

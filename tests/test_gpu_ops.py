@@ -313,3 +313,49 @@ def test_conditional_full_cov_matches_oracle(gp_handle, kern, whiten, N, M, with
     # K(x, x) carries exp(-r(x, x)) with r(x, x) = sqrt(1e-12) (euclid_dist) where Kdiag is exact: the diagonals agree
     # to 1e-6 of the prior variance and no closer — in the reference too
     np.testing.assert_allclose(np.diag(fc[:, :, 0]), fv[:, 0], rtol=0, atol=3e-6 * max(np.abs(fv).max(), kern["variance"]))
+
+
+@pytest.mark.parametrize("M,ld", [(128, 128), (160, 164), (352, 352), (512, 520)])
+def test_cholesky_by_a_workgroup_cluster(gp_handle, M, ld):
+    """chol_cluster.hip (one matrix, 128 <= M <= 512, M % 32 == 0): factor in place with and without the inverse, three
+    launches in a row on the same buffers (the exchange flags carry the launch's epoch: nothing is cleared in between),
+    a row stride wider than the matrix, and a bad pivot in the middle of the chain"""
+    from gpitch_amd import _lib
+    h = gp_handle
+    rng = np.random.RandomState(M)
+    B = rng.randn(M, M)
+    K = B @ B.T / M + np.diag(0.5 + rng.rand(M))
+    Lref = np.linalg.cholesky(K)
+    A = np.zeros((M, ld))
+    for rep in range(3):
+        A[:, :M] = K * (1.0 + rep)
+        dA = h.to_device(A)
+        h.check(h.lib.gp_cholesky_inplace(h.h, dA.data_ptr(), M, ld))
+        L = dA.cpu().numpy()[:, :M]
+        assert np.all(np.triu(L, 1) == 0)
+        np.testing.assert_allclose(L, Lref * np.sqrt(1.0 + rep), rtol=0, atol=1e-12 * np.abs(Lref).max() * M)
+    if ld == M:         # the factor + inverse entry point builds its own Kuu: Matern-3/2 on a grid (cond ~ 1e6)
+        kern = KERNELS[1]
+        z = np.linspace(0, 2.0, M).reshape(-1, 1)
+        d, th = _desc(h, kern)
+        dz = h.to_device(z)
+        Ld, Wd = h.empty(M, M), h.empty(M, M)
+        ws = h.workspace(h.lib.gp_chol_workspace_bytes(M))
+        for rep in range(2):
+            h.check(h.lib.gp_kuu_cholesky(h.h, C.byref(d), dz.data_ptr(), M, 1e-6, Ld.data_ptr(), Wd.data_ptr(), ws.data_ptr(), ws.numel()))
+        Kuu = orc.K(kern, z, None) + 1e-6 * np.eye(M)
+        Lg, Wg = Ld.cpu().numpy(), Wd.cpu().numpy()
+        assert np.all(np.triu(Lg, 1) == 0) and np.all(np.triu(Wg, 1) == 0)
+        np.testing.assert_allclose(Lg @ Lg.T, Kuu, rtol=0, atol=1e-12 * np.abs(Kuu).max() * M)
+        np.testing.assert_allclose(Wg @ Lg, np.eye(M), rtol=0, atol=1e-8)
+    Kbad = K.copy()
+    Kbad[M // 2 + 3, M // 2 + 3] = -5.0
+    A[:, :M] = Kbad
+    dA = h.to_device(A)
+    st = h.lib.gp_cholesky_inplace(h.h, dA.data_ptr(), M, ld)
+    assert st == _lib.GP_ERR_NOT_PD
+    assert h.lib.gp_last_not_pd_index(h.h) == M // 2 + 3
+    A[:, :M] = K        # and the next launch on that buffer is clean again
+    dA.copy_(h.torch.as_tensor(A))
+    h.check(h.lib.gp_cholesky_inplace(h.h, dA.data_ptr(), M, ld))
+    np.testing.assert_allclose(dA.cpu().numpy()[:, :M], Lref, rtol=0, atol=1e-12 * np.abs(Lref).max() * M)
