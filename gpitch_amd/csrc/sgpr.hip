@@ -374,16 +374,30 @@ static gp_status sgpr_local(gp_sgpr_plan p, const double* params, const double* 
   { GemmProblem& r = probs[1]; r.A = p->A; r.lda = ld; r.B = p->A; r.ldb = ld; r.C = p->H; r.ldc = M; r.M = M; r.N = M; r.K = N; r.o2 = p->slabs;
     r.v2 = Y; r.o1 = p->upart; r.o0 = p->u; }      // u = A' y fused into the product's first tile column (slab_reduce sums the K-slices)
   { GemmProblem& r = probs[2]; r.A = p->A; r.lda = ld; r.M = M; r.N = N; r.v0 = Y; r.o0 = p->u; r.a_f32 = f32; }
-  GP_CHECK(sg_upload(p, probs, desc, 0));
   // Kuu, Kuf: GPflow Add kernel = sum over kern_list (sgpr_ss.py:42-43)
   // (all-Mercer sums of up to eight kernels are built in one pass per matrix: launch_kernel_build_sum)
   std::vector<DevKern> kerns(p->P);
   std::vector<double*> feats(p->P);
+  // the 2 P spectral-mixture feature tables (Z and X of every kernel) from ONE launch when the kernels share a padded partial
+  // count: ten 4-us launches with their gaps were 0.1 ms of a 3-ms evaluation
+  std::vector<FeatItem> fitems;
+  bool one_feat_launch = p->P > 1 && (size_t)2 * p->P * sizeof(FeatItem) <= SG_FIN_OFF - SG_EXTRA_OFF;
   for (int i = 0; i < p->P; i++) {
     kerns[i] = sg_kern(p, params, i);
     feats[i] = p->feat + (size_t)i * sgpr_feat_stride(p);
-    GP_CHECK(launch_sm_features(h, kerns[i], Z, M, X, N, feats[i]));
+    one_feat_launch = one_feat_launch && gp_kern_is_mercer(kerns[i].type) && sm_mpad(kerns[i].m) == sm_mpad(kerns[0].m);
   }
+  if (one_feat_launch)
+    for (int i = 0; i < p->P; i++) {
+      const int mp = sm_mpad(kerns[i].m);
+      fitems.push_back(FeatItem{kerns[i], Z, feats[i], M, 0});
+      fitems.push_back(FeatItem{kerns[i], X, feats[i] + gp_align_up((size_t)2 * mp * M, 32), N, 0});
+    }
+  GP_CHECK(sg_upload(p, probs, desc, 0, fitems.empty() ? nullptr : fitems.data(), fitems.size() * sizeof(FeatItem)));
+  if (one_feat_launch)
+    GP_CHECK(launch_sm_features_items(h, (const FeatItem*)(p->d_desc + SG_EXTRA_OFF), 2 * p->P, N > M ? N : M, sm_mpad(kerns[0].m), nullptr, 0));
+  else
+    for (int i = 0; i < p->P; i++) GP_CHECK(launch_sm_features(h, kerns[i], Z, M, X, N, feats[i]));
   {
     gp_status st = GP_OK;
     if (launch_kernel_build_sum(h, kerns.data(), feats.data(), p->P, Z, M, nullptr, M, p->L, M, p->jitter, 0, &st)) GP_CHECK(st);
