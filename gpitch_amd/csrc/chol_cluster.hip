@@ -217,7 +217,8 @@ __device__ __forceinline__ bool cc_lds_wait(int* flag, int atleast, int want, in
 
 template <bool WITH_W>
 __global__ void __launch_bounds__(CC_THREADS) chol_cluster_kernel(double* const* __restrict__ mats, double* const* __restrict__ Ws,
-                                                                  double* single_A, double* single_W, int M, int ld_,
+                                                                  const int* __restrict__ Ms, const int* __restrict__ lds_,
+                                                                  double* single_A, double* single_W, int single_M, int single_ld,
                                                                   char* scratch, int* __restrict__ status, int pivot_base) {
   // workgroup 0 only: the chain's tiles and what it hands to / takes from its courier
   __shared__ __attribute__((aligned(16))) double Dg[2][CC_T][CH_LDP];     // tile (s, s): in, and L(s, s) out, by parity of s
@@ -228,8 +229,8 @@ __global__ void __launch_bounds__(CC_THREADS) chol_cluster_kernel(double* const*
   const int mat = blockIdx.y;
   double* const A = mats ? mats[mat] : single_A;
   double* const W = WITH_W ? (Ws ? Ws[mat] : single_W) : nullptr;
-  const int64_t ld = ld_;
-  const int T = M / CC_T;
+  const int64_t ld = mats ? lds_[mat] : single_ld;
+  const int T = (mats ? Ms[mat] : single_M) / CC_T;
   int* const ctl = (int*)(scratch + (size_t)mat * CC_SCRATCH_BYTES);
   double* const dinv_g = (double*)((char*)ctl + CC_CTL_BYTES);
   const int lane = threadIdx.x & 63, lc = lane & 15, kq = lane >> 4;
@@ -551,10 +552,25 @@ bool launch_cholesky_cluster_single(gp_handle h, double* A, double* W, int M, in
   GpTimerScope ts(h, GP_TIMER_CHOL);
   if (W)
     hipLaunchKernelGGL(chol_cluster_kernel<true>, dim3(CC_G, 1), dim3(CC_THREADS), 0, h->stream, (double* const*)nullptr,
-                       (double* const*)nullptr, A, W, M, (int)ld, area, h->d_status, pivot_base);
+                       (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, A, W, M, (int)ld, area, h->d_status, pivot_base);
   else
     hipLaunchKernelGGL(chol_cluster_kernel<false>, dim3(CC_G, 1), dim3(CC_THREADS), 0, h->stream, (double* const*)nullptr,
-                       (double* const*)nullptr, A, (double*)nullptr, M, (int)ld, area, h->d_status, pivot_base);
+                       (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, A, (double*)nullptr, M, (int)ld, area, h->d_status,
+                       pivot_base);
+  *st = (hipGetLastError() == hipSuccess) ? GP_OK : gp_fail(h, GP_ERR_HIP, "chol_cluster_kernel launch failed");
+  return true;
+}
+
+// `count` matrices (device arrays of pointers, sizes and row strides; every size a multiple of 32 in [128, 512] — the caller
+// vouches for it, minM / maxM are its host copies of the range), factor and inverse of each by its own cluster, one launch
+bool launch_cholesky_cluster_batched(gp_handle h, double* const* d_mats, double* const* d_W, const int* d_M, const int* d_ld,
+                                     int count, int minM, int maxM, gp_status* st) {
+  if (!cholesky_cluster_takes(minM, count) || !cholesky_cluster_takes(maxM, count) || !d_mats || !d_W) return false;
+  char* area = cc_area(h, d_mats, count);
+  if (!area) return false;
+  GpTimerScope ts(h, GP_TIMER_CHOL);
+  hipLaunchKernelGGL(chol_cluster_kernel<true>, dim3(CC_G, count), dim3(CC_THREADS), 0, h->stream, d_mats, d_W, d_M, d_ld,
+                     (double*)nullptr, (double*)nullptr, 0, 0, area, h->d_status, 0);
   *st = (hipGetLastError() == hipSuccess) ? GP_OK : gp_fail(h, GP_ERR_HIP, "chol_cluster_kernel launch failed");
   return true;
 }

@@ -217,6 +217,8 @@ gp_status check_not_pd(gp_handle h);  // syncs; turns the device flag into GP_ER
 // not a launch the cluster takes (shape, switch, exchange area not allocatable inside a stream capture)
 bool cholesky_cluster_takes(int M, int count);
 bool launch_cholesky_cluster_single(gp_handle h, double* A, double* W, int M, int64_t ld, int pivot_base, gp_status* st);
+bool launch_cholesky_cluster_batched(gp_handle h, double* const* d_mats, double* const* d_W, const int* d_M, const int* d_ld,
+                                     int count, int minM, int maxM, gp_status* st);
 void cholesky_cluster_release(gp_handle h);
 
 // gemm.hip

@@ -259,6 +259,17 @@ static gp_status cond_batch_block_row_inverse(gp_handle h, CondBatch& cb) {
 // blocks below them as batched GEMMs.
 static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb, bool resident) {
   const int G = (int)cb.tasks.size();
+  {   // a few Kuu-sized matrices (one or two pitches: a pitch-sharded rank, BASELINE configs[1]): a workgroup cluster each,
+      // factor and inverse from one launch (chol_cluster.hip); the one-workgroup forms below keep G CUs busy for 0.7 ms
+    int minM = cb.maxM;
+    bool whole = true;
+    for (const CondTask& t : cb.tasks) { minM = t.M < minM ? t.M : minM; whole = whole && (t.M % 32) == 0; }
+    gp_status st = GP_OK;
+    if (whole && launch_cholesky_cluster_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs), (double* const*)(cb.d_desc + cb.off_w_ptrs),
+                                                 (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G, minM,
+                                                 cb.maxM, &st))
+      return st;
+  }
   if (!cb.blocked) {
     return launch_cholesky_inverse_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs),
                                            (double* const*)(cb.d_desc + cb.off_w_ptrs),
