@@ -28,7 +28,17 @@ GpTimerScope::~GpTimerScope() {
 bool gp_aux_fork(gp_handle h) {
   if (h->aux_active) return false;
   if (!h->aux_stream) {
-    if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) { h->aux_stream = nullptr; return false; }
+    // (aux_priority: the helper stream carries what the step's dependent chains wait for — the Kuu factorisation, the split-K
+    // product in front of the M x M chain — beside device-filling strip kernels of the main stream: its workgroups go first)
+    hipError_t ce;
+    if (gp_switches().aux_priority) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      ce = hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, hi);
+    } else {
+      ce = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+    }
+    if (ce != hipSuccess) { (void)hipGetLastError(); h->aux_stream = nullptr; return false; }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(h->aux_stream); h->aux_stream = nullptr;
@@ -579,7 +589,7 @@ const GpSwitches& gp_switches() {
     struct { const char* name; int* slot; } table[] = {
         {"strip_wave", &w.strip_wave}, {"strip_wave_f32", &w.strip_wave_f32}, {"strip_wave_roles", &w.strip_wave_roles}, {"strip_lean", &w.strip_lean},
         {"hyper_fuse", &w.hyper_fuse}, {"kufbar_split", &w.kufbar_split}, {"cond_a_early", &w.cond_a_early},
-        {"blocked_256", &w.blocked_256}, {"cov_sum", &w.cov_sum}, {"hyper_sum", &w.hyper_sum}, {"chol_cluster", &w.chol_cluster}};
+        {"blocked_256", &w.blocked_256}, {"cov_sum", &w.cov_sum}, {"hyper_sum", &w.hyper_sum}, {"chol_cluster", &w.chol_cluster}, {"aux_priority", &w.aux_priority}};
     std::string all(e);
     size_t pos = 0;
     while (pos < all.size()) {

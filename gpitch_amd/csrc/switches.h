@@ -17,11 +17,12 @@
 //   cov_sum           1      SGPRSS: the kernel sum K = sum_p K_p built in one pass (0: one accumulate launch per kernel)
 //   hyper_sum         1      SGPRSS: the P kernels' Kuf-side contractions in one pass over Kuf_bar
 //   chol_cluster      1      chol_cluster.hip: one M x M factor + inverse (128 <= M <= 512, M % 32 == 0) by a cluster of 16 workgroups (0: chol.hip)
+//   aux_priority      1      the handle's helper stream is created with the highest stream priority (0: default priority)
 //
 // Unknown names are reported once on stderr and ignored.
 #pragma once
 struct GpSwitches {
   int strip_wave = 1, strip_wave_f32 = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_wave_roles = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_lean = 1, hyper_fuse = 1, kufbar_split = 2,
-      cond_a_early = 1, blocked_256 = 1, cov_sum = 1, hyper_sum = 1, chol_cluster = 1;
+      cond_a_early = 1, blocked_256 = 1, cov_sum = 1, hyper_sum = 1, chol_cluster = 1, aux_priority = 1;
 };
 const GpSwitches& gp_switches();     // abi.hip
