@@ -33,10 +33,10 @@
 #define CC_T 32
 #define CC_MAXT 16                 // M <= 512
 #define CC_THREADS 256
-#define CC_G 17                    // workgroups per matrix: 66 workers, at most two tiles of L and two of W each (M = 512)
+#define CC_G_MAX 17                // workgroups per matrix at M = 512: 66 workers, at most two tiles of L and two of W each
 #define CC_LSLOTS 2
 #define CC_WSLOTS 2
-#define CC_MAX_WGS 68
+#define CC_MAX_WGS 128
 // control block (ints), then the published L_ss^-1 tiles (row-major 32 x 32 doubles each)
 #define CC_EPOCH 0
 #define CC_ARRIVE 1
@@ -538,9 +538,18 @@ static char* cc_area(gp_handle h, const void* key, int count) {
   return p;
 }
 
+// workgroups per matrix: enough workers that none owns more than CC_LSLOTS tiles of L and CC_WSLOTS of W
+static int cc_groups(int M) {
+  const int T = M / CC_T;
+  const int nl = T * (T + 1) / 2 - 5, nw = T * (T - 1) / 2;
+  const int wl = (nl + CC_LSLOTS - 1) / CC_LSLOTS, ww = (nw + CC_WSLOTS - 1) / CC_WSLOTS;
+  const int waves = 2 + (wl > ww ? wl : ww);
+  return (waves + 3) / 4;
+}
+
 bool cholesky_cluster_takes(int M, int count) {
   return gp_switches().chol_cluster != 0 && M >= 4 * CC_T && M <= CC_MAXT * CC_T && (M % CC_T) == 0 && count >= 1 &&
-         count * CC_G <= CC_MAX_WGS;
+         count * cc_groups(M) <= CC_MAX_WGS;
 }
 
 // A -> L in place (zeros above the diagonal) and, when W is given, W = L^-1 (zeros above the diagonal), one launch.
@@ -551,10 +560,10 @@ bool launch_cholesky_cluster_single(gp_handle h, double* A, double* W, int M, in
   if (!area) return false;
   GpTimerScope ts(h, GP_TIMER_CHOL);
   if (W)
-    hipLaunchKernelGGL(chol_cluster_kernel<true>, dim3(CC_G, 1), dim3(CC_THREADS), 0, h->stream, (double* const*)nullptr,
+    hipLaunchKernelGGL(chol_cluster_kernel<true>, dim3(CC_G_MAX, 1), dim3(CC_THREADS), 0, h->stream, (double* const*)nullptr,
                        (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, A, W, M, (int)ld, area, h->d_status, pivot_base);
   else
-    hipLaunchKernelGGL(chol_cluster_kernel<false>, dim3(CC_G, 1), dim3(CC_THREADS), 0, h->stream, (double* const*)nullptr,
+    hipLaunchKernelGGL(chol_cluster_kernel<false>, dim3(CC_G_MAX, 1), dim3(CC_THREADS), 0, h->stream, (double* const*)nullptr,
                        (double* const*)nullptr, (const int*)nullptr, (const int*)nullptr, A, (double*)nullptr, M, (int)ld, area, h->d_status,
                        pivot_base);
   *st = (hipGetLastError() == hipSuccess) ? GP_OK : gp_fail(h, GP_ERR_HIP, "chol_cluster_kernel launch failed");
@@ -569,7 +578,7 @@ bool launch_cholesky_cluster_batched(gp_handle h, double* const* d_mats, double*
   char* area = cc_area(h, d_mats, count);
   if (!area) return false;
   GpTimerScope ts(h, GP_TIMER_CHOL);
-  hipLaunchKernelGGL(chol_cluster_kernel<true>, dim3(CC_G, count), dim3(CC_THREADS), 0, h->stream, d_mats, d_W, d_M, d_ld,
+  hipLaunchKernelGGL(chol_cluster_kernel<true>, dim3(cc_groups(maxM), count), dim3(CC_THREADS), 0, h->stream, d_mats, d_W, d_M, d_ld,
                      (double*)nullptr, (double*)nullptr, 0, 0, area, h->d_status, 0);
   *st = (hipGetLastError() == hipSuccess) ? GP_OK : gp_fail(h, GP_ERR_HIP, "chol_cluster_kernel launch failed");
   return true;
