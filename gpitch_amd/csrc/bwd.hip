@@ -1806,7 +1806,14 @@ gp_status pdgp_backward(gp_pdgp_plan p, const double* params, const double* x, i
     bool any_fused = false;
     for (int fi = 0; fi < nfam; fi++) any_fused |= (ffuse[fi] != 0);
     int sm_fam = -1, other_fam = -1, sm_slot = -1, other_slot = -1;
-    const int split_mode = gp_switches().kufbar_split;   // (switches.h)
+    // (switches.h; -1 = by precision: with float32 strips the spectral-mixture family goes first — its vector-ALU contraction then runs
+    // beside the other family's float32 matrix product, which leaves the vector ALU free; the float64 MFMA holds it, so there the
+    // stationary family goes first.  cfg3 3.90 -> 3.80 ms, headline 19.47 / 19.56 the other way round)
+    int split_mode = gp_switches().kufbar_split;
+    if (split_mode < 0) {
+      split_mode = 2;
+      for (const auto& fam : p->hy_fams) if (fam.mfma && fam.f32) split_mode = 1;
+    }
     if (split_mode >= 1 && p->hy_fams.size() == 2 && forked && p->overlap >= 2) {
       for (int fi = 0; fi < 2; fi++) {
         if (p->hy_fams[fi].mfma) sm_fam = fi; else other_fam = fi;

@@ -11,7 +11,7 @@
 //   strip_wave_f32    46     gemm_wave_f32.hip: the same form for float32 strips, a bitmask 1 << role (0: gemm_strip_f32.hip / gemm_f32.hip)
 //   strip_lean        1      gemm_strip.hip / gemm_strip_f32.hip: the lean 128 x 128 LDS tiles (0: gemm.hip / gemm_f32.hip's)
 //   hyper_fuse        1      a stationary family's Kuf-side contraction as the epilogue of its Kuf_bar product
-//   kufbar_split      2      Kuf_bar per kernel family: 2 stationary family first, 1 spectral-mixture family first, 0 one launch
+//   kufbar_split     -1      Kuf_bar per kernel family: 2 stationary family first, 1 spectral-mixture family first, 0 one launch, -1: 1 with float32 strips, else 2
 //   cond_a_early      1      first row-block of A = W Kuf underneath the block-row inverse of the Kuu factorisation
 //   blocked_256       1      M in (128, 256] with long batches: resident factor + blocked inverse (0: one fused kernel)
 //   cov_sum           1      SGPRSS: the kernel sum K = sum_p K_p built in one pass (0: one accumulate launch per kernel)
@@ -22,7 +22,7 @@
 // Unknown names are reported once on stderr and ignored.
 #pragma once
 struct GpSwitches {
-  int strip_wave = 1, strip_wave_f32 = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_wave_roles = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_lean = 1, hyper_fuse = 1, kufbar_split = 2,
+  int strip_wave = 1, strip_wave_f32 = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_wave_roles = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_lean = 1, hyper_fuse = 1, kufbar_split = -1,
       cond_a_early = 1, blocked_256 = 1, cov_sum = 1, hyper_sum = 1, chol_cluster = 1, aux_priority = 1;
 };
 const GpSwitches& gp_switches();     // abi.hip

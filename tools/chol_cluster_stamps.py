@@ -45,12 +45,6 @@ def main():
         else:
             print("%3d %6d   (last)                                      | %6d %8d" % (s, r[1] - r[0], r[1] - r[0], r[0] - t0))
     print("chain total %d ticks" % (a[T - 1, 1] - t0))
-    print("workers: end of step s relative to the end of the chain's diagonal block s (ticks); min / median / max over workers")
-    for s in range(T):
-        v = wk[:, s][wk[:, s] > 0] - a[s, 1]
-        if v.size:
-            print("%3d  %8d %8d %8d   (%d workers)" % (s, v.min(), np.median(v), v.max(), v.size))
-    print("last worker done %d ticks after the chain's last publication" % (wk[wk > 0].max() - a[T - 1, 1]))
 
 
 if __name__ == "__main__":
