@@ -277,8 +277,11 @@ __device__ __forceinline__ void gwf_tile(const GemmProblem& p, const WaveF32Flag
 #undef GF_SB
 }
 
+#ifndef GWF_OCC
+#define GWF_OCC 3          // wavefronts per SIMD the register budget is cut for (168 VGPRs)
+#endif
 template <int TAG, int KT = -1>
-__global__ void __launch_bounds__(256, 3) gemm_wave_f32_kernel(const GemmProblem* __restrict__ probs, WaveF32Flags f) {
+__global__ void __launch_bounds__(256, GWF_OCC) gemm_wave_f32_kernel(const GemmProblem* __restrict__ probs, WaveF32Flags f) {
   __shared__ double etabs[(TAG == 5) ? 4 * 64 : 1];
   int bid = blockIdx.x, bz = blockIdx.z;
   {
