@@ -359,3 +359,45 @@ def test_cholesky_by_a_workgroup_cluster(gp_handle, M, ld):
     dA.copy_(h.torch.as_tensor(A))
     h.check(h.lib.gp_cholesky_inplace(h.h, dA.data_ptr(), M, ld))
     np.testing.assert_allclose(dA.cpu().numpy()[:, :M], Lref, rtol=0, atol=1e-12 * np.abs(Lref).max() * M)
+
+
+def test_concurrent_clusters_on_separate_handles():
+    """four host threads, each with its own handle and stream, factorising (and inverting) 512 x 512 matrices at the same
+    time: the clusters' exchange areas are per (handle, matrix), their workgroups share the device"""
+    import threading
+    import torch
+    from gpitch_amd import _lib
+    M, nthreads, reps = 512, 4, 6
+    kern = KERNELS[1]
+    z = np.linspace(0, 2.0, M).reshape(-1, 1)
+    Kuu = orc.K(kern, z, None) + 1e-6 * np.eye(M)
+    Lref = np.linalg.cholesky(Kuu)
+    errs = [None] * nthreads
+
+    def work(t):
+        try:
+            dev = _lib.default_handle().device
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                h = _lib.Handle(dev.index, stream=stream)
+                d, th = _desc(h, kern)
+                dz = h.to_device(z)
+                L, W = h.empty(M, M), h.empty(M, M)
+                ws = h.workspace(h.lib.gp_chol_workspace_bytes(M))
+                worst = 0.0
+                for _ in range(reps):
+                    h.check(h.lib.gp_kuu_cholesky(h.h, C.byref(d), dz.data_ptr(), M, 1e-6, L.data_ptr(), W.data_ptr(), ws.data_ptr(), ws.numel()))
+                    Lg, Wg = L.cpu().numpy(), W.cpu().numpy()
+                    worst = max(worst, np.abs(Lg - Lref).max() / np.abs(Lref).max(), np.abs(Wg @ Lg - np.eye(M)).max())
+                errs[t] = worst
+        except Exception as e:      # noqa: BLE001
+            errs[t] = e
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th_ in ths:
+        th_.start()
+    for th_ in ths:
+        th_.join()
+    for e in errs:
+        assert not isinstance(e, Exception), e
+        assert e is not None and e <= 1e-7, errs
