@@ -92,8 +92,10 @@ __device__ __noinline__ void chol_diag_block(PT A, int64_t ld, int M, int k0, in
       v[j + 1] = fma(-nv, lane_bcast(nv, j + 1), v[j + 1]);
       pivot(j + 1);
     }
+#ifndef CH_DIAG_PROBE_NO_UPDATES        // (timing probe only: wrong results)
 #pragma unroll
     for (int c = j + 2; c < CH_NB; c++) v[c] = fma(-nv, lane_bcast(nv, c), v[c]);   // lane c (low half) holds L_cj
+#endif
   }
   if (bad >= 0 && lane == 0) {
     if (atomicCAS(&status[0], 0, 1) == 0) { status[1] = pbase + k0 + bad; status[2] = b; }
