@@ -257,13 +257,22 @@ static gp_status cond_batch_block_row_inverse(gp_handle h, CondBatch& cb) {
 // factor comes from ONE launch, one workgroup per matrix, started before the strip builds and resident beside them;
 // the inverse (by then the builds are ending) goes the blocked way: all diagonal 128-blocks in one launch, the
 // blocks below them as batched GEMMs.
+// the Kuu batch is one the workgroup-cluster factorisation takes (sizes whole tiles, few enough workgroups)
+static bool cond_batch_cluster_shape(const CondBatch& cb, int* min_m) {
+  int minM = cb.maxM;
+  bool whole = true;
+  for (const CondTask& t : cb.tasks) { minM = t.M < minM ? t.M : minM; whole = whole && (t.M % 32) == 0; }
+  *min_m = minM;
+  const int G = (int)cb.tasks.size();
+  return whole && cholesky_cluster_takes(minM, G) && cholesky_cluster_takes(cb.maxM, G);
+}
+
 static gp_status cond_batch_factorize(gp_handle h, CondBatch& cb, bool resident) {
   const int G = (int)cb.tasks.size();
-  {   // a few Kuu-sized matrices (one or two pitches: a pitch-sharded rank, BASELINE configs[1]): a workgroup cluster each,
-      // factor and inverse from one launch (chol_cluster.hip); the one-workgroup forms below keep G CUs busy for 0.7 ms
+  {   // a few Kuu-sized matrices (one or two pitches: a pitch-sharded rank, BASELINE configs[1]; cfg3's 24 of 256 rows): a workgroup
+      // cluster each, factor and inverse from one launch (chol_cluster.hip); the one-workgroup forms below keep G CUs busy for 0.7 ms
     int minM = cb.maxM;
-    bool whole = true;
-    for (const CondTask& t : cb.tasks) { minM = t.M < minM ? t.M : minM; whole = whole && (t.M % 32) == 0; }
+    const bool whole = cond_batch_cluster_shape(cb, &minM);
     gp_status st = GP_OK;
     if (whole && launch_cholesky_cluster_batched(h, (double* const*)(cb.d_desc + cb.off_chol_ptrs), (double* const*)(cb.d_desc + cb.off_w_ptrs),
                                                  (const int*)(cb.d_desc + cb.off_Ms), (const int*)(cb.d_desc + cb.off_lds), G, minM,
@@ -391,7 +400,10 @@ gp_status cond_batch_run(gp_handle h, CondBatch& cb, const double* x, int N, boo
     st = build_kuu();
     // The Kuf builds (main stream) start only once the Kuu builds are through, i.e. together with the factorisation
     // launch: its workgroups must be on their CUs before the strip builds fill the device.
-    if (forked && resident && st == GP_OK) {
+    // (not with the cluster factorisation: its launch is short and early builds pay more than its workgroups' wait costs —
+    // cfg3 3.82 -> 3.76 ms; with the one-workgroup kernels the wait stays: headline 19.4 against 19.4 - 19.7 without it)
+    int min_m_unused = 0;
+    if (forked && resident && st == GP_OK && !cond_batch_cluster_shape(cb, &min_m_unused)) {
       if (!h->ev_kuu && hipEventCreateWithFlags(&h->ev_kuu, hipEventDisableTiming) != hipSuccess) h->ev_kuu = nullptr;
       if (h->ev_kuu && hipEventRecord(h->ev_kuu, h->stream) == hipSuccess)
         (void)hipStreamWaitEvent(h->main_stream_saved, h->ev_kuu, 0);
