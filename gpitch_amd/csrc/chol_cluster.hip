@@ -6,24 +6,28 @@
 // the inverse): half of that is the serial chain of 32 x 32 diagonal blocks, the other half the trailing updates that
 // the same CU has to fit around it.  Here the chain gets a wavefront of its own and everything else is dataflow:
 //
-//   * 32 x 32 tiles; G workgroups of four wavefronts (one per SIMD) per matrix.  Wavefront 0 of workgroup 0 is the
-//     CHAIN: for s = 0 .. T-1 it factorises tile (s, s) in registers (chol_diag_block), publishes L_ss^-1, solves the tile
-//     below it, L(s+1, s), and applies the last two updates to tiles (s+1, s) and (s+1, s+1) itself.
-//   * every other wavefront is a WORKER that owns up to three tiles of L and two of W, held in MFMA accumulators for
+//   * 32 x 32 tiles; G workgroups of four wavefronts (one per SIMD) per matrix, G by the tile count (17 at M = 512, 5 at 256, 2 at
+//     128).  Wavefront 0 of workgroup 0 is the CHAIN: for s = 0 .. T-1 it factorises tile (s, s) in registers
+//     (chol_diag_block), solves the tile below it, L(s+1, s), and applies the last update to tile (s+1, s+1) — on LDS and
+//     registers only.  Wavefront 1 is its COURIER: it fetches tiles (s+1, s) and (s+1, s+1) as the workers left them, adds the
+//     update of column s-1 and leaves them in LDS for the chain; it publishes L_ss^-1, L(s, s), W(s, s) and L(s+1, s).
+//   * every other wavefront is a WORKER that owns up to two tiles of L and two of W, held in MFMA accumulators for
 //     the whole factorisation (right-looking: when column s of L is known, every owned tile right of it takes its
 //     update; a tile of column s is solved against L_ss^-1 and published).  Tiles (k, k-1) and (k, k) are handed to the
-//     chain two columns early, so the chain never waits for an exchange that started in its own period.
+//     courier two columns early, so the chain never waits for an exchange that started in its own period.
 //   * W follows in the shadow of the chain: S(i, j) = sum_k L(i, k) W(k, j) accumulates as rows of W are published,
 //     W(i, j) = -L_ii^-1 S(i, j) when L_ii^-1 is.
 //   * exchange through memory: every exchanged value is stored and loaded with agent-scope relaxed atomics (sc1: written
 //     through / read past the XCD's L2 — no cache write-back or invalidate, which would also flush the strips other
 //     kernels are writing), a flag per tile announces it (store data, s_waitcnt vmcnt(0), store flag; poll flag, load
 //     data).  Flags hold the launch's epoch + 1: nothing is cleared between launches, the last wavefront to finish bumps
-//     the epoch (so a recorded launch sequence replays without a memset node).
+//     the epoch (so a recorded launch sequence replays without a memset node).  Inside workgroup 0 the chain and its courier
+//     hand over through counters in LDS.
 //   * every wait is bounded: after ~2 s of polling a wavefront raises the cluster's abort word, all others leave their
 //     loops at their next check, and the launch reports GP_ERR_HIP through the status word instead of hanging the GPU.
 //     All wavefronts of a cluster must be resident for it to make progress: the launcher only takes launches of at most
-//     CC_MAX_WGS workgroups (a 256-CU device holds 512 of them), everything else goes to chol.hip.
+//     CC_MAX_WGS workgroups (a 256-CU device holds 256 of them at this kernel's register count), everything else goes to
+//     chol.hip.  DESIGN.md section 3.01 has the measurements.
 #include "common.h"
 #include "switches.h"
 #include "chol_diag.h"
