@@ -621,6 +621,12 @@ gp_status launch_gemm_batched(gp_handle h, const GemmProblem* d_probs, int batch
   if (f.role == 2) return launch_one<128, 128, true, false, 2>(h, d_probs, batch, maxM, maxN, df, 1);
   if (f.role == 3) return launch_one<128, 128, false, false, 3>(h, d_probs, batch, maxM, maxN, df, 1);
   if (f.big_tiles) return dispatch_trans<128>(h, d_probs, batch, maxM, maxN, f, df, 1);
+  // a launch that would not put a 64 x 64 workgroup on every CU (one or two Kuu-sized problems: the dependent M x M chains of an
+  // SGPRSS evaluation or of a one-pitch model) takes 32 x 32 tiles: four times the workgroups, a quarter of the K loop's work each
+  // (plain products only: the column-sum epilogues' partial rows are laid out per 64-row block)
+  if (gp_switches().gemm_tile32 && f.role == 0 && f.epilogue == EPI_STORE && f.tile_m0 == 0 && f.tile_mcount == 0 && maxM >= 64 && maxN >= 64 &&
+      (int64_t)batch * ((maxM + 63) / 64) * ((maxN + 63) / 64) < (int64_t)gp_switches().gemm_tile32)
+    return dispatch_trans<32>(h, d_probs, batch, maxM, maxN, f, df, 1);
   return dispatch_trans<64>(h, d_probs, batch, maxM, maxN, f, df, 1);
 }
 
