@@ -16,7 +16,7 @@
 //   blocked_256       1      M in (128, 256] with long batches: resident factor + blocked inverse (0: one fused kernel)
 //   cov_sum           1      SGPRSS: the kernel sum K = sum_p K_p built in one pass (0: one accumulate launch per kernel)
 //   hyper_sum         1      SGPRSS: the P kernels' Kuf-side contractions in one pass over Kuf_bar
-//   chol_cluster      1      chol_cluster.hip: one M x M factor + inverse (128 <= M <= 512, M % 32 == 0) by a cluster of 16 workgroups (0: chol.hip)
+//   chol_cluster      1      chol_cluster.hip: M x M factor + inverse (128 <= M <= 512, M % 32 == 0) by a cluster of 17 / 5 / 2 workgroups per matrix, up to 128 per launch (0: chol.hip)
 //   aux_priority      1      the handle's helper stream is created with the highest stream priority (0: default priority)
 //   gemm_tile32       320    generic M x M products with fewer 64 x 64 tiles than this in the launch take 32 x 32 tiles (0: never)
 //
