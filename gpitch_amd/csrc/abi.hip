@@ -589,7 +589,7 @@ const GpSwitches& gp_switches() {
     struct { const char* name; int* slot; } table[] = {
         {"strip_wave", &w.strip_wave}, {"strip_wave_f32", &w.strip_wave_f32}, {"strip_wave_roles", &w.strip_wave_roles}, {"strip_lean", &w.strip_lean},
         {"hyper_fuse", &w.hyper_fuse}, {"kufbar_split", &w.kufbar_split}, {"cond_a_early", &w.cond_a_early},
-        {"blocked_256", &w.blocked_256}, {"cov_sum", &w.cov_sum}, {"hyper_sum", &w.hyper_sum}, {"chol_cluster", &w.chol_cluster}, {"aux_priority", &w.aux_priority}, {"gemm_tile32", &w.gemm_tile32}};
+        {"blocked_256", &w.blocked_256}, {"cov_sum", &w.cov_sum}, {"hyper_sum", &w.hyper_sum}, {"chol_cluster", &w.chol_cluster}, {"aux_priority", &w.aux_priority}, {"gemm_tile32", &w.gemm_tile32}, {"nt_cover", &w.nt_cover}};
     std::string all(e);
     size_t pos = 0;
     while (pos < all.size()) {

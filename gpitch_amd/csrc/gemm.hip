@@ -635,7 +635,10 @@ int gemm_nt_nsplit(int M, int Nlong, int batch) {
   // slice >= 512 deep; fewer slices = less slab traffic
   int tiles = ((M + 127) / 128);
   tiles = tiles * (tiles + 1) / 2 * (batch > 0 ? batch : 1);
-  int want = (2048 + tiles - 1) / tiles;
+  // (coverage target: 2048 workgroups for the long batches; short ones — a few latent GPs, cfg3's 72 tiles — sit on the step's
+  // critical chain with their slab reduction behind them and come out 0.5 - 1.5 % ahead with half the slices: nt_cover = 0 picks)
+  const int cover = gp_switches().nt_cover > 0 ? gp_switches().nt_cover : (tiles < 128 ? 1024 : 2048);
+  int want = (cover + tiles - 1) / tiles;
   int maxs = (Nlong + 511) / 512;
   // a window-sized problem (one tile, a few thousand frames) would be 4 workgroups of 32 K-tiles each: latency, not
   // throughput — slices down to 128 deep then

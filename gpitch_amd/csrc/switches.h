@@ -19,11 +19,12 @@
 //   chol_cluster      1      chol_cluster.hip: M x M factor + inverse (128 <= M <= 512, M % 32 == 0) by a cluster of 17 / 5 / 2 workgroups per matrix, up to 128 per launch (0: chol.hip)
 //   aux_priority      1      the handle's helper stream is created with the highest stream priority (0: default priority)
 //   gemm_tile32       320    generic M x M products with fewer 64 x 64 tiles than this in the launch take 32 x 32 tiles (0: never)
+//   nt_cover          0      split-K product: workgroups the K-slices are chosen to cover (0: 1024 below 128 output tiles in the launch, else 2048)
 //
 // Unknown names are reported once on stderr and ignored.
 #pragma once
 struct GpSwitches {
   int strip_wave = 1, strip_wave_f32 = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_wave_roles = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5), strip_lean = 1, hyper_fuse = 1, kufbar_split = -1,
-      cond_a_early = 1, blocked_256 = 1, cov_sum = 1, hyper_sum = 1, chol_cluster = 1, aux_priority = 1, gemm_tile32 = 320;
+      cond_a_early = 1, blocked_256 = 1, cov_sum = 1, hyper_sum = 1, chol_cluster = 1, aux_priority = 1, gemm_tile32 = 320, nt_cover = 0;
 };
 const GpSwitches& gp_switches();     // abi.hip
