@@ -533,14 +533,39 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const GemmProblem* __r
                                                           double alpha) {
   const GemmProblem p = probs[blockIdx.z];
   const int64_t total = (int64_t)p.M * p.N;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+  // two adjacent elements per thread (16-byte loads) when the rows allow it, four slabs in flight per accumulator set: the
+  // slabs are read once, in a fixed order per element (the sum's association is k = 0, 4, 8, .. | 1, 5, .. | .. then the four)
+  const bool pair = ((p.N & 1) == 0) && ((((uintptr_t)p.o2) & 15) == 0) && ((total & 1) == 0);
+  const int64_t step = pair ? 2 : 1;
+  for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * step; idx < total; idx += (int64_t)gridDim.x * blockDim.x * step) {
     const int i = (int)(idx / p.N), j = (int)(idx % p.N);
     if (sym && j > i) continue;
-    double s = 0.0;
-    for (int k = 0; k < nsplit; k++) s += p.o2[(int64_t)k * total + idx];
-    s *= alpha;
-    p.C[(int64_t)i * p.ldc + j] = s;
-    if (sym && j < i) p.C[(int64_t)j * p.ldc + i] = s;
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* src = p.o2 + idx;
+    int k = 0;
+    if (pair) {
+      for (; k + 4 <= nsplit; k += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const dbl2 v = *(const dbl2*)(src + (int64_t)(k + q) * total); s0[q] += v.x; s1[q] += v.y; }
+      }
+      for (; k < nsplit; k++) { const dbl2 v = *(const dbl2*)(src + (int64_t)k * total); s0[0] += v.x; s1[0] += v.y; }
+    } else {
+      for (; k + 4 <= nsplit; k += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) s0[q] += src[(int64_t)(k + q) * total];
+      }
+      for (; k < nsplit; k++) s0[0] += src[(int64_t)k * total];
+    }
+    const double a = ((s0[0] + s0[1]) + (s0[2] + s0[3])) * alpha;
+    p.C[(int64_t)i * p.ldc + j] = a;
+    if (sym && j < i) p.C[(int64_t)j * p.ldc + i] = a;
+    if (pair) {
+      const double b = ((s1[0] + s1[1]) + (s1[2] + s1[3])) * alpha;
+      if (!(sym && j + 1 > i)) {
+        p.C[(int64_t)i * p.ldc + j + 1] = b;
+        if (sym && j + 1 < i) p.C[(int64_t)(j + 1) * p.ldc + i] = b;
+      }
+    }
   }
   if (p.v2 && p.o1 && blockIdx.x == 0) {   // u = sum over K-slices of the fused row-dot partials; o0 = u, v0 += u
     for (int i = threadIdx.x; i < p.M; i += blockDim.x) {
@@ -674,7 +699,8 @@ gp_status launch_gemm_nt_reduce_batched(gp_handle h, const GemmProblem* d_probs,
 
 gp_status launch_slab_reduce(gp_handle h, const GemmProblem* d_probs, int batch, int maxM, int nsplit, int sym, double alpha) {
   GpTimerScope ts(h, GP_TIMER_SMALL_GEMM);
-  int blocks = (int)(((int64_t)maxM * maxM + 255) / 256);
+  int blocks = (int)(((int64_t)maxM * maxM / 2 + 255) / 256);      // (two elements per thread where rows are even)
+  if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1, batch), dim3(256), 0, h->stream, d_probs, nsplit, sym, alpha);
   GP_HIP_CHECK(h, hipGetLastError());
