@@ -401,3 +401,22 @@ def test_concurrent_clusters_on_separate_handles():
     for e in errs:
         assert not isinstance(e, Exception), e
         assert e is not None and e <= 1e-7, errs
+
+
+def test_cluster_factorisation_at_every_tile_count(gp_handle):
+    """every size the workgroup cluster takes (M = 128, 160, .. 512: 4 .. 16 tiles a side, 2 .. 17 workgroups): factor and
+    inverse of a Matern-3/2 Kuu against numpy"""
+    h = gp_handle
+    kern = KERNELS[1]
+    for M in range(128, 513, 32):
+        z = np.linspace(0, 2.0, M).reshape(-1, 1)
+        d, th = _desc(h, kern)
+        dz = h.to_device(z)
+        Ld, Wd = h.empty(M, M), h.empty(M, M)
+        ws = h.workspace(h.lib.gp_chol_workspace_bytes(M))
+        h.check(h.lib.gp_kuu_cholesky(h.h, C.byref(d), dz.data_ptr(), M, 1e-6, Ld.data_ptr(), Wd.data_ptr(), ws.data_ptr(), ws.numel()))
+        Kuu = orc.K(kern, z, None) + 1e-6 * np.eye(M)
+        Lg, Wg = Ld.cpu().numpy(), Wd.cpu().numpy()
+        assert np.all(np.triu(Lg, 1) == 0) and np.all(np.triu(Wg, 1) == 0), M
+        np.testing.assert_allclose(Lg @ Lg.T, Kuu, rtol=0, atol=1e-12 * np.abs(Kuu).max() * M, err_msg=str(M))
+        np.testing.assert_allclose(Wg @ Lg, np.eye(M), rtol=0, atol=1e-8, err_msg=str(M))
