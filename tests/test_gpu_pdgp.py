@@ -747,3 +747,29 @@ def test_gp_sharded_adam_steps_follow_the_unsharded_model(gp_handle):
                                        (full.q_mu_act if act else full.q_mu_com)[i].value, rtol=0, atol=1e-11)
             np.testing.assert_allclose((s.q_sqrt_act if act else s.q_sqrt_com)[i].value,
                                        (full.q_sqrt_act if act else full.q_sqrt_com)[i].value, rtol=0, atol=1e-11)
+
+
+def test_cluster_factorisation_with_two_inducing_set_sizes(gp_handle):
+    """activation GPs on 192 inducing points, component GPs on 128 (both whole 32-row tiles, N >= 4096: the Kuu batch of four
+    matrices of two sizes takes the workgroup-cluster factorisation, workgroups per matrix by the larger size): ELBO and
+    gradient against the oracle"""
+    from gpitch_amd.synth import make_problem, uniform_inducing
+    N, P, m = 4608, 2, 3
+    prob = make_problem(N, 192, P, num_partials=m, seed=5)
+    rq = np.random.RandomState(11)
+    Mc = 128
+    prob["zc"] = [uniform_inducing(prob["x"], Mc) for _ in range(P)]
+    prob["q_mu_com"] = [0.3 * rq.randn(Mc, 1) for _ in range(P)]
+    prob["q_sqrt_com"] = [np.tril(np.eye(Mc) + 0.05 * rq.randn(Mc, Mc))[:, :, None] for _ in range(P)]
+    model = pdgp_from_problem(prob, handle=gp_handle)
+    model._pack()
+    f = model._elbo(True)
+    ref_f, ref_g = oracle_elbo_and_grads(prob)
+    assert abs(f - ref_f) <= ELBO_RTOL * abs(ref_f), (f, ref_f)
+    got_g = model_grad_dict(model)
+    for name, rg in ref_g.items():
+        gg = got_g[name]
+        if name.startswith("q_sqrt"):
+            rg = np.tril(rg[:, :, 0])[:, :, None]
+        scale = max(np.abs(rg).max(), 1e-12)
+        np.testing.assert_allclose(gg.reshape(rg.shape), rg, rtol=0, atol=2e-7 * scale, err_msg=name)
