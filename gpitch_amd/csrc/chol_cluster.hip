@@ -33,6 +33,7 @@
 #include "chol_diag.h"
 #include <map>
 #include <mutex>
+#include <vector>
 
 #define CC_T 32
 #define CC_MAXT 16                 // M <= 512
@@ -515,7 +516,12 @@ __global__ void __launch_bounds__(CC_THREADS) chol_cluster_kernel(double* const*
 struct CcPool {
   std::mutex mu;
   std::map<std::pair<gp_handle, const void*>, std::pair<char*, int>> areas;
+  std::vector<std::pair<gp_handle, const void*>> order;       // allocation order, for the cap below
+  std::map<std::pair<gp_handle, const void*>, bool> pinned;   // handed to a launch that was being recorded: lives as long as the handle
 };
+// a process that keeps creating plans (a model per window, each with a workspace of its own) would otherwise collect one
+// 133-KB area per matrix address it has ever factorised: past this many areas the older half is released
+#define CC_POOL_CAP 64
 static CcPool& cc_pool() { static CcPool p; return p; }
 
 void cholesky_cluster_release(gp_handle h) {
@@ -525,20 +531,44 @@ void cholesky_cluster_release(gp_handle h) {
     if (it->first.first == h) { (void)hipFree(it->second.first); it = P.areas.erase(it); }
     else ++it;
   }
+  for (auto it = P.order.begin(); it != P.order.end();) it = (it->first == h) ? P.order.erase(it) : it + 1;
+  for (auto it = P.pinned.begin(); it != P.pinned.end();) it = (it->first.first == h) ? P.pinned.erase(it) : std::next(it);
 }
 
 static char* cc_area(gp_handle h, const void* key, int count) {
   CcPool& P = cc_pool();
   std::lock_guard<std::mutex> g(P.mu);
   auto it = P.areas.find({h, key});
-  if (it != P.areas.end() && it->second.second >= count) return it->second.first;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (h->stream && hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
-  if (it != P.areas.end()) { (void)hipStreamSynchronize(h->stream); (void)hipFree(it->second.first); P.areas.erase(it); }
+  const bool capturing = h->stream && hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (it != P.areas.end() && it->second.second >= count) {
+    if (capturing) P.pinned[{h, key}] = true;        // the recorded launch keeps this address
+    return it->second.first;
+  }
+  if (capturing) return nullptr;
+  if (it != P.areas.end()) {
+    (void)hipStreamSynchronize(h->stream); (void)hipFree(it->second.first); P.areas.erase(it);
+    for (auto o = P.order.begin(); o != P.order.end();) o = (*o == std::make_pair(h, key)) ? P.order.erase(o) : o + 1;
+  }
+  if (P.order.size() >= CC_POOL_CAP + P.pinned.size()) {      // (not capturing here: the whole device may be drained)
+    (void)hipDeviceSynchronize();
+    std::vector<std::pair<gp_handle, const void*>> keep;
+    for (size_t q = 0; q < P.order.size(); q++) {
+      const bool old_half = q < CC_POOL_CAP / 2;
+      if (old_half && !P.pinned.count(P.order[q])) {
+        auto old = P.areas.find(P.order[q]);
+        if (old != P.areas.end()) { (void)hipFree(old->second.first); P.areas.erase(old); }
+      } else {
+        keep.push_back(P.order[q]);
+      }
+    }
+    P.order.swap(keep);
+  }
   char* p = nullptr;
   if (hipMalloc(&p, (size_t)count * CC_SCRATCH_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   if (hipMemset(p, 0, (size_t)count * CC_SCRATCH_BYTES) != hipSuccess) { (void)hipFree(p); (void)hipGetLastError(); return nullptr; }
   P.areas[{h, key}] = {p, count};
+  P.order.push_back({h, key});
   return p;
 }
 

@@ -420,3 +420,23 @@ def test_cluster_factorisation_at_every_tile_count(gp_handle):
         assert np.all(np.triu(Lg, 1) == 0) and np.all(np.triu(Wg, 1) == 0), M
         np.testing.assert_allclose(Lg @ Lg.T, Kuu, rtol=0, atol=1e-12 * np.abs(Kuu).max() * M, err_msg=str(M))
         np.testing.assert_allclose(Wg @ Lg, np.eye(M), rtol=0, atol=1e-8, err_msg=str(M))
+
+
+def test_cluster_exchange_areas_are_capped(gp_handle):
+    """150 different matrix buffers factorised through the cluster on one handle: the exchange areas (one per matrix address)
+    are released in halves past 64, results stay right before and after"""
+    h = gp_handle
+    M = 128
+    rng = np.random.RandomState(1)
+    B = rng.randn(M, M)
+    K = B @ B.T / M + np.eye(M)
+    Lref = np.linalg.cholesky(K)
+    bufs = []
+    for rep in range(150):
+        dA = h.to_device(K)
+        bufs.append(dA)              # (kept alive: every buffer is a new address)
+        h.check(h.lib.gp_cholesky_inplace(h.h, dA.data_ptr(), M, M))
+        if rep % 37 == 0 or rep == 149:
+            np.testing.assert_allclose(dA.cpu().numpy(), Lref, rtol=0, atol=1e-12 * M)
+    h.check(h.lib.gp_cholesky_inplace(h.h, bufs[0].copy_(h.torch.as_tensor(K)).data_ptr(), M, M))     # an evicted address again
+    np.testing.assert_allclose(bufs[0].cpu().numpy(), Lref, rtol=0, atol=1e-12 * M)
