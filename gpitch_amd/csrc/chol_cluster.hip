@@ -566,7 +566,11 @@ static char* cc_area(gp_handle h, const void* key, int count) {
   }
   char* p = nullptr;
   if (hipMalloc(&p, (size_t)count * CC_SCRATCH_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (hipMemset(p, 0, (size_t)count * CC_SCRATCH_BYTES) != hipSuccess) { (void)hipFree(p); (void)hipGetLastError(); return nullptr; }
+  // zeroed ON the handle's stream and waited for: a memset on the null stream is not ordered against a non-blocking stream, and
+  // recycled device memory is not zero — the first launch then read a stale epoch in some wavefronts and a cleared one in others
+  if (hipMemsetAsync(p, 0, (size_t)count * CC_SCRATCH_BYTES, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+    (void)hipFree(p); (void)hipGetLastError(); return nullptr;
+  }
   P.areas[{h, key}] = {p, count};
   P.order.push_back({h, key});
   return p;
