@@ -110,11 +110,12 @@ def _torch_bound_and_grads(X, Y, Z, kl, noise, reg=False):
 
 
 @pytest.mark.parametrize("N,M,P,reg,npart", [(300, 16, 1, False, 2), (1200, 48, 3, True, 2), (1100, 40, 5, False, 4),
-                                             (900, 32, 3, False, 6)])
+                                             (900, 32, 3, False, 6), (1500, 96, 2, False, 3), (4500, 160, 2, True, 2)])
 def test_sgpr_gradient_matches_autograd(gp_handle, N, M, P, reg, npart):
     """P >= 2 Mercer kernels: Kuu / Kuf of the sum come from one pass (cov_mercer_sum_kernel: padded partial counts 4 and
     8) and, with at most four partials per kernel, the Kuf-side contractions of all kernels from one pass over Kuf_bar
-    (hyper_contract_sum_kernel); six partials take the per-kernel contraction"""
+    (hyper_contract_sum_kernel); six partials take the per-kernel contraction; M = 96 / 160: the M x M chain's products on 32 x 32
+    tiles (gemm_tile32), M = 160 with N >= 4096 also the cluster factorisation of Kuu and B"""
     X, Y, Z, kl = _problem(N, M, P, N + 1, npart)
     m = _model(X, Y, Z, kl, 0.3, gp_handle, reg=reg)
     m._compile(); m._pack()
