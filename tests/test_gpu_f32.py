@@ -410,3 +410,21 @@ def test_fallback_strip_forms_keep_parity(switches):
     r = subprocess.run([sys.executable, "-m", "pytest", target, "-q", "-m", "gpu", "-x",
                         "-k", "elbo or gradient or fused or overlap_levels"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
+def test_float32_wave_kernels_are_reproducible_run_to_run(gp_handle):
+    """the float32 strip products in the wave form (gemm_wave_f32.hip) at BASELINE configs[2]'s tile grid (N = 32768, M = 256),
+    helper-stream overlap on: 25 evaluations of the same ELBO and gradient agree bit for bit (the 16-byte strip stores go
+    out from distinct payload registers: a torn store would show here)"""
+    from gpitch_amd.synth import make_problem
+    prob = make_problem(32768, 256, 3, num_partials=5, seed=2)
+    model = _model(prob, gp_handle)
+    model._pack()
+    f0 = model._elbo(True)
+    g0 = {k: v.copy() for k, v in model_grad_dict(model).items()}
+    for _ in range(24):
+        f = model._elbo(True)
+        assert f == f0
+        g = model_grad_dict(model)
+        for k in g0:
+            np.testing.assert_array_equal(g[k], g0[k], err_msg=k)
